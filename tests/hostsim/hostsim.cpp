@@ -1,0 +1,105 @@
+// TEST HARNESS ONLY.  Compiles the device headers of threshold_crypto_amd/csrc with g++ so
+// the per-lane job bodies can be differential-tested against the oracle in a container
+// without a GPU.  Never linked into, loaded by, or used as a fallback for libtc_amd.so.
+#include "tc_jobs.h"
+#include <string.h>
+using namespace tc;
+
+extern "C" {
+int hs_fq_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fq x, y;
+  if (!fq_from_be48(a, false, x) || !fq_from_be48(b, false, y)) return -1;
+  fq_to_be48(x * y, out);
+  return 0;
+}
+int hs_fq_inv(const uint8_t* a, uint8_t* out) {
+  Fq x;
+  if (!fq_from_be48(a, false, x)) return -1;
+  fq_to_be48(x.inv(), out);
+  return 0;
+}
+int hs_fq_addsub(const uint8_t* a, const uint8_t* b, uint8_t* sum, uint8_t* diff, uint8_t* neg) {
+  Fq x, y;
+  if (!fq_from_be48(a, false, x) || !fq_from_be48(b, false, y)) return -1;
+  fq_to_be48(x + y, sum);
+  fq_to_be48(x - y, diff);
+  fq_to_be48(-x, neg);
+  return 0;
+}
+int hs_fq2_sqrt(const uint8_t* a /*c0||c1 be48*/, uint8_t* out) {
+  Fq2 x, y;
+  fq_from_be48(a, false, x.c0);
+  fq_from_be48(a + 48, false, x.c1);
+  if (!fq2_sqrt(x, y)) return 0;
+  fq_to_be48(y.c0, out);
+  fq_to_be48(y.c1, out + 48);
+  return 1;
+}
+int hs_g1_mul(const uint8_t* fr, const uint8_t* pt, uint8_t* out) { return job_point_mul<Fq>(fr, pt, out); }
+int hs_g2_mul(const uint8_t* fr, const uint8_t* pt, uint8_t* out) { return job_point_mul<Fq2>(fr, pt, out); }
+int hs_lagrange(const uint64_t* idx, int t, int i, uint8_t* out32le) {
+  uint32_t w[8];
+  int st = job_lagrange(idx, t, i, w);
+  memcpy(out32le, w, 32);
+  return st;
+}
+static int combine(int g2, int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) {
+  uint32_t lam[8 * 256];
+  if (t + 1 > 256) return -1;
+  for (int i = 0; i <= t; i++) {
+    int st = job_lagrange(idx, t, i, lam + 8 * i);
+    if (st) return st;
+  }
+  return g2 ? job_combine<Fq2>(t, shares, lam, out) : job_combine<Fq>(t, shares, lam, out);
+}
+int hs_combine_g2(int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) { return combine(1, t, idx, shares, out); }
+int hs_combine_g1(int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) { return combine(0, t, idx, shares, out); }
+int hs_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
+  return job_pairing_check(a, b, c, d);
+}
+// GT value of FE(ML(a,b)) : 12 x 48 B big-endian in tower order c0.c0.c0, c0.c0.c1, c0.c1.c0 ...
+int hs_pairing_gt(const uint8_t* a, const uint8_t* b, uint8_t* out576) {
+  G1Affine p;
+  G2Affine q;
+  if (!g1_decode_uncompressed(a, p) || !g2_decode_uncompressed(b, q)) return -1;
+  G1Affine ps[1] = {p};
+  G2Affine qs[1] = {q};
+  Fq12 f = final_exponentiation(miller_loop<1>(ps, qs));
+  const Fq* e = reinterpret_cast<const Fq*>(&f);
+  for (int i = 0; i < 12; i++) fq_to_be48(e[i], out576 + 48 * i);
+  return 0;
+}
+int hs_cyclo_check(const uint8_t* a, const uint8_t* b) {
+  // cyclotomic_sqr == generic sqr on an element of the cyclotomic subgroup
+  G1Affine p;
+  G2Affine q;
+  if (!g1_decode_uncompressed(a, p) || !g2_decode_uncompressed(b, q)) return -1;
+  G1Affine ps[1] = {p};
+  G2Affine qs[1] = {q};
+  Fq12 f = miller_loop<1>(ps, qs);
+  Fq12 r = f.conj() * f.inv();
+  r = r.frobenius(2) * r;
+  return (r.cyclotomic_sqr() == r.sqr()) && (r.sqr() == r * r) ? 1 : 0;
+}
+void hs_sha3(const uint8_t* msg, size_t len, uint8_t* out32) {
+  uint32_t w[8];
+  sha3_256_words(msg, len, w);
+  memcpy(out32, w, 32);
+}
+void hs_chacha_words(const uint8_t* seed32, int n, uint32_t* out) {
+  uint32_t k[8];
+  memcpy(k, seed32, 32);
+  ChaChaRng rng;
+  rng.init(k);
+  for (int i = 0; i < n; i++) out[i] = rng.next_u32();
+}
+void hs_hash_g2(const uint8_t* msg, size_t len, uint8_t* out192) { job_hash_g2(msg, len, out192); }
+int hs_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out192) {
+  return job_hash_g1_g2(g1, msg, len, out192);
+}
+int hs_xor_with_hash(const uint8_t* g1, const uint8_t* data, size_t len, uint8_t* out) {
+  return job_xor_with_hash(g1, data, len, out);
+}
+int hs_compress_g1(const uint8_t* in, uint8_t* out) { return job_compress<Fq>(in, out); }
+int hs_compress_g2(const uint8_t* in, uint8_t* out) { return job_compress<Fq2>(in, out); }
+}

@@ -1,0 +1,33 @@
+// Common macros for the gfx950 device library.
+//
+// Every arithmetic routine in csrc/*.h is written once, as TC_HD (host+device) code: hipcc
+// compiles it for gfx950 (the product), and tests/hostsim compiles the very same headers
+// with g++ so the logic can be differential-tested against the oracle in the GPU-less
+// build container.  The host compilation is a TEST HARNESS only: libtc_amd.so (the product)
+// contains no CPU compute path and fails loudly without a HIP device.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TC_HD __host__ __device__ __forceinline__
+#define TC_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define TC_D __device__ __forceinline__
+#define TC_CONST static constexpr
+#else
+#define TC_HD inline
+#define TC_HD_NOINLINE __attribute__((noinline))
+#define TC_D inline
+#define TC_CONST static constexpr
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TC_UNROLL _Pragma("unroll")
+#define TC_NOUNROLL _Pragma("nounroll")
+#else
+#define TC_UNROLL
+#define TC_NOUNROLL
+#endif
+
+#include "tc_constants.h"

@@ -1,0 +1,160 @@
+// G1 / G2 group arithmetic (Jacobian coordinates), templated over the coordinate field.
+// Device replacement for pairing::bls12_381::{G1,G2,G1Affine,G2Affine} as reached from
+// /root/reference/src/lib.rs:373 (sign_g2), :461 (decrypt_share), :764 (interpolate).
+#pragma once
+#include "tc_tower.h"
+
+namespace tc {
+
+template <class F>
+struct Affine {
+  F x, y;
+  bool inf;
+  TC_HD static Affine infinity() { return Affine{F::zero(), F::one(), true}; }
+};
+
+template <class F>
+struct Jac {
+  F x, y, z;  // infinity <=> z == 0
+  TC_HD static Jac infinity() { return Jac{F::zero(), F::one(), F::zero()}; }
+  TC_HD bool is_inf() const { return z.is_zero(); }
+  TC_HD static Jac from_affine(const Affine<F>& a) {
+    Jac r{a.x, a.y, F::one()};
+    if (a.inf) r = infinity();
+    return r;
+  }
+  TC_HD static Jac select(bool c, const Jac& a, const Jac& b) {
+    return Jac{F::select(c, a.x, b.x), F::select(c, a.y, b.y), F::select(c, a.z, b.z)};
+  }
+};
+
+// dbl-2009-l (a = 0): 2M + 5S.  Doubling the identity (z = 0) yields z3 = 0 again.
+template <class F>
+TC_HD Jac<F> jac_dbl(const Jac<F>& p) {
+  F a = p.x.sqr();
+  F b = p.y.sqr();
+  F c = b.sqr();
+  F d = ((p.x + b).sqr() - a - c).dbl();
+  F e = a.dbl() + a;
+  F f = e.sqr();
+  Jac<F> r;
+  r.z = (p.y * p.z).dbl();
+  r.x = f - d.dbl();
+  r.y = e * (d - r.x) - c.dbl().dbl().dbl();
+  return r;
+}
+
+// madd-2007-bl with the exceptional cases handled (p = inf, q = inf, p = +-q).
+template <class F>
+TC_HD Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
+  if (q.inf) return p;
+  F z1z1 = p.z.sqr();
+  F u2 = q.x * z1z1;
+  F s2 = q.y * p.z * z1z1;
+  F h = u2 - p.x;
+  F rr = (s2 - p.y).dbl();
+  const bool p_inf = p.is_inf();
+  const bool same_x = h.is_zero();
+  if (!p_inf && same_x) {
+    // p == q -> double; p == -q -> infinity
+    if (rr.is_zero()) return jac_dbl(p);
+    return Jac<F>::infinity();
+  }
+  F hh = h.sqr();
+  F i = hh.dbl().dbl();
+  F j = h * i;
+  F v = p.x * i;
+  Jac<F> r;
+  r.x = rr.sqr() - j - v.dbl();
+  r.y = rr * (v - r.x) - (p.y * j).dbl();
+  r.z = (p.z + h).sqr() - z1z1 - hh;
+  if (p_inf) r = Jac<F>{q.x, q.y, F::one()};
+  return r;
+}
+
+// add-2007-bl with the exceptional cases handled.
+template <class F>
+TC_HD Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+  const bool p_inf = p.is_inf();
+  const bool q_inf = q.is_inf();
+  F z1z1 = p.z.sqr();
+  F z2z2 = q.z.sqr();
+  F u1 = p.x * z2z2;
+  F u2 = q.x * z1z1;
+  F s1 = p.y * q.z * z2z2;
+  F s2 = q.y * p.z * z1z1;
+  F h = u2 - u1;
+  F rr = (s2 - s1).dbl();
+  if (!p_inf && !q_inf && h.is_zero()) {
+    if (rr.is_zero()) return jac_dbl(p);
+    return Jac<F>::infinity();
+  }
+  F i = h.dbl().sqr();
+  F j = h * i;
+  F v = u1 * i;
+  Jac<F> r;
+  r.x = rr.sqr() - j - v.dbl();
+  r.y = rr * (v - r.x) - (s1 * j).dbl();
+  r.z = ((p.z + q.z).sqr() - z1z1 - z2z2) * h;
+  if (q_inf) r = p;
+  if (p_inf) r = q;
+  return r;
+}
+
+template <class F>
+TC_HD Jac<F> jac_neg(const Jac<F>& p) {
+  return Jac<F>{p.x, -p.y, p.z};
+}
+
+template <class F>
+TC_HD Affine<F> jac_to_affine(const Jac<F>& p) {
+  if (p.is_inf()) return Affine<F>::infinity();
+  F zi = p.z.inv();
+  F zi2 = zi.sqr();
+  return Affine<F>{p.x * zi2, p.y * zi2 * zi, false};
+}
+
+// k * P for a scalar given as nwords little-endian u32 words (bits above nbits are zero).
+// MSB-first double-and-add with mixed additions (the CurveAffine::mul shape of group 0.6).
+// Control flow depends on the scalar: use when the scalar is wave-uniform (shared secret
+// key share, cofactor) so that no lane diverges.
+template <class F, class SC>
+TC_HD Jac<F> jac_mul_affine_uniform(const Affine<F>& p, SC word, int nbits) {
+  Jac<F> acc = Jac<F>::infinity();
+  TC_NOUNROLL for (int i = nbits - 1; i >= 0; i--) {
+    acc = jac_dbl(acc);
+    if ((word(i >> 5) >> (i & 31)) & 1u) acc = jac_add_mixed(acc, p);
+  }
+  return acc;
+}
+
+// y^2 == x^3 + b ?
+template <class F>
+TC_HD bool affine_on_curve(const Affine<F>& p, const F& b) {
+  if (p.inf) return true;
+  return p.y.sqr() == p.x.sqr() * p.x + b;
+}
+
+TC_HD Fq g1_b() {
+  Fq b;
+  TC_UNROLL for (int i = 0; i < 12; i++) b.v.l[i] = FQ_B1[i];
+  return b;
+}
+TC_HD Fq2 g2_b() { return Fq2{g1_b(), g1_b()}; }
+
+TC_HD Affine<Fq> g1_generator() {
+  Affine<Fq> g;
+  TC_UNROLL for (int i = 0; i < 12; i++) {
+    g.x.v.l[i] = G1_GEN_X[i];
+    g.y.v.l[i] = G1_GEN_Y[i];
+  }
+  g.inf = false;
+  return g;
+}
+
+using G1Affine = Affine<Fq>;
+using G2Affine = Affine<Fq2>;
+using G1Jac = Jac<Fq>;
+using G2Jac = Jac<Fq2>;
+
+}  // namespace tc

@@ -1,0 +1,194 @@
+// SHA3-256, ChaCha20 word stream and the RNG-driven hash onto G2 (device side).
+// Replaces, for batches: sha3_256 (/root/reference/src/util.rs:3-9), hash_g2
+// (/root/reference/src/lib.rs:691-694), hash_g1_g2 (:697-707), xor_with_hash (:710-715).
+// The sampling order (H-spec) follows rand_chacha 0.2.2 / ff_derive 0.6 /
+// pairing 0.16 G2::random as published; it is the one implementation-defined part of the path.
+#pragma once
+#include "tc_codec.h"
+
+namespace tc {
+
+// ---------------------------------------------------------------------------------------
+// Keccak-f[1600] / SHA3-256 (FIPS 202)
+// ---------------------------------------------------------------------------------------
+TC_HD uint64_t rotl64(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
+
+TC_HD void keccak_f1600(uint64_t* s) {
+  const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+      0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+      0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+      0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+      0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  TC_NOUNROLL for (int round = 0; round < 24; round++) {
+    uint64_t c[5], d[5];
+    TC_UNROLL for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+    TC_UNROLL for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+    TC_UNROLL for (int i = 0; i < 25; i++) s[i] ^= d[i % 5];
+    // rho + pi
+    uint64_t b[25];
+    b[0] = s[0];
+    b[10] = rotl64(s[1], 1);   b[20] = rotl64(s[2], 62);  b[5] = rotl64(s[3], 28);   b[15] = rotl64(s[4], 27);
+    b[16] = rotl64(s[5], 36);  b[1] = rotl64(s[6], 44);   b[11] = rotl64(s[7], 6);   b[21] = rotl64(s[8], 55);
+    b[6] = rotl64(s[9], 20);   b[7] = rotl64(s[10], 3);   b[17] = rotl64(s[11], 10); b[2] = rotl64(s[12], 43);
+    b[12] = rotl64(s[13], 25); b[22] = rotl64(s[14], 39); b[23] = rotl64(s[15], 41); b[8] = rotl64(s[16], 45);
+    b[18] = rotl64(s[17], 15); b[3] = rotl64(s[18], 21);  b[13] = rotl64(s[19], 8);  b[14] = rotl64(s[20], 18);
+    b[24] = rotl64(s[21], 2);  b[9] = rotl64(s[22], 61);  b[19] = rotl64(s[23], 56); b[4] = rotl64(s[24], 14);
+    // chi
+    TC_UNROLL for (int y = 0; y < 25; y += 5) {
+      TC_UNROLL for (int x = 0; x < 5; x++) s[y + x] = b[y + x] ^ ((~b[y + (x + 1) % 5]) & b[y + (x + 2) % 5]);
+    }
+    s[0] ^= RC[round];
+  }
+}
+
+// SHA3-256 of data[0..len); out = 32 bytes as 8 little-endian u32 words (the ChaCha key layout).
+TC_HD void sha3_256_words(const uint8_t* data, size_t len, uint32_t* out_words) {
+  uint64_t s[25];
+  TC_UNROLL for (int i = 0; i < 25; i++) s[i] = 0;
+  const size_t RATE = 136;
+  size_t off = 0;
+  bool final_done = false;
+  TC_NOUNROLL while (!final_done) {
+    size_t remaining = len - off;
+    const bool last = remaining < RATE;
+    TC_UNROLL for (int w = 0; w < 17; w++) {
+      uint64_t v = 0;
+      TC_UNROLL for (int k = 0; k < 8; k++) {
+        size_t pos = (size_t)(w * 8 + k);
+        uint8_t byte = 0;
+        if (pos < remaining) byte = data[off + pos];
+        else if (last && pos == remaining) byte = 0x06;
+        if (last && pos == RATE - 1) byte |= 0x80;
+        v |= (uint64_t)byte << (8 * k);
+      }
+      s[w] ^= v;
+    }
+    keccak_f1600(s);
+    off += RATE;
+    final_done = last;
+  }
+  TC_UNROLL for (int i = 0; i < 4; i++) {
+    out_words[2 * i] = (uint32_t)s[i];
+    out_words[2 * i + 1] = (uint32_t)(s[i] >> 32);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// ChaCha20 (djb layout: 64-bit block counter, 64-bit stream id = 0) as a u32 word stream
+// == rand_chacha 0.2.2 ChaChaRng::from_seed(key).next_u32()/next_u64()
+// ---------------------------------------------------------------------------------------
+TC_HD uint32_t rotl32(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+
+#define TC_QR(a, b, c, d)                       \
+  a += b; d ^= a; d = rotl32(d, 16);            \
+  c += d; b ^= c; b = rotl32(b, 12);            \
+  a += b; d ^= a; d = rotl32(d, 8);             \
+  c += d; b ^= c; b = rotl32(b, 7);
+
+struct ChaChaRng {
+  uint32_t key[8];
+  uint64_t counter;
+  uint32_t buf[16];
+  int idx;
+
+  TC_HD void init(const uint32_t* key_words) {
+    TC_UNROLL for (int i = 0; i < 8; i++) key[i] = key_words[i];
+    counter = 0;
+    idx = 16;
+  }
+  TC_HD void refill() {
+    uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+    uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3];
+    uint32_t x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+    uint32_t x12 = (uint32_t)counter, x13 = (uint32_t)(counter >> 32), x14 = 0, x15 = 0;
+    TC_NOUNROLL for (int r = 0; r < 10; r++) {
+      TC_QR(x0, x4, x8, x12) TC_QR(x1, x5, x9, x13) TC_QR(x2, x6, x10, x14) TC_QR(x3, x7, x11, x15)
+      TC_QR(x0, x5, x10, x15) TC_QR(x1, x6, x11, x12) TC_QR(x2, x7, x8, x13) TC_QR(x3, x4, x9, x14)
+    }
+    buf[0] = x0 + 0x61707865u; buf[1] = x1 + 0x3320646eu; buf[2] = x2 + 0x79622d32u; buf[3] = x3 + 0x6b206574u;
+    buf[4] = x4 + key[0]; buf[5] = x5 + key[1]; buf[6] = x6 + key[2]; buf[7] = x7 + key[3];
+    buf[8] = x8 + key[4]; buf[9] = x9 + key[5]; buf[10] = x10 + key[6]; buf[11] = x11 + key[7];
+    buf[12] = x12 + (uint32_t)counter; buf[13] = x13 + (uint32_t)(counter >> 32); buf[14] = x14; buf[15] = x15;
+    counter++;
+    idx = 0;
+  }
+  TC_HD uint32_t next_u32() {
+    if (idx >= 16) refill();
+    return buf[idx++];
+  }
+};
+
+// ff_derive 0.6 random() for Fq: 6 x next_u64 (12 words, limb 0 first), top limb masked to 61
+// bits, accept if < q; the accepted bit pattern IS the Montgomery representation.
+TC_HD Fq fq_random(ChaChaRng& rng) {
+  Fq r;
+  bool ok = false;
+  TC_NOUNROLL while (!ok) {
+    for (int i = 0; i < 12; i++) r.v.l[i] = rng.next_u32();
+    r.v.l[11] &= 0x1fffffffu;
+    ok = limbs_lt_p<FqParams>(r.v.l);
+  }
+  return r;
+}
+
+// Square root in Fq2 (q = 3 mod 4), Algorithm 9 of eprint 2012/685.  false for non-squares.
+TC_HD bool fq2_sqrt(const Fq2& a, Fq2& out) {
+  if (a.is_zero()) {
+    out = Fq2::zero();
+    return true;
+  }
+  const Fq2 minus_one = -Fq2::one();
+  Fq2 a1 = field_pow_fixed(a, [](int i) { return FQ_P_MINUS_3_DIV_4[i]; }, 379);
+  Fq2 alpha = a1.sqr() * a;
+  Fq2 a0 = alpha.conj() * alpha;
+  if (a0 == minus_one) return false;
+  a1 = a1 * a;
+  if (alpha == minus_one) {
+    out = Fq2{-a1.c1, a1.c0};  // times u
+    return true;
+  }
+  Fq2 b = field_pow_fixed(alpha + Fq2::one(), [](int i) { return FQ_P_MINUS_1_DIV_2[i]; }, 380);
+  out = b * a1;
+  return true;
+}
+
+// G2Affine::get_point_from_x(x, greatest) of pairing 0.16
+TC_HD bool g2_point_from_x(const Fq2& x, bool greatest, G2Affine& p) {
+  Fq2 rhs = x.sqr() * x + g2_b();
+  Fq2 y;
+  if (!fq2_sqrt(rhs, y)) return false;
+  Fq2 negy = -y;
+  // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
+  bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
+  p.x = x;
+  p.y = (y_lt_negy ^ greatest) ? y : negy;
+  p.inf = false;
+  return true;
+}
+
+// G2::random(ChaChaRng::from_seed(seed)) followed by into_affine() is left to the caller:
+// returns the Jacobian point h2 * (x, y).
+TC_HD G2Jac g2_random_from_seed(const uint32_t* seed_words) {
+  ChaChaRng rng;
+  rng.init(seed_words);
+  G2Jac res = G2Jac::infinity();
+  bool done = false;
+  TC_NOUNROLL while (!done) {
+    G2Affine cand;
+    bool have = false;
+    TC_NOUNROLL while (!have) {
+      Fq2 x;
+      x.c0 = fq_random(rng);
+      x.c1 = fq_random(rng);
+      bool greatest = (rng.next_u32() & 1u) != 0;
+      have = g2_point_from_x(x, greatest, cand);
+    }
+    res = jac_mul_affine_uniform(cand, [](int i) { return G2_COFACTOR[i]; }, G2_COFACTOR_BITS);
+    done = !res.is_inf();
+  }
+  return res;
+}
+
+}  // namespace tc

@@ -1,0 +1,182 @@
+// Per-lane job bodies: one independent (message, share-set) job or one curve op per lane.
+// The __global__ kernels in tc_kernels.hip call these with the lane's slice of the batch;
+// tests/hostsim calls the same bodies from a host loop (test harness only).
+#pragma once
+#include "tc_codec.h"
+#include "tc_hash.h"
+#include "tc_pairing.h"
+#include "tc_threshold.h"
+
+namespace tc {
+
+template <class F>
+struct PointIO;
+
+template <>
+struct PointIO<Fq> {
+  static constexpr int BYTES = 96;
+  static constexpr int CBYTES = 48;
+  TC_HD static bool decode(const uint8_t* b, Affine<Fq>& p) { return g1_decode_uncompressed(b, p); }
+  TC_HD static void encode(const Affine<Fq>& p, uint8_t* b) { g1_encode_uncompressed(p, b); }
+};
+template <>
+struct PointIO<Fq2> {
+  static constexpr int BYTES = 192;
+  static constexpr int CBYTES = 96;
+  TC_HD static bool decode(const uint8_t* b, Affine<Fq2>& p) { return g2_decode_uncompressed(b, p); }
+  TC_HD static void encode(const Affine<Fq2>& p, uint8_t* b) { g2_encode_uncompressed(p, b); }
+};
+
+// out = fr * pt           (CurveAffine::mul: sign_g2 src/lib.rs:373, decrypt_share :461)
+// The scalar is shared by all lanes of a wave (one secret key share per wave), so the
+// bit-serial double-and-add below has wave-uniform control flow.
+template <class F>
+TC_HD uint8_t job_point_mul(const uint8_t* fr_le32, const uint8_t* pt, uint8_t* out) {
+  uint32_t k[8];
+  Affine<F> p;
+  bool ok = fr_from_le32(fr_le32, k);
+  ok &= PointIO<F>::decode(pt, p);
+  if (!ok) {
+    PointIO<F>::encode(Affine<F>::infinity(), out);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  Jac<F> r = jac_mul_affine_uniform(p, [&](int i) { return k[i]; }, 255);
+  PointIO<F>::encode(jac_to_affine(r), out);
+  return TC_JOB_OK;
+}
+
+// Lagrange coefficient (job, position i) -> 8 canonical LE words
+TC_HD uint8_t job_lagrange(const uint64_t* idx, int t, int i, uint32_t* out_words) {
+  Fr lam;
+  if (!lagrange_coeff_at_zero(idx, t, i, lam)) {
+    for (int w = 0; w < 8; w++) out_words[w] = 0;
+    return TC_JOB_DUPLICATE_ENTRY;
+  }
+  lam.to_canonical(out_words);
+  return TC_JOB_OK;
+}
+
+// out = sum_{i <= t} lambda_i * share_i over the FIRST t+1 samples of the job
+// (interpolate, src/lib.rs:719-767).  lam: (t+1) x 8 canonical words from job_lagrange.
+template <class F>
+TC_HD uint8_t job_combine(int t, const uint8_t* shares, const uint32_t* lam, uint8_t* out) {
+  constexpr int PB = PointIO<F>::BYTES;
+  if (t == 0) {
+    // t == 0: the first sample is returned unchanged (src/lib.rs:735-737)
+    Affine<F> p;
+    if (!PointIO<F>::decode(shares, p)) {
+      PointIO<F>::encode(Affine<F>::infinity(), out);
+      return TC_JOB_INVALID_ENCODING;
+    }
+    PointIO<F>::encode(p, out);
+    return TC_JOB_OK;
+  }
+  Jac<F> total = Jac<F>::infinity();
+  bool ok = true;
+  TC_NOUNROLL for (int base = 0; base <= t; base += 4) {
+    const int k = (t + 1 - base) < 4 ? (t + 1 - base) : 4;
+    Affine<F> pts[4];
+    uint32_t sc[4][8];
+    TC_NOUNROLL for (int j = 0; j < 4; j++) {
+      if (j < k) {
+        ok &= PointIO<F>::decode(shares + (size_t)(base + j) * PB, pts[j]);
+        for (int w = 0; w < 8; w++) sc[j][w] = lam[(size_t)(base + j) * 8 + w];
+      } else {
+        pts[j] = Affine<F>::infinity();
+        for (int w = 0; w < 8; w++) sc[j][w] = 0;
+      }
+    }
+    Jac<F> part = straus_chunk<F, 4>(pts, sc);
+    total = jac_add(total, part);
+  }
+  if (!ok) {
+    PointIO<F>::encode(Affine<F>::infinity(), out);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  PointIO<F>::encode(jac_to_affine(total), out);
+  return TC_JOB_OK;
+}
+
+// ok = e(a, b) == e(c, d)     (src/lib.rs:109, :185, :511)
+TC_HD uint8_t job_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
+  G1Affine pa, pc;
+  G2Affine qb, qd;
+  bool ok = g1_decode_uncompressed(a, pa);
+  ok &= g2_decode_uncompressed(b, qb);
+  ok &= g1_decode_uncompressed(c, pc);
+  ok &= g2_decode_uncompressed(d, qd);
+  if (!ok) return 0;
+  return pairing_check(pa, qb, pc, qd) ? 1 : 0;
+}
+
+// out = hash_g2(msg).into_affine()      (src/lib.rs:691-694)
+TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2) {
+  uint32_t seed[8];
+  sha3_256_words(msg, len, seed);
+  G2Jac h = g2_random_from_seed(seed);
+  g2_encode_uncompressed(jac_to_affine(h), out_g2);
+}
+
+// out = hash_g1_g2(g1, msg).into_affine()   (src/lib.rs:697-707)
+TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2) {
+  G1Affine p;
+  if (!g1_decode_uncompressed(g1, p)) {
+    g2_encode_uncompressed(G2Affine::infinity(), out_g2);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  uint8_t buf[64 + 48];
+  size_t n;
+  if (len > 64) {
+    uint32_t d[8];
+    sha3_256_words(msg, len, d);
+    for (int i = 0; i < 8; i++) {
+      buf[4 * i] = (uint8_t)d[i];
+      buf[4 * i + 1] = (uint8_t)(d[i] >> 8);
+      buf[4 * i + 2] = (uint8_t)(d[i] >> 16);
+      buf[4 * i + 3] = (uint8_t)(d[i] >> 24);
+    }
+    n = 32;
+  } else {
+    for (size_t i = 0; i < len; i++) buf[i] = msg[i];
+    n = len;
+  }
+  g1_encode_compressed(p, buf + n);
+  job_hash_g2(buf, n + 48, out_g2);
+  return TC_JOB_OK;
+}
+
+// out[i] = data[i] ^ (u8) ChaCha20(sha3_256(compress(g1))).next_u32()   (src/lib.rs:710-715)
+TC_HD uint8_t job_xor_with_hash(const uint8_t* g1, const uint8_t* data, size_t len, uint8_t* out) {
+  G1Affine p;
+  if (!g1_decode_uncompressed(g1, p)) return TC_JOB_INVALID_ENCODING;
+  uint8_t comp[48];
+  g1_encode_compressed(p, comp);
+  uint32_t seed[8];
+  sha3_256_words(comp, 48, seed);
+  ChaChaRng rng;
+  rng.init(seed);
+  for (size_t i = 0; i < len; i++) out[i] = data[i] ^ (uint8_t)rng.next_u32();
+  return TC_JOB_OK;
+}
+
+// uncompressed -> compressed (to_bytes, src/lib.rs:149-153, 255-259)
+template <class F>
+TC_HD uint8_t job_compress(const uint8_t* in, uint8_t* out);
+template <>
+TC_HD uint8_t job_compress<Fq>(const uint8_t* in, uint8_t* out) {
+  G1Affine p;
+  bool ok = g1_decode_uncompressed(in, p);
+  if (!ok) p = G1Affine::infinity();
+  g1_encode_compressed(p, out);
+  return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+}
+template <>
+TC_HD uint8_t job_compress<Fq2>(const uint8_t* in, uint8_t* out) {
+  G2Affine p;
+  bool ok = g2_decode_uncompressed(in, p);
+  if (!ok) p = G2Affine::infinity();
+  g2_encode_compressed(p, out);
+  return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+}
+
+}  // namespace tc

@@ -1,0 +1,193 @@
+// Extension tower Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3-(u+1)), Fq12 = Fq6[w]/(w^2-v)
+// (device replacement for pairing::bls12_381::{Fq2,Fq6,Fq12}).
+#pragma once
+#include "tc_field.h"
+
+namespace tc {
+
+struct Fq2 {
+  Fq c0, c1;
+  TC_HD static Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
+  TC_HD static Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
+  TC_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  TC_HD bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+  TC_HD bool operator!=(const Fq2& b) const { return !(*this == b); }
+  TC_HD Fq2 operator+(const Fq2& b) const { return Fq2{c0 + b.c0, c1 + b.c1}; }
+  TC_HD Fq2 operator-(const Fq2& b) const { return Fq2{c0 - b.c0, c1 - b.c1}; }
+  TC_HD Fq2 operator-() const { return Fq2{-c0, -c1}; }
+  TC_HD Fq2 dbl() const { return Fq2{c0.dbl(), c1.dbl()}; }
+  TC_HD Fq2 conj() const { return Fq2{c0, -c1}; }
+  // Karatsuba: 3 Fq mul
+  TC_HD Fq2 operator*(const Fq2& b) const {
+    Fq aa = c0 * b.c0;
+    Fq bb = c1 * b.c1;
+    Fq o = (c0 + c1) * (b.c0 + b.c1);
+    return Fq2{aa - bb, o - aa - bb};
+  }
+  // complex squaring: 2 Fq mul
+  TC_HD Fq2 sqr() const {
+    Fq ab = c0 * c1;
+    Fq s = (c0 + c1) * (c0 - c1);
+    return Fq2{s, ab.dbl()};
+  }
+  TC_HD Fq2 scale(const Fq& k) const { return Fq2{c0 * k, c1 * k}; }
+  // times the non-residue (1 + u)
+  TC_HD Fq2 mul_xi() const { return Fq2{c0 - c1, c0 + c1}; }
+  TC_HD Fq2 inv() const {
+    Fq t = (c0.sqr() + c1.sqr()).inv();
+    return Fq2{c0 * t, -(c1 * t)};
+  }
+  TC_HD static Fq2 select(bool c, const Fq2& a, const Fq2& b) {
+    return Fq2{Fq::select(c, a.c0, b.c0), Fq::select(c, a.c1, b.c1)};
+  }
+};
+
+struct Fq6 {
+  Fq2 c0, c1, c2;
+  TC_HD static Fq6 zero() { return Fq6{Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+  TC_HD static Fq6 one() { return Fq6{Fq2::one(), Fq2::zero(), Fq2::zero()}; }
+  TC_HD bool operator==(const Fq6& b) const { return c0 == b.c0 && c1 == b.c1 && c2 == b.c2; }
+  TC_HD Fq6 operator+(const Fq6& b) const { return Fq6{c0 + b.c0, c1 + b.c1, c2 + b.c2}; }
+  TC_HD Fq6 operator-(const Fq6& b) const { return Fq6{c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
+  TC_HD Fq6 operator-() const { return Fq6{-c0, -c1, -c2}; }
+  TC_HD Fq6 operator*(const Fq6& b) const {
+    Fq2 t0 = c0 * b.c0;
+    Fq2 t1 = c1 * b.c1;
+    Fq2 t2 = c2 * b.c2;
+    Fq6 r;
+    r.c0 = t0 + ((c1 + c2) * (b.c1 + b.c2) - t1 - t2).mul_xi();
+    r.c1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1 + t2.mul_xi();
+    r.c2 = (c0 + c2) * (b.c0 + b.c2) - t0 - t2 + t1;
+    return r;
+  }
+  // CH-SQR2 (Chung-Hasan): 2 mul + 3 sqr in Fq2
+  TC_HD Fq6 sqr() const {
+    Fq2 s0 = c0.sqr();
+    Fq2 ab = c0 * c1;
+    Fq2 s1 = ab.dbl();
+    Fq2 s2 = (c0 - c1 + c2).sqr();
+    Fq2 bc = c1 * c2;
+    Fq2 s3 = bc.dbl();
+    Fq2 s4 = c2.sqr();
+    Fq6 r;
+    r.c0 = s0 + s3.mul_xi();
+    r.c1 = s1 + s4.mul_xi();
+    r.c2 = s1 + s2 + s3 - s0 - s4;
+    return r;
+  }
+  TC_HD Fq6 mul_by_v() const { return Fq6{c2.mul_xi(), c0, c1}; }
+  // sparse: times (b0 + b1 v)
+  TC_HD Fq6 mul_by_01(const Fq2& b0, const Fq2& b1) const {
+    Fq2 aa = c0 * b0;
+    Fq2 bb = c1 * b1;
+    Fq6 r;
+    r.c0 = ((c1 + c2) * b1 - bb).mul_xi() + aa;
+    r.c1 = (c0 + c1) * (b0 + b1) - aa - bb;
+    r.c2 = (c0 + c2) * b0 - aa + bb;
+    return r;
+  }
+  // sparse: times (b1 v)
+  TC_HD Fq6 mul_by_1(const Fq2& b1) const { return Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1}; }
+  TC_HD Fq6 inv() const {
+    Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
+    Fq2 t1 = c2.sqr().mul_xi() - c0 * c1;
+    Fq2 t2 = c1.sqr() - c0 * c2;
+    Fq2 d = c0 * t0 + (c2 * t1 + c1 * t2).mul_xi();
+    Fq2 di = d.inv();
+    return Fq6{t0 * di, t1 * di, t2 * di};
+  }
+};
+
+TC_HD Fq2 frob_coeff(int k, int i) {  // gamma_k[i], i = 1..5
+  Fq2 g;
+  const uint32_t* a0 = (k == 1) ? FROB1_C0[i - 1] : (k == 2) ? FROB2_C0[i - 1] : FROB3_C0[i - 1];
+  const uint32_t* a1 = (k == 1) ? FROB1_C1[i - 1] : (k == 2) ? FROB2_C1[i - 1] : FROB3_C1[i - 1];
+  TC_UNROLL for (int j = 0; j < 12; j++) {
+    g.c0.v.l[j] = a0[j];
+    g.c1.v.l[j] = a1[j];
+  }
+  return g;
+}
+
+struct Fq12 {
+  Fq6 c0, c1;
+  TC_HD static Fq12 one() { return Fq12{Fq6::one(), Fq6::zero()}; }
+  TC_HD bool operator==(const Fq12& b) const { return c0 == b.c0 && c1 == b.c1; }
+  TC_HD Fq12 operator*(const Fq12& b) const {
+    Fq6 t0 = c0 * b.c0;
+    Fq6 t1 = c1 * b.c1;
+    Fq12 r;
+    r.c1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1;
+    r.c0 = t0 + t1.mul_by_v();
+    return r;
+  }
+  // complex squaring over Fq6: 2 Fq6 mul
+  TC_HD Fq12 sqr() const {
+    Fq6 ab = c0 * c1;
+    Fq6 t = (c0 + c1) * (c0 + c1.mul_by_v()) - ab - ab.mul_by_v();
+    return Fq12{t, ab + ab};
+  }
+  TC_HD Fq12 conj() const { return Fq12{c0, -c1}; }
+  TC_HD Fq12 inv() const {
+    Fq6 t = (c0.sqr() - c1.sqr().mul_by_v()).inv();
+    return Fq12{c0 * t, -(c1 * t)};
+  }
+  // sparse multiplication by (d0 + d1 v) + (d4 v) w -- the Miller-loop line shape
+  TC_HD Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
+    Fq6 aa = c0.mul_by_01(d0, d1);
+    Fq6 bb = c1.mul_by_1(d4);
+    Fq2 o = d1 + d4;
+    Fq12 r;
+    r.c1 = (c1 + c0).mul_by_01(d0, o) - aa - bb;
+    r.c0 = bb.mul_by_v() + aa;
+    return r;
+  }
+  // a^(q^k), k in {1,2,3}
+  TC_HD Fq12 frobenius(int k) const {
+    const bool cj = (k & 1);
+    Fq12 r;
+    r.c0.c0 = cj ? c0.c0.conj() : c0.c0;
+    r.c0.c1 = (cj ? c0.c1.conj() : c0.c1) * frob_coeff(k, 2);
+    r.c0.c2 = (cj ? c0.c2.conj() : c0.c2) * frob_coeff(k, 4);
+    r.c1.c0 = (cj ? c1.c0.conj() : c1.c0) * frob_coeff(k, 1);
+    r.c1.c1 = (cj ? c1.c1.conj() : c1.c1) * frob_coeff(k, 3);
+    r.c1.c2 = (cj ? c1.c2.conj() : c1.c2) * frob_coeff(k, 5);
+    return r;
+  }
+  // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part
+  // of the final exponentiation): 9 Fq2 squarings' worth instead of 2 Fq6 mul.
+  TC_HD Fq12 cyclotomic_sqr() const {
+    // view as three Fq4 = Fq2[s]/(s^2 - xi) pairs: (c0.c0, c1.c1), (c1.c0, c0.c2), (c0.c1, c1.c2)
+    Fq2 z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2;
+    Fq2 t0, t1, t2, t3;
+    // fp4 square (z0, z1)
+    {
+      Fq2 a2 = z0.sqr(), b2 = z1.sqr();
+      t0 = b2.mul_xi() + a2;
+      t1 = (z0 + z1).sqr() - a2 - b2;
+    }
+    z0 = (t0 - z0).dbl() + t0;
+    z1 = (t1 + z1).dbl() + t1;
+    {
+      Fq2 a2 = z2.sqr(), b2 = z3.sqr();
+      t0 = b2.mul_xi() + a2;
+      t1 = (z2 + z3).sqr() - a2 - b2;
+    }
+    {
+      Fq2 a2 = z4.sqr(), b2 = z5.sqr();
+      t2 = b2.mul_xi() + a2;
+      t3 = (z4 + z5).sqr() - a2 - b2;
+    }
+    z4 = (t0 - z4).dbl() + t0;
+    z5 = (t1 + z5).dbl() + t1;
+    Fq2 t3x = t3.mul_xi();
+    z2 = (t3x + z2).dbl() + t3x;
+    z3 = (t2 - z3).dbl() + t2;
+    Fq12 r;
+    r.c0.c0 = z0; r.c0.c1 = z4; r.c0.c2 = z3;
+    r.c1.c0 = z2; r.c1.c1 = z1; r.c1.c2 = z5;
+    return r;
+  }
+};
+
+}  // namespace tc
