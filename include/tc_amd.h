@@ -1,0 +1,145 @@
+/* tc_amd.h -- C ABI of libtc_amd.so: batched BLS12-381 threshold-crypto hot path on MI355X.
+ *
+ * Drop-in boundary for the data-parallel path of poanetwork/threshold_crypto 0.4.0.  Each
+ * entry point is the BATCH form of one reference method (cited below, paths relative to
+ * the reference repository); the reference's single-item Rust method maps to a batch of 1.
+ * Plain pointers and sizes only; no C++/torch types.  Caller owns every buffer; the library
+ * retains no pointer after a call returns (all calls are synchronous unless noted).
+ *
+ * Encodings (identical to the reference's, so results compare byte-for-byte):
+ *   G1 point  : 96 B  uncompressed Zcash form  x || y           (big-endian, flag bits in byte 0)
+ *   G2 point  : 192 B uncompressed Zcash form  x.c1||x.c0||y.c1||y.c0
+ *               = `into_affine().into_uncompressed()`            (src/lib.rs:89,163,224,238,276)
+ *   compressed: 48 B / 96 B = PublicKey::to_bytes / Signature::to_bytes (src/lib.rs:149-153,255-259)
+ *   Fr scalar : 32 B little-endian canonical (4 x u64 LE limbs)  (src/serde_impl.rs:296)
+ *   share idx : u64, the `T: IntoFr` index of combine_signatures/decrypt (src/into_fr.rs:16-26)
+ * Decoding an uncompressed point checks range, flags and the curve equation; it does NOT
+ * run the r-torsion check (values the reference holds in G1/G2 are already in the subgroup).
+ *
+ * Return value: 0 = TC_OK, < 0 = call-level failure (bad argument / HIP error / no device);
+ * never aborts, never throws across the boundary.  Per-job results go to `status[]`
+ * (mirrors threshold_crypto::error::Error / FromBytesError, src/error.rs:7-17,37-41) and
+ * `ok[]` (the `bool` of the verify methods).
+ *
+ * I/O residency: by default every data pointer is HOST memory and the call stages through
+ * device buffers owned by the context.  After tc_ctx_set_device_io(ctx, 1) every data
+ * pointer (inputs, outputs, offsets, status, ok) must be DEVICE memory on the context's GPU,
+ * 8-byte aligned, and nothing crosses PCIe.
+ *
+ * Threading: a context is bound to one GPU and one HIP stream and is thread-compatible (one
+ * thread at a time); distinct contexts may be used concurrently (one per GPU / per process).
+ */
+#ifndef TC_AMD_H
+#define TC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_OK 0
+#define TC_ERR_INVALID_ARG (-1)
+#define TC_ERR_HIP (-2)
+#define TC_ERR_NO_DEVICE (-3)
+
+/* per-job status codes */
+#define TC_JOB_OK 0
+#define TC_JOB_NOT_ENOUGH_SHARES 1 /* Error::NotEnoughShares   src/error.rs:9  */
+#define TC_JOB_DUPLICATE_ENTRY 2   /* Error::DuplicateEntry    src/error.rs:12 */
+#define TC_JOB_INVALID_ENCODING 3  /* FromBytesError::Invalid  src/error.rs:39 */
+
+#define TC_G1_BYTES 96
+#define TC_G2_BYTES 192
+#define TC_G1_COMPRESSED_BYTES 48 /* PK_SIZE  src/lib.rs:71 */
+#define TC_G2_COMPRESSED_BYTES 96 /* SIG_SIZE src/lib.rs:75 */
+#define TC_FR_BYTES 32
+
+typedef struct tc_ctx tc_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device`.  Fails with TC_ERR_NO_DEVICE when no gfx950
+ * device is visible: there is no CPU fallback. */
+int tc_ctx_create(tc_ctx** out, int device);
+void tc_ctx_destroy(tc_ctx* ctx);
+int tc_ctx_set_device_io(tc_ctx* ctx, int enabled);
+/* Use an externally owned HIP stream (hipStream_t passed as void*), e.g. torch's current
+ * stream; NULL restores the context's own stream. */
+int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream);
+int tc_sync(tc_ctx* ctx);
+const char* tc_last_error(const tc_ctx* ctx);
+/* Milliseconds spent in the kernels of the most recent call, measured with HIP events on
+ * the context's stream (0 if timing is disabled).  tc_ctx_set_timing(ctx, 1) enables it. */
+int tc_ctx_set_timing(tc_ctx* ctx, int enabled);
+double tc_last_kernel_ms(const tc_ctx* ctx);
+const char* tc_version(void);
+
+/* ---- hashing onto G2 -------------------------------------------------------------------- */
+/* out[j] = hash_g2(msgs[off[j]..off[j+1]])                 pub fn hash_g2, src/lib.rs:691-694 */
+int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out_g2);
+/* out[j] = hash_g1_g2(g1[j], msgs[j])                      fn hash_g1_g2, src/lib.rs:697-707 */
+int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
+                        uint8_t* out_g2, uint8_t* status);
+
+/* ---- scalar multiplication (share signing / decryption shares) --------------------------- */
+/* out[j*S + s] = fr[s] * pts[j]   S signers x B hash points; status[j*S + s].
+ * SecretKey::sign_g2 src/lib.rs:372-374, SecretKeyShare::sign_g2 :442-444 */
+int tc_g2_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                    uint8_t* status);
+/* SecretKeyShare::decrypt_share_no_verify src/lib.rs:460-462, SecretKey::public_key :367-369 */
+int tc_g1_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                    uint8_t* status);
+/* out[j*S + s] = fr[s] * hash_g2(msg[j])   SecretKey::sign :379-381, SecretKeyShare::sign :447-449 */
+int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uint64_t* off, size_t S, size_t B,
+                  uint8_t* out_g2, uint8_t* status);
+
+/* ---- Lagrange combination ------------------------------------------------------------------ */
+/* Job j holds n_per_job samples (idx[j*n + k], shares[(j*n + k)*192]) in iteration order (the
+ * reference iterates a BTreeMap: ascending index).  As `interpolate` (src/lib.rs:719-767): only
+ * the FIRST t+1 samples are used; n_per_job <= t gives status NOT_ENOUGH_SHARES for every job;
+ * t == 0 returns the first sample; equal indices are filtered by value from the denominator.
+ * PublicKeySet::combine_signatures src/lib.rs:608-615 (t = commit.degree(), :614). */
+int tc_combine_g2_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+                        size_t B, uint8_t* out, uint8_t* status);
+/* Same in G1 (96 B points): the interpolate call of PublicKeySet::decrypt, src/lib.rs:618-625 */
+int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+                        size_t B, uint8_t* out, uint8_t* status);
+/* PublicKeySet::decrypt src/lib.rs:618-626: out bytes[off[j]..off[j+1]] = xor_with_hash(combine_g1, v_j) */
+int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
+                     const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status);
+/* out[j] = data[j] ^ keystream(g1[j])                       fn xor_with_hash, src/lib.rs:710-715 */
+int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
+                           uint8_t* out, uint8_t* status);
+
+/* ---- pairing checks ------------------------------------------------------------------------ */
+/* ok[j] = ( e(a[j], b[j]) == e(c[j], d[j]) ).  A stride of 0 broadcasts one operand to every job;
+ * otherwise strides are in bytes (96 / 192 for packed arrays).  An undecodable operand gives 0.
+ * PEngine::pairing(..) == PEngine::pairing(..): src/lib.rs:109, :185, :511 */
+int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a_g1, size_t a_stride, const uint8_t* b_g2, size_t b_stride,
+                           const uint8_t* c_g1, size_t c_stride, const uint8_t* d_g2, size_t d_stride, size_t B,
+                           uint8_t* ok);
+/* ok[j] = pk.verify_g2(sig[j], hash[j]) = e(pk, hash[j]) == e(g1, sig[j])     src/lib.rs:108-110,170-172 */
+int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk_g1, size_t pk_stride, const uint8_t* sig_g2,
+                       const uint8_t* hash_g2, size_t B, uint8_t* ok);
+/* ok[j] = pk.verify(sig[j], msg[j])                                              src/lib.rs:115-117,177-179 */
+int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk_g1, size_t pk_stride, const uint8_t* sig_g2,
+                        const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* ok);
+/* ok[j] = Ciphertext(u[j], v[j], w[j]).verify() = e(g1, w) == e(u, hash_g1_g2(u, v))   src/lib.rs:508-512 */
+int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
+                               const uint8_t* w_g2, size_t B, uint8_t* ok);
+/* ok[j] = pk_share[j].verify_decryption_share(share[j], ct[j])
+ *       = e(share, hash_g1_g2(u, v)) == e(pk_share, w)                                  src/lib.rs:182-186 */
+int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share_g1, size_t pk_stride,
+                                     const uint8_t* share_g1, const uint8_t* u_g1, const uint8_t* v,
+                                     const uint64_t* off, const uint8_t* w_g2, size_t B, uint8_t* ok);
+
+/* ---- wire formats --------------------------------------------------------------------------- */
+/* uncompressed -> compressed: PublicKey::to_bytes src/lib.rs:149-153, Signature::to_bytes :255-259 */
+int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status);
+int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* out96, uint8_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TC_AMD_H */

@@ -1,0 +1,293 @@
+"""GPU parity: every C-ABI batch entry point vs the oracle (bit-exact), on seeded inputs at
+sizes the Python oracle finishes in seconds.  Run with `pytest -m gpu` on an MI355X."""
+import random
+
+import numpy as np
+import pytest
+
+import tc_oracle as o
+from threshold_crypto_amd.engine import pack_messages
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x7C5EED
+
+
+def u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def g2s(points):
+    return np.stack([u8(o.g2_uncompressed(p)) for p in points])
+
+
+def g1s(points):
+    return np.stack([u8(o.g1_uncompressed(p)) for p in points])
+
+
+def frs(scalars):
+    return np.stack([u8(o.fr_to_bytes(s)) for s in scalars])
+
+
+@pytest.fixture(scope="module")
+def rnd():
+    return random.Random(SEED)
+
+
+def test_version(engine):
+    assert "gfx950" in engine.version()
+
+
+def test_g2_mul_matches_oracle(engine, rnd):
+    """SecretKeyShare::sign_g2 (src/lib.rs:442-444): S signers x B hash points."""
+    S, B = 3, 70  # B > 64 so a wave boundary is crossed
+    sks = [rnd.randrange(o.R) for _ in range(S)]
+    sks[1] = 1
+    pts = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(B)]
+    pts[5] = None  # infinity in, infinity out
+    out, st = engine.g2_mul(frs(sks), g2s(pts))
+    assert st.shape == (B, S) and not st.any()
+    for j in rnd.sample(range(B), 12) + [5]:
+        for s in range(S):
+            assert bytes(out[j, s]) == o.g2_uncompressed(o.E2.mul(pts[j], sks[s])), (j, s)
+
+
+def test_g1_mul_matches_oracle(engine, rnd):
+    """decrypt_share_no_verify (src/lib.rs:460-462)."""
+    S, B = 2, 65
+    sks = [rnd.randrange(o.R), 0]
+    pts = [o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)) for _ in range(B)]
+    out, st = engine.g1_mul(frs(sks), g1s(pts))
+    assert not st.any()
+    for j in rnd.sample(range(B), 10):
+        assert bytes(out[j, 0]) == o.g1_uncompressed(o.E1.mul(pts[j], sks[0]))
+        assert bytes(out[j, 1]) == o.g1_uncompressed(None)
+
+
+def test_mul_rejects_bad_encodings(engine):
+    pt = bytearray(o.g2_uncompressed(o.G2_GEN))
+    pt[191] ^= 1  # off the curve
+    big = (o.R).to_bytes(32, "little")  # non-canonical scalar
+    out, st = engine.g2_mul(np.stack([u8(o.fr_to_bytes(7)), u8(big)]), np.stack([u8(pt), u8(o.g2_uncompressed(o.G2_GEN))]))
+    assert st[0, 0] == 3 and st[0, 1] == 3 and st[1, 1] == 3 and st[1, 0] == 0
+    assert bytes(out[1, 0]) == o.g2_uncompressed(o.E2.mul(o.G2_GEN, 7))
+
+
+@pytest.mark.parametrize("t", [0, 1, 3, 5])
+def test_combine_g2_matches_oracle(engine, rnd, t):
+    """PublicKeySet::combine_signatures (src/lib.rs:608-615) on per-job signer subsets."""
+    B, N = 66, 10
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    sk = [o.secret_key_share(poly, i) for i in range(N)]
+    idx = np.zeros((B, t + 1), dtype=np.uint64)
+    shares = np.zeros((B, t + 1, 192), dtype=np.uint8)
+    expect = []
+    cache = {}
+    for j in range(B):
+        h = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) if j < 6 else cache["h"]
+        cache["h"] = h
+        ids = sorted(rnd.sample(range(N), t + 1))
+        idx[j] = ids
+        pts = []
+        for k, i in enumerate(ids):
+            key = (id(h), i)
+            if key not in cache:
+                cache[key] = o.E2.mul(h, sk[i])
+            pts.append(cache[key])
+            shares[j, k] = u8(o.g2_uncompressed(cache[key]))
+        expect.append((h, ids, pts))
+    out, st = engine.combine_g2(t, idx, shares)
+    assert not st.any()
+    for j in list(range(8)) + rnd.sample(range(8, B), 6):
+        h, ids, pts = expect[j]
+        want = o.combine_signatures(t, list(zip(ids, pts)))
+        assert want == o.E2.mul(h, poly[0])
+        assert bytes(out[j]) == o.g2_uncompressed(want), j
+
+
+def test_combine_takes_first_t_plus_1_and_flags_too_few(engine, rnd):
+    """interpolate: take(t+1) (src/lib.rs:728) and NotEnoughShares (:731-733)."""
+    t, N = 2, 7
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    h = o.E2.mul(o.G2_GEN, 99)
+    ids = [0, 2, 3, 5, 6]
+    pts = [o.E2.mul(h, o.secret_key_share(poly, i)) for i in ids]
+    idx = np.array([ids], dtype=np.uint64)
+    shares = g2s(pts)[None]
+    out, st = engine.combine_g2(t, idx, shares)  # 5 supplied, first 3 used
+    assert st[0] == 0 and bytes(out[0]) == o.g2_uncompressed(o.E2.mul(h, poly[0]))
+    out, st = engine.combine_g2(t, idx[:, :2].copy(), shares[:, :2].copy())  # 2 <= t
+    assert st[0] == 1
+
+
+def test_combine_duplicate_index_quirk(engine, rnd):
+    """Equal indices are filtered by VALUE from the denominator (src/lib.rs:758): no error,
+    and the (wrong) point the reference would return is reproduced bit-exactly."""
+    t = 2
+    h = o.E2.mul(o.G2_GEN, 5)
+    pts = [o.E2.mul(h, k) for k in (3, 4, 9)]
+    ids = [1, 1, 4]
+    out, st = engine.combine_g2(t, np.array([ids], dtype=np.uint64), g2s(pts)[None])
+    assert st[0] == 0
+    assert bytes(out[0]) == o.g2_uncompressed(o.interpolate(o.E2, t, list(zip(ids, pts))))
+
+
+def test_combine_g1_and_decrypt(engine, rnd):
+    """PublicKeySet::decrypt (src/lib.rs:618-626)."""
+    t, N, B = 3, 10, 5
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    pk = o.public_key(poly[0])
+    idx = np.zeros((B, t + 1), dtype=np.uint64)
+    shares = np.zeros((B, t + 1, 96), dtype=np.uint8)
+    vs, plains = [], []
+    for j in range(B):
+        msg = bytes(rnd.randrange(256) for _ in range(5 + 13 * j))
+        ct = o.encrypt_with_r(pk, rnd.randrange(1, o.R), msg)
+        ids = sorted(rnd.sample(range(N), t + 1))
+        idx[j] = ids
+        for k, i in enumerate(ids):
+            shares[j, k] = u8(o.g1_uncompressed(o.decrypt_share_no_verify(o.secret_key_share(poly, i), ct)))
+        vs.append(ct[1])
+        plains.append(msg)
+    v, off = pack_messages(vs)
+    out, st = engine.decrypt(t, idx, shares, v, off)
+    assert not st.any()
+    assert bytes(out[: int(off[-1])]) == b"".join(plains)
+    g, st = engine.combine_g1(t, idx, shares)
+    assert not st.any()
+    assert bytes(g[0]) == o.g1_uncompressed(o.interpolate(o.E1, t, [(int(idx[0, k]), o.g1_from_uncompressed(bytes(shares[0, k]), check=False)) for k in range(t + 1)]))
+
+
+def test_hash_g2_matches_oracle(engine, rnd):
+    """hash_g2 (src/lib.rs:691-694); lengths straddle the 136-byte SHA3 rate."""
+    msgs = [b"", b"a", b"Test message", bytes(range(135)), bytes(range(136)), bytes(range(137)), bytes(300)]
+    msgs += [bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 80))) for _ in range(60)]
+    flat, off = pack_messages(msgs)
+    out = engine.hash_g2(flat, off)
+    for j in list(range(7)) + rnd.sample(range(7, len(msgs)), 5):
+        assert bytes(out[j]) == o.g2_uncompressed(o.hash_g2(msgs[j])), j
+
+
+def test_hash_g1_g2_and_xor(engine, rnd):
+    """hash_g1_g2 (src/lib.rs:697-707) both sides of the 64-byte switch; xor_with_hash (:710-715)."""
+    pts = [o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)) for _ in range(4)]
+    msgs = [bytes(range(10)), bytes(range(64)), bytes(range(65)), bytes(200)]
+    flat, off = pack_messages(msgs)
+    out, st = engine.hash_g1_g2(g1s(pts), flat, off)
+    assert not st.any()
+    for j in range(4):
+        assert bytes(out[j]) == o.g2_uncompressed(o.hash_g1_g2(pts[j], msgs[j])), j
+    x, st = engine.xor_with_hash(g1s(pts), flat, off)
+    assert not st.any()
+    assert bytes(x[: int(off[-1])]) == b"".join(o.xor_with_hash(p, m) for p, m in zip(pts, msgs))
+
+
+def test_pairing_check_matches_oracle(engine, rnd):
+    """e(a,b) == e(c,d) (src/lib.rs:109,185,511): true, false and infinity cases."""
+    B = 70
+    a_, b_, c_, d_, want = [], [], [], [], []
+    for j in range(B):
+        x, y = rnd.randrange(1, o.R), rnd.randrange(1, o.R)
+        a_.append(o.E1.mul(o.G1_GEN, x))
+        b_.append(o.E2.mul(o.G2_GEN, y))
+        c_.append(o.G1_GEN)
+        good = (j % 3 != 1)
+        d_.append(o.E2.mul(o.G2_GEN, (x * y + (0 if good else 1)) % o.R))
+        want.append(1 if good else 0)
+    # infinity operands: e(inf, b) == e(c, inf) -> 1 == 1
+    a_[2], d_[2], want[2] = None, None, 1
+    a_[3], want[3] = None, 0
+    ok = engine.pairing_check(g1s(a_), g2s(b_), g1s(c_), g2s(d_))
+    assert ok.tolist() == want
+    # oracle agrees on a sample (two full pairings, as the reference)
+    for j in (0, 1, 2, 3):
+        assert o.pairing_check(a_[j], b_[j], c_[j], d_[j]) == bool(want[j])
+    # broadcast of the constant operand (stride 0)
+    ok2 = engine.pairing_check(g1s(a_), g2s(b_), u8(o.g1_uncompressed(o.G1_GEN)), g2s(d_))
+    assert ok2.tolist() == want
+
+
+def test_sign_combine_verify_pipeline(engine, rnd):
+    """The doc-test of combine_signatures (src/lib.rs:583-607) and test_threshold_sig (:822-873)
+    at the C ABI: sign shares -> verify shares -> combine two disjoint subsets -> same signature
+    -> verifies under the master key; wrong message fails."""
+    t, N = 3, 10
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    commit = o.commitment(poly)
+    sks = [o.secret_key_share(poly, i) for i in range(N)]
+    msgs = [b"Totally real news", b"Real news", b"Happy birthday!"]
+    flat, off = pack_messages(msgs)
+    shares, st = engine.sign(frs(sks), flat, off)  # (B, N, 192)
+    assert not st.any()
+    assert bytes(shares[0, 4]) == o.g2_uncompressed(o.sign(sks[4], msgs[0]))
+    # share verification under public_key_share(i)
+    pks = g1s([o.public_key_share(commit, i) for i in range(N)])
+    for j in range(len(msgs)):
+        m_flat, m_off = pack_messages([msgs[j]] * N)
+        ok = engine.verify_sig(pks, np.ascontiguousarray(shares[j]), m_flat, m_off)
+        assert ok.all()
+    sets = [[5, 8, 7, 9], [0, 1, 2, 3]]
+    sigs = []
+    for ids in sets:
+        ids = sorted(ids)
+        idx = np.array([ids] * len(msgs), dtype=np.uint64)
+        sh = np.ascontiguousarray(shares[:, ids, :])
+        sig, st = engine.combine_g2(t, idx, sh)
+        assert not st.any()
+        sigs.append(sig)
+    assert (sigs[0] == sigs[1]).all()
+    assert bytes(sigs[0][1]) == o.g2_uncompressed(o.sign(poly[0], msgs[1]))
+    pk = u8(o.g1_uncompressed(commit[0]))
+    assert engine.verify_sig(pk, sigs[0], flat, off).all()
+    wrong_flat, wrong_off = pack_messages([msgs[1], msgs[2], msgs[0]])
+    assert not engine.verify_sig(pk, sigs[0], wrong_flat, wrong_off).any()
+
+
+def test_ciphertext_verify_and_decryption_shares(engine, rnd):
+    """Ciphertext::verify (src/lib.rs:508-512), verify_decryption_share (:182-186),
+    test_threshold_enc (:907-939): tampered v fails."""
+    t, N = 2, 5
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    commit = o.commitment(poly)
+    cts = [o.encrypt_with_r(commit[0], rnd.randrange(1, o.R), m) for m in (b"Totally real news", bytes(100))]
+    bad = (cts[0][0], b"X" + cts[0][1][1:], cts[0][2])
+    allc = cts + [bad]
+    v, off = pack_messages([c[1] for c in allc])
+    ok = engine.ciphertext_verify(g1s([c[0] for c in allc]), v, off, g2s([c[2] for c in allc]))
+    assert ok.tolist() == [1, 1, 0]
+    assert [o.ciphertext_verify(c) for c in allc] == [True, True, False]
+    # decryption shares of ct 0 by the N nodes, verified against their public key shares
+    ct = cts[0]
+    dsh = [o.decrypt_share_no_verify(o.secret_key_share(poly, i), ct) for i in range(N)]
+    dsh_bad = list(dsh)
+    dsh_bad[1] = dsh[2]
+    pks = g1s([o.public_key_share(commit, i) for i in range(N)])
+    v1, off1 = pack_messages([ct[1]] * N)
+    u = g1s([ct[0]] * N)
+    w = g2s([ct[2]] * N)
+    assert engine.verify_decryption_share(pks, g1s(dsh), u, v1, off1, w).all()
+    assert engine.verify_decryption_share(pks, g1s(dsh_bad), u, v1, off1, w).tolist() == [1, 0, 1, 1, 1]
+
+
+def test_compress(engine, rnd):
+    """to_bytes (src/lib.rs:149-153, 255-259)."""
+    p1 = [o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)) for _ in range(5)] + [None]
+    p2 = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(5)] + [None]
+    c1, st1 = engine.g1_compress(g1s(p1))
+    c2, st2 = engine.g2_compress(g2s(p2))
+    assert not st1.any() and not st2.any()
+    assert [bytes(x) for x in c1] == [o.g1_compressed(p) for p in p1]
+    assert [bytes(x) for x in c2] == [o.g2_compressed(p) for p in p2]
+
+
+def test_device_resident_io(engine, rnd):
+    """Device-pointer mode (torch CUDA tensors own the memory): same bytes as host mode."""
+    import torch
+    S, B = 2, 64
+    sks = frs([rnd.randrange(o.R) for _ in range(S)])
+    pts = g2s([o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(4)] * 16)
+    host, _ = engine.g2_mul(sks, pts)
+    dev, st = engine.g2_mul(torch.from_numpy(sks).cuda(), torch.from_numpy(pts).cuda())
+    torch.cuda.synchronize()
+    engine.sync()
+    assert (dev.cpu().numpy() == host).all() and not st.cpu().numpy().any()

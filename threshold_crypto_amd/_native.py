@@ -1,0 +1,92 @@
+"""ctypes binding of libtc_amd.so (the C ABI declared in include/tc_amd.h).
+
+The shared library is the product: if it is missing or cannot create a context on a HIP
+device the import / the call fails loudly -- there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtc_amd.so")
+
+TC_OK = 0
+TC_ERR_INVALID_ARG = -1
+TC_ERR_HIP = -2
+TC_ERR_NO_DEVICE = -3
+
+JOB_OK = 0
+JOB_NOT_ENOUGH_SHARES = 1
+JOB_DUPLICATE_ENTRY = 2
+JOB_INVALID_ENCODING = 3
+
+_u8p = ctypes.c_void_p      # data pointers are passed as raw addresses (host or device)
+_u64p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_ctx = ctypes.c_void_p
+
+# name -> argument types (after the leading tc_ctx*); every function returns int
+PROTOTYPES = {
+    "tc_hash_g2_batch": [_u8p, _u64p, _sz, _u8p],
+    "tc_hash_g1_g2_batch": [_u8p, _u8p, _u64p, _sz, _u8p, _u8p],
+    "tc_g2_mul_batch": [_u8p, _u8p, _sz, _sz, _u8p, _u8p],
+    "tc_g1_mul_batch": [_u8p, _u8p, _sz, _sz, _u8p, _u8p],
+    "tc_sign_batch": [_u8p, _u8p, _u64p, _sz, _sz, _u8p, _u8p],
+    "tc_combine_g2_batch": [_sz, _sz, _u64p, _u8p, _sz, _u8p, _u8p],
+    "tc_combine_g1_batch": [_sz, _sz, _u64p, _u8p, _sz, _u8p, _u8p],
+    "tc_decrypt_batch": [_sz, _sz, _u64p, _u8p, _u8p, _u64p, _sz, _u8p, _u8p],
+    "tc_xor_with_hash_batch": [_u8p, _u8p, _u64p, _sz, _u8p, _u8p],
+    "tc_pairing_check_batch": [_u8p, _sz, _u8p, _sz, _u8p, _sz, _u8p, _sz, _sz, _u8p],
+    "tc_verify_g2_batch": [_u8p, _sz, _u8p, _u8p, _sz, _u8p],
+    "tc_verify_sig_batch": [_u8p, _sz, _u8p, _u8p, _u64p, _sz, _u8p],
+    "tc_ciphertext_verify_batch": [_u8p, _u8p, _u64p, _u8p, _sz, _u8p],
+    "tc_verify_decryption_share_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p],
+    "tc_g1_compress_batch": [_u8p, _sz, _u8p, _u8p],
+    "tc_g2_compress_batch": [_u8p, _sz, _u8p, _u8p],
+}
+
+CONTEXT_SYMBOLS = ["tc_ctx_create", "tc_ctx_destroy", "tc_ctx_set_device_io", "tc_ctx_set_stream", "tc_sync",
+                   "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version"]
+
+ALL_SYMBOLS = CONTEXT_SYMBOLS + sorted(PROTOTYPES)
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libtc_amd.so; raises NativeLibraryMissing when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            "%s not found: build it with `python -m threshold_crypto_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.tc_ctx_create.argtypes = [ctypes.POINTER(_ctx), ctypes.c_int]
+    lib.tc_ctx_create.restype = ctypes.c_int
+    lib.tc_ctx_destroy.argtypes = [_ctx]
+    lib.tc_ctx_destroy.restype = None
+    lib.tc_ctx_set_device_io.argtypes = [_ctx, ctypes.c_int]
+    lib.tc_ctx_set_device_io.restype = ctypes.c_int
+    lib.tc_ctx_set_stream.argtypes = [_ctx, ctypes.c_void_p]
+    lib.tc_ctx_set_stream.restype = ctypes.c_int
+    lib.tc_ctx_set_timing.argtypes = [_ctx, ctypes.c_int]
+    lib.tc_ctx_set_timing.restype = ctypes.c_int
+    lib.tc_last_kernel_ms.argtypes = [_ctx]
+    lib.tc_last_kernel_ms.restype = ctypes.c_double
+    lib.tc_sync.argtypes = [_ctx]
+    lib.tc_sync.restype = ctypes.c_int
+    lib.tc_last_error.argtypes = [_ctx]
+    lib.tc_last_error.restype = ctypes.c_char_p
+    lib.tc_version.argtypes = []
+    lib.tc_version.restype = ctypes.c_char_p
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_ctx] + args
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib

@@ -1,0 +1,49 @@
+// gfx950 kernels: Lagrange coefficients and the share combiner (interpolate).
+#include "tc_jobs.h"
+#include "tc_launch.h"
+
+namespace tc {
+
+// one lane per (job, sample position): lambda_i of job j
+__global__ __launch_bounds__(kBlock) void k_lagrange(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t,
+                                                     size_t B, uint32_t* __restrict__ lam,
+                                                     uint8_t* __restrict__ status) {
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t k = t + 1;
+  if (tid >= B * k) return;
+  const size_t j = tid / k, i = tid % k;
+  uint8_t st = job_lagrange(idx + j * n_per_job, (int)t, (int)i, lam + tid * 8);
+  if (st && status) status[j] = st;
+}
+
+// one lane per job: sum_i lambda_i * share_i
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, const uint8_t* __restrict__ shares,
+                                                    const uint32_t* __restrict__ lam, size_t B,
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  constexpr int PB = PointIO<F>::BYTES;
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
+    PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
+    return;
+  }
+  uint8_t st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
+  if (status) status[j] = st;
+}
+
+void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
+                     uint8_t* status) {
+  const size_t n = B * (t + 1);
+  if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status);
+}
+void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
+                       size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_combine<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, shares, lam, B, out, status);
+}
+void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
+                       size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, shares, lam, B, out, status);
+}
+
+}  // namespace tc

@@ -1,0 +1,46 @@
+// gfx950 kernels: SHA3 -> ChaCha20 -> G2 hashing and the keystream XOR.
+#include "tc_jobs.h"
+#include "tc_launch.h"
+
+namespace tc {
+
+__global__ __launch_bounds__(kBlock) void k_hash_g2(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
+                                                    size_t B, uint8_t* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  job_hash_g2(msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192);
+}
+
+__global__ __launch_bounds__(kBlock) void k_hash_g1_g2(const uint8_t* __restrict__ g1, const uint8_t* __restrict__ msgs,
+                                                       const uint64_t* __restrict__ off, size_t B,
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  uint8_t st = job_hash_g1_g2(g1 + j * 96, msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192);
+  if (status) status[j] = st;
+}
+
+__global__ __launch_bounds__(kBlock) void k_xor_with_hash(const uint8_t* __restrict__ g1,
+                                                          const uint8_t* __restrict__ data,
+                                                          const uint64_t* __restrict__ off, size_t B,
+                                                          uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  if (status && status[j] != TC_JOB_OK) return;  // an earlier stage (combine) flagged the job
+  uint8_t st = job_xor_with_hash(g1 + j * 96, data + off[j], (size_t)(off[j + 1] - off[j]), out + off[j]);
+  if (status) status[j] = st;
+}
+
+void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out) {
+  if (B) hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B)), dim3(kBlock), 0, st, msgs, off, B, out);
+}
+void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
+                       uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status);
+}
+void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
+                          uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_xor_with_hash, dim3(grid_for(B)), dim3(kBlock), 0, st, g1, data, off, B, out, status);
+}
+
+}  // namespace tc

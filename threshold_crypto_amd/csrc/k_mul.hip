@@ -1,0 +1,53 @@
+// gfx950 kernels: batched G1/G2 scalar multiplication and point compression.
+#include "tc_jobs.h"
+#include "tc_launch.h"
+
+namespace tc {
+
+// One curve op per lane.  Lane order is signer-major (tid = s*B + j) so that the 64 lanes of
+// a wave share the signer's scalar: the bit-serial double-and-add stays wave-uniform.
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_point_mul(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts,
+                                                      size_t S, size_t B, uint8_t* __restrict__ out,
+                                                      uint8_t* __restrict__ status) {
+  constexpr int PB = PointIO<F>::BYTES;
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= S * B) return;
+  const size_t s = tid / B, j = tid % B;
+  const size_t o = j * S + s;
+  uint8_t st = job_point_mul<F>(fr + s * 32, pts + j * PB, out + o * PB);
+  if (status) status[o] = st;
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_compress(const uint8_t* __restrict__ in, size_t B,
+                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  uint8_t st = job_compress<F>(in + j * PointIO<F>::BYTES, out + j * PointIO<F>::CBYTES);
+  if (status) status[j] = st;
+}
+
+__global__ void k_fill_g1_generator(uint8_t* out96) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) g1_encode_uncompressed(g1_generator(), out96);
+}
+
+void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                   uint8_t* status) {
+  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+}
+void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                   uint8_t* status) {
+  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+}
+void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_compress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
+}
+void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_compress<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
+}
+void launch_fill_g1_generator(hipStream_t st, uint8_t* out96) {
+  hipLaunchKernelGGL(k_fill_g1_generator, dim3(1), dim3(64), 0, st, out96);
+}
+
+}  // namespace tc

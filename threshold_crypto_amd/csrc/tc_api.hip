@@ -1,0 +1,546 @@
+// C ABI of libtc_amd.so (declared in include/tc_amd.h): context, device staging and the
+// batch entry points.  Host code only; every computation is a gfx950 kernel launch (see
+// tc_launch.h).  There is no CPU compute path: without a HIP device tc_ctx_create fails.
+#include "tc_launch.h"
+#include "../../include/tc_amd.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Slot {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct tc_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool device_io = false;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  std::string err;
+  std::vector<Slot> slots;  // grow-only device staging buffers, reused across calls
+  size_t next_slot = 0;
+  uint8_t* g1_gen = nullptr;  // 96 B uncompressed G1 generator on the device
+};
+
+namespace {
+
+struct Call {
+  tc_ctx* c;
+  bool failed = false;
+  struct CopyBack {
+    void* host;
+    const void* dev;
+    size_t n;
+  };
+  std::vector<CopyBack> outs;
+  std::vector<std::pair<void*, size_t>> wipe;
+
+  explicit Call(tc_ctx* ctx) : c(ctx) {
+    c->next_slot = 0;
+    c->err.clear();
+    if (hipSetDevice(c->device) != hipSuccess) fail("hipSetDevice failed");
+  }
+  void fail(const std::string& m) {
+    if (!failed) c->err = m;
+    failed = true;
+  }
+  bool check(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+      fail(std::string(what) + ": " + hipGetErrorString(e));
+      return false;
+    }
+    return true;
+  }
+  void* scratch(size_t n) {
+    if (n == 0) n = 8;
+    if (c->next_slot >= c->slots.size()) c->slots.emplace_back();
+    Slot& s = c->slots[c->next_slot++];
+    if (s.cap < n) {
+      if (s.p) (void)hipFree(s.p);
+      s.p = nullptr;
+      s.cap = 0;
+      size_t cap = n + n / 4 + 256;
+      if (!check(hipMalloc(&s.p, cap), "hipMalloc")) return nullptr;
+      s.cap = cap;
+    }
+    return s.p;
+  }
+  // input operand: device pointer usable by kernels
+  template <class T>
+  const T* in(const T* p, size_t count, bool secret = false) {
+    if (c->device_io || p == nullptr) return p;
+    size_t n = count * sizeof(T);
+    void* d = scratch(n);
+    if (!d) return nullptr;
+    if (n && !check(hipMemcpyAsync(d, p, n, hipMemcpyHostToDevice, c->stream), "H2D copy")) return nullptr;
+    if (secret) wipe.emplace_back(d, n);
+    return (const T*)d;
+  }
+  // output operand: device pointer the kernels write; copied back in finish()
+  template <class T>
+  T* out(T* p, size_t count, bool zero = false) {
+    if (p == nullptr) return nullptr;
+    size_t n = count * sizeof(T);
+    T* d = p;
+    if (!c->device_io) {
+      d = (T*)scratch(n);
+      if (!d) return nullptr;
+      outs.push_back({p, d, n});
+    }
+    if (zero && n) check(hipMemsetAsync(d, 0, n, c->stream), "memset");
+    return d;
+  }
+  template <class T>
+  T* temp(size_t count, bool zero = false) {
+    size_t n = count * sizeof(T);
+    T* d = (T*)scratch(n);
+    if (d && zero && n) check(hipMemsetAsync(d, 0, n, c->stream), "memset");
+    return d;
+  }
+  void begin_timing() {
+    if (c->timing && !failed) check(hipEventRecord(c->ev0, c->stream), "event record");
+  }
+  void end_timing() {
+    if (c->timing && !failed) check(hipEventRecord(c->ev1, c->stream), "event record");
+  }
+  int finish() {
+    if (!failed) check(hipGetLastError(), "kernel launch");
+    for (auto& w : wipe) (void)hipMemsetAsync(w.first, 0, w.second, c->stream);  // zero secret scalars
+    if (!failed)
+      for (auto& o : outs)
+        if (o.n) check(hipMemcpyAsync(o.host, o.dev, o.n, hipMemcpyDeviceToHost, c->stream), "D2H copy");
+    if (!c->device_io || c->timing || failed) {
+      hipError_t e = hipStreamSynchronize(c->stream);
+      if (!failed) check(e, "stream sync");
+    }
+    if (c->timing && !failed) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+    }
+    return failed ? TC_ERR_HIP : TC_OK;
+  }
+};
+
+// total message bytes = off[B]; in device-io mode read it back (8 bytes)
+bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
+  if (!k.c->device_io) {
+    *total = off[B];
+    return true;
+  }
+  if (!k.check(hipMemcpyAsync(total, off + B, 8, hipMemcpyDeviceToHost, k.c->stream), "offset readback")) return false;
+  return k.check(hipStreamSynchronize(k.c->stream), "stream sync");
+}
+
+#define TC_REQUIRE(cond)            \
+  do {                              \
+    if (!(cond)) {                  \
+      if (ctx) ctx->err = "invalid argument: " #cond; \
+      return TC_ERR_INVALID_ARG;    \
+    }                               \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* tc_version(void) { return "tc_amd 0.1.0 (gfx950)"; }
+
+int tc_ctx_create(tc_ctx** out, int device) {
+  if (!out) return TC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TC_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return TC_ERR_INVALID_ARG;
+  if (hipSetDevice(device) != hipSuccess) return TC_ERR_HIP;
+  tc_ctx* c = new tc_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipMalloc((void**)&c->g1_gen, 96) != hipSuccess) {
+    tc_ctx_destroy(c);
+    return TC_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  tc::launch_fill_g1_generator(c->stream, c->g1_gen);
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+    // typically: no gfx950 code object for this device
+    tc_ctx_destroy(c);
+    return TC_ERR_NO_DEVICE;
+  }
+  *out = c;
+  return TC_OK;
+}
+
+void tc_ctx_destroy(tc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto& s : c->slots)
+    if (s.p) (void)hipFree(s.p);
+  if (c->g1_gen) (void)hipFree(c->g1_gen);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int tc_ctx_set_device_io(tc_ctx* ctx, int enabled) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  ctx->device_io = enabled != 0;
+  return TC_OK;
+}
+
+int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return TC_OK;
+}
+
+int tc_ctx_set_timing(tc_ctx* ctx, int enabled) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  ctx->timing = enabled != 0;
+  return TC_OK;
+}
+
+double tc_last_kernel_ms(const tc_ctx* ctx) { return ctx ? ctx->last_ms : 0.0; }
+
+int tc_sync(tc_ctx* ctx) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return TC_ERR_HIP;
+  return hipStreamSynchronize(ctx->stream) == hipSuccess ? TC_OK : TC_ERR_HIP;
+}
+
+const char* tc_last_error(const tc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ---- hashing ------------------------------------------------------------------------------
+int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out_g2) {
+  TC_REQUIRE(ctx && off && out_g2);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || msgs);
+  const uint8_t* d_msgs = k.in(msgs, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  uint8_t* d_out = k.out(out_g2, B * 192);
+  k.begin_timing();
+  if (!k.failed) tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_out);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
+                        uint8_t* out_g2, uint8_t* status) {
+  TC_REQUIRE(ctx && g1 && off && out_g2);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || msgs);
+  const uint8_t* d_g1 = k.in(g1, B * 96);
+  const uint8_t* d_msgs = k.in(msgs, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  uint8_t* d_out = k.out(out_g2, B * 192);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_hash_g1_g2(ctx->stream, d_g1, d_msgs, d_off, B, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
+// ---- scalar multiplication -----------------------------------------------------------------
+static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                     uint8_t* status) {
+  TC_REQUIRE(ctx && fr && pts && out);
+  if (S == 0 || B == 0) return TC_OK;
+  const size_t PB = g2 ? 192 : 96;
+  Call k(ctx);
+  const uint8_t* d_fr = k.in(fr, S * 32, /*secret=*/true);
+  const uint8_t* d_pts = k.in(pts, B * PB);
+  uint8_t* d_out = k.out(out, S * B * PB);
+  uint8_t* d_st = k.out(status, S * B);
+  k.begin_timing();
+  if (!k.failed) {
+    if (g2) tc::launch_g2_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
+    else tc::launch_g1_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_g2_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                    uint8_t* status) {
+  return point_mul(ctx, true, fr, pts, S, B, out, status);
+}
+
+int tc_g1_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                    uint8_t* status) {
+  return point_mul(ctx, false, fr, pts, S, B, out, status);
+}
+
+int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uint64_t* off, size_t S, size_t B,
+                  uint8_t* out_g2, uint8_t* status) {
+  TC_REQUIRE(ctx && fr && off && out_g2);
+  if (S == 0 || B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || msgs);
+  const uint8_t* d_fr = k.in(fr, S * 32, true);
+  const uint8_t* d_msgs = k.in(msgs, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_out = k.out(out_g2, S * B * 192);
+  uint8_t* d_st = k.out(status, S * B);
+  k.begin_timing();
+  if (!k.failed) {
+    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash);
+    tc::launch_g2_mul(ctx->stream, d_fr, d_hash, S, B, d_out, d_st);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+// ---- combination -----------------------------------------------------------------------------
+static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx, const uint8_t* shares, size_t B,
+                   uint8_t* out, uint8_t* status, const uint8_t* v, const uint64_t* off, uint8_t* plain) {
+  TC_REQUIRE(ctx && out && status);
+  TC_REQUIRE(t < (1u << 20));
+  if (B == 0) return TC_OK;
+  const size_t PB = g2 ? 192 : 96;
+  Call k(ctx);
+  if (n <= t) {
+    // samples.len() <= t  =>  Err(NotEnoughShares) for every job        (src/lib.rs:731-733)
+    if (ctx->device_io) {
+      k.check(hipMemsetAsync(status, TC_JOB_NOT_ENOUGH_SHARES, B, ctx->stream), "memset");
+      k.check(hipMemsetAsync(out, 0, B * PB, ctx->stream), "memset");
+    } else {
+      memset(status, TC_JOB_NOT_ENOUGH_SHARES, B);
+      memset(out, 0, B * PB);
+    }
+    return k.finish();
+  }
+  TC_REQUIRE(idx && shares);
+  uint64_t total = 0;
+  if (plain) {
+    TC_REQUIRE(off);
+    if (!total_bytes(k, off, B, &total)) return k.finish();
+    TC_REQUIRE(total == 0 || v);
+  }
+  const uint64_t* d_idx = k.in(idx, B * n);
+  const uint8_t* d_sh = k.in(shares, B * n * PB);
+  uint32_t* d_lam = k.temp<uint32_t>(B * (t + 1) * 8);
+  uint8_t* d_st = k.out(status, B, /*zero=*/true);
+  uint8_t* d_pt = plain ? k.temp<uint8_t>(B * PB) : k.out(out, B * PB);
+  const uint8_t* d_v = nullptr;
+  const uint64_t* d_off = nullptr;
+  uint8_t* d_plain = nullptr;
+  if (plain) {
+    d_v = k.in(v, (size_t)total);
+    d_off = k.in(off, B + 1);
+    d_plain = k.out(plain, (size_t)total);
+  }
+  k.begin_timing();
+  if (!k.failed) {
+    if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st);
+    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_sh, d_lam, B, d_pt, d_st);
+    else tc::launch_combine_g1(ctx->stream, t, n, d_sh, d_lam, B, d_pt, d_st);
+    if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_combine_g2_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+                        size_t B, uint8_t* out, uint8_t* status) {
+  return combine(ctx, true, t, n_per_job, idx, shares, B, out, status, nullptr, nullptr, nullptr);
+}
+
+int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+                        size_t B, uint8_t* out, uint8_t* status) {
+  return combine(ctx, false, t, n_per_job, idx, shares, B, out, status, nullptr, nullptr, nullptr);
+}
+
+int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
+                     const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
+  TC_REQUIRE(ctx && out && status && off);
+  if (n_per_job <= t) {
+    if (B == 0) return TC_OK;
+    Call k(ctx);
+    if (ctx->device_io) k.check(hipMemsetAsync(status, TC_JOB_NOT_ENOUGH_SHARES, B, ctx->stream), "memset");
+    else memset(status, TC_JOB_NOT_ENOUGH_SHARES, B);
+    return k.finish();
+  }
+  return combine(ctx, false, t, n_per_job, idx, shares_g1, B, out /*non-null marker*/, status, v, off, out);
+}
+
+int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
+                           uint8_t* out, uint8_t* status) {
+  TC_REQUIRE(ctx && g1 && off && out);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || data);
+  const uint8_t* d_g1 = k.in(g1, B * 96);
+  const uint8_t* d_data = k.in(data, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  uint8_t* d_out = k.out(out, (size_t)total);
+  uint8_t* d_st = k.out(status, B, /*zero=*/true);
+  k.begin_timing();
+  if (!k.failed) tc::launch_xor_with_hash(ctx->stream, d_g1, d_data, d_off, B, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
+// ---- pairing checks ---------------------------------------------------------------------------
+int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
+                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx && a && b && c && d && ok);
+  TC_REQUIRE((sa == 0 || sa >= 96) && (sc == 0 || sc >= 96) && (sb == 0 || sb >= 192) && (sd == 0 || sd >= 192));
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  auto span = [&](size_t stride, size_t bytes) { return stride ? (B - 1) * stride + bytes : bytes; };
+  const uint8_t* da = k.in(a, span(sa, 96));
+  const uint8_t* db = k.in(b, span(sb, 192));
+  const uint8_t* dc = k.in(c, span(sc, 96));
+  const uint8_t* dd = k.in(d, span(sd, 192));
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_pairing_check(ctx->stream, da, sa, db, sb, dc, sc, dd, sd, B, d_ok);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* sig, const uint8_t* hash,
+                       size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx && pk && sig && hash && ok);
+  TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  const uint8_t* d_pk = k.in(pk, pk_stride ? (B - 1) * pk_stride + 96 : 96);
+  const uint8_t* d_sig = k.in(sig, B * 192);
+  const uint8_t* d_hash = k.in(hash, B * 192);
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  // e(pk, hash) == e(g1, sig)                                           (src/lib.rs:109)
+  if (!k.failed) tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen, 0, d_sig, 192, B, d_ok);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* sig, const uint8_t* msgs,
+                        const uint64_t* off, size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx && pk && sig && off && ok);
+  TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || msgs);
+  const uint8_t* d_pk = k.in(pk, pk_stride ? (B - 1) * pk_stride + 96 : 96);
+  const uint8_t* d_sig = k.in(sig, B * 192);
+  const uint8_t* d_msgs = k.in(msgs, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  if (!k.failed) {
+    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash);
+    tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen, 0, d_sig, 192, B, d_ok);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, const uint64_t* off,
+                               const uint8_t* w, size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx && u && off && w && ok);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || v);
+  const uint8_t* d_u = k.in(u, B * 96);
+  const uint8_t* d_v = k.in(v, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  const uint8_t* d_w = k.in(w, B * 192);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  if (!k.failed) {
+    // an undecodable u leaves an infinity hash; the pairing kernel then rejects u itself
+    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr);
+    // e(g1, w) == e(u, hash)                                            (src/lib.rs:511)
+    tc::launch_pairing_check(ctx->stream, ctx->g1_gen, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_t pk_stride, const uint8_t* share,
+                                     const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
+                                     size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx && pk_share && share && u && off && w && ok);
+  TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || v);
+  const uint8_t* d_pk = k.in(pk_share, pk_stride ? (B - 1) * pk_stride + 96 : 96);
+  const uint8_t* d_share = k.in(share, B * 96);
+  const uint8_t* d_u = k.in(u, B * 96);
+  const uint8_t* d_v = k.in(v, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  const uint8_t* d_w = k.in(w, B * 192);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_st = k.temp<uint8_t>(B);
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  if (!k.failed) {
+    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st);
+    // e(share, hash) == e(pk_share, w)                                  (src/lib.rs:185)
+    tc::launch_pairing_check(ctx->stream, d_share, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+// ---- wire formats ------------------------------------------------------------------------------
+int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status) {
+  TC_REQUIRE(ctx && in96 && out48);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  const uint8_t* d_in = k.in(in96, B * 96);
+  uint8_t* d_out = k.out(out48, B * 48);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_g1_compress(ctx->stream, d_in, B, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* out96, uint8_t* status) {
+  TC_REQUIRE(ctx && in192 && out96);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  const uint8_t* d_in = k.in(in192, B * 192);
+  uint8_t* d_out = k.out(out96, B * 96);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_g2_compress(ctx->stream, d_in, B, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
+}  // extern "C"

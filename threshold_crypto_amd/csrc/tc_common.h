@@ -12,12 +12,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define TC_HD __host__ __device__ __forceinline__
-#define TC_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define TC_HD_NOINLINE __host__ __device__ __attribute__((noinline)) inline
 #define TC_D __device__ __forceinline__
 #define TC_CONST static constexpr
 #else
 #define TC_HD inline
-#define TC_HD_NOINLINE __attribute__((noinline))
+#define TC_HD_NOINLINE __attribute__((noinline)) inline
 #define TC_D inline
 #define TC_CONST static constexpr
 #endif

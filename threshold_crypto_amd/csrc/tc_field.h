@@ -132,15 +132,15 @@ TC_HD Mont<PR> mont_dbl(const Mont<PR>& a) {
 // Montgomery product a*b*R^-1 mod p, coarsely-integrated operand scanning (CIOS).  The top
 // limb of both moduli is < 2^31, so the running value never needs an (N+2)-th limb.
 template <class PR>
-TC_HD Mont<PR> mont_mul(const Mont<PR>& a, const Mont<PR>& b) {
+TC_HD void mont_mul_body(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   constexpr int N = PR::N;
   uint32_t t[N + 1];
   TC_UNROLL for (int i = 0; i <= N; i++) t[i] = 0;
   TC_UNROLL for (int i = 0; i < N; i++) {
     uint64_t c = 0;
-    const uint32_t bi = b.l[i];
+    const uint32_t bi = b[i];
     TC_UNROLL for (int j = 0; j < N; j++) {
-      uint64_t s = (uint64_t)a.l[j] * bi + t[j] + c;
+      uint64_t s = (uint64_t)a[j] * bi + t[j] + c;
       t[j] = (uint32_t)s;
       c = s >> 32;
     }
@@ -160,8 +160,50 @@ TC_HD Mont<PR> mont_mul(const Mont<PR>& a, const Mont<PR>& b) {
   Mont<PR> r;
   TC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
   mont_cond_sub_p(r);
+  TC_UNROLL for (int i = 0; i < N; i++) out[i] = r.l[i];
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TC_INLINE_MUL)
+// On the device the product is a REAL function (not inlined into every tower/curve routine:
+// that makes the pairing kernel's code object several MB and hipcc compile times unbounded).
+// Operands travel as 2N scalar u32 arguments so the AMDGPU calling convention keeps them in
+// VGPRs (aggregates beyond 16 registers would be passed through scratch memory).
+__device__ __attribute__((noinline)) inline Mont<FqParams> fq_mul_call(
+    uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+    uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+    uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
+  const uint32_t a[12] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11};
+  const uint32_t b[12] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11};
+  Mont<FqParams> r;
+  mont_mul_body<FqParams>(a, b, r.l);
   return r;
 }
+__device__ __attribute__((noinline)) inline Mont<FrParams> fr_mul_call(
+    uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+    uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7) {
+  const uint32_t a[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+  const uint32_t b[8] = {b0, b1, b2, b3, b4, b5, b6, b7};
+  Mont<FrParams> r;
+  mont_mul_body<FrParams>(a, b, r.l);
+  return r;
+}
+TC_HD Mont<FqParams> mont_mul(const Mont<FqParams>& a, const Mont<FqParams>& b) {
+  return fq_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
+                     a.l[11], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9],
+                     b.l[10], b.l[11]);
+}
+TC_HD Mont<FrParams> mont_mul(const Mont<FrParams>& a, const Mont<FrParams>& b) {
+  return fr_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], b.l[0], b.l[1], b.l[2],
+                     b.l[3], b.l[4], b.l[5], b.l[6], b.l[7]);
+}
+#else
+template <class PR>
+TC_HD Mont<PR> mont_mul(const Mont<PR>& a, const Mont<PR>& b) {
+  Mont<PR> r;
+  mont_mul_body<PR>(a.l, b.l, r.l);
+  return r;
+}
+#endif
 
 template <class PR>
 TC_HD Mont<PR> mont_sqr(const Mont<PR>& a) {
@@ -239,7 +281,7 @@ struct Fe {
   TC_HD static Fe from_canonical(const uint32_t* limbs) { return Fe{mont_from_canonical<PR>(limbs)}; }
   TC_HD void to_canonical(uint32_t* limbs) const { mont_to_canonical(v, limbs); }
   // Fermat inverse a^(p-2); 0 -> 0
-  TC_HD Fe inv() const {
+  TC_HD_NOINLINE Fe inv() const {
     return field_pow_fixed(*this, [](int i) { return PR::pm2(i); }, PR::bits);
   }
   TC_HD static Fe select(bool c, const Fe& a, const Fe& b) {

@@ -13,7 +13,7 @@ namespace tc {
 // ---------------------------------------------------------------------------------------
 TC_HD uint64_t rotl64(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
 
-TC_HD void keccak_f1600(uint64_t* s) {
+TC_HD_NOINLINE void keccak_f1600(uint64_t* s) {
   const uint64_t RC[24] = {
       0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
       0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
@@ -98,7 +98,7 @@ struct ChaChaRng {
     counter = 0;
     idx = 16;
   }
-  TC_HD void refill() {
+  TC_HD_NOINLINE void refill() {
     uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
     uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3];
     uint32_t x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
@@ -122,7 +122,7 @@ struct ChaChaRng {
 
 // ff_derive 0.6 random() for Fq: 6 x next_u64 (12 words, limb 0 first), top limb masked to 61
 // bits, accept if < q; the accepted bit pattern IS the Montgomery representation.
-TC_HD Fq fq_random(ChaChaRng& rng) {
+TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
   Fq r;
   bool ok = false;
   TC_NOUNROLL while (!ok) {
@@ -134,7 +134,7 @@ TC_HD Fq fq_random(ChaChaRng& rng) {
 }
 
 // Square root in Fq2 (q = 3 mod 4), Algorithm 9 of eprint 2012/685.  false for non-squares.
-TC_HD bool fq2_sqrt(const Fq2& a, Fq2& out) {
+TC_HD_NOINLINE bool fq2_sqrt(const Fq2& a, Fq2& out) {
   if (a.is_zero()) {
     out = Fq2::zero();
     return true;

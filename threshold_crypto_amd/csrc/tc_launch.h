@@ -1,0 +1,38 @@
+// Host-side launch prototypes of the gfx950 kernels (one translation unit per kernel family
+// so hipcc can build them in parallel).  All pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tc {
+
+constexpr int kBlock = 64;  // one wavefront per workgroup: the jobs are register/scratch heavy
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                   uint8_t* status);
+void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+                   uint8_t* status);
+void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
+void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
+
+void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
+                     uint8_t* status);
+void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
+                       size_t B, uint8_t* out, uint8_t* status);
+void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
+                       size_t B, uint8_t* out, uint8_t* status);
+
+void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
+                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok);
+
+void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out);
+void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
+                       uint8_t* out, uint8_t* status);
+void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
+                          uint8_t* out, uint8_t* status);
+void launch_fill_g1_generator(hipStream_t st, uint8_t* out96);
+
+}  // namespace tc

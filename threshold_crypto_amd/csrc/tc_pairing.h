@@ -17,7 +17,7 @@ struct LineCoeffs {
 };
 
 // Algorithm 26 of eprint 2010/354 (Jacobian doubling + tangent line), a = 0.
-TC_HD LineCoeffs miller_doubling_step(G2Jac& r) {
+TC_HD_NOINLINE LineCoeffs miller_doubling_step(G2Jac& r) {
   Fq2 tmp0 = r.x.sqr();
   Fq2 tmp1 = r.y.sqr();
   Fq2 tmp2 = tmp1.sqr();
@@ -40,7 +40,7 @@ TC_HD LineCoeffs miller_doubling_step(G2Jac& r) {
 }
 
 // Algorithm 27 of eprint 2010/354 (mixed addition + chord line).
-TC_HD LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
+TC_HD_NOINLINE LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
   Fq2 zsq = r.z.sqr();
   Fq2 ysq = q.y.sqr();
   Fq2 t0 = zsq * q.x;
@@ -112,7 +112,7 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
 }
 
 // f^|x| followed by conjugation (x < 0), for f in the cyclotomic subgroup
-TC_HD Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
+TC_HD_NOINLINE Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
   Fq12 r = f;
   bool started = false;
   TC_NOUNROLL for (int i = 63; i >= 0; i--) {
@@ -127,7 +127,7 @@ TC_HD Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
 
 // f^(3 (q^12-1)/r): easy part, then the y0..y3 hard-part chain with cyclotomic squarings.
 // (The factor 3 is a property of this chain; 3 does not divide r, so "== 1" is unaffected.)
-TC_HD Fq12 final_exponentiation(const Fq12& f) {
+TC_HD_NOINLINE Fq12 final_exponentiation(const Fq12& f) {
   Fq12 r = f.conj() * f.inv();  // f^(q^6-1)
   r = r.frobenius(2) * r;       // ^(q^2+1): r is now in the cyclotomic subgroup
   const uint64_t x = BLS_X_ABS;

@@ -33,7 +33,7 @@ struct Fq2 {
   TC_HD Fq2 scale(const Fq& k) const { return Fq2{c0 * k, c1 * k}; }
   // times the non-residue (1 + u)
   TC_HD Fq2 mul_xi() const { return Fq2{c0 - c1, c0 + c1}; }
-  TC_HD Fq2 inv() const {
+  TC_HD_NOINLINE Fq2 inv() const {
     Fq t = (c0.sqr() + c1.sqr()).inv();
     return Fq2{c0 * t, -(c1 * t)};
   }
@@ -50,7 +50,7 @@ struct Fq6 {
   TC_HD Fq6 operator+(const Fq6& b) const { return Fq6{c0 + b.c0, c1 + b.c1, c2 + b.c2}; }
   TC_HD Fq6 operator-(const Fq6& b) const { return Fq6{c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
   TC_HD Fq6 operator-() const { return Fq6{-c0, -c1, -c2}; }
-  TC_HD Fq6 operator*(const Fq6& b) const {
+  TC_HD_NOINLINE Fq6 operator*(const Fq6& b) const {
     Fq2 t0 = c0 * b.c0;
     Fq2 t1 = c1 * b.c1;
     Fq2 t2 = c2 * b.c2;
@@ -61,7 +61,7 @@ struct Fq6 {
     return r;
   }
   // CH-SQR2 (Chung-Hasan): 2 mul + 3 sqr in Fq2
-  TC_HD Fq6 sqr() const {
+  TC_HD_NOINLINE Fq6 sqr() const {
     Fq2 s0 = c0.sqr();
     Fq2 ab = c0 * c1;
     Fq2 s1 = ab.dbl();
@@ -77,7 +77,7 @@ struct Fq6 {
   }
   TC_HD Fq6 mul_by_v() const { return Fq6{c2.mul_xi(), c0, c1}; }
   // sparse: times (b0 + b1 v)
-  TC_HD Fq6 mul_by_01(const Fq2& b0, const Fq2& b1) const {
+  TC_HD_NOINLINE Fq6 mul_by_01(const Fq2& b0, const Fq2& b1) const {
     Fq2 aa = c0 * b0;
     Fq2 bb = c1 * b1;
     Fq6 r;
@@ -87,8 +87,8 @@ struct Fq6 {
     return r;
   }
   // sparse: times (b1 v)
-  TC_HD Fq6 mul_by_1(const Fq2& b1) const { return Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1}; }
-  TC_HD Fq6 inv() const {
+  TC_HD_NOINLINE Fq6 mul_by_1(const Fq2& b1) const { return Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1}; }
+  TC_HD_NOINLINE Fq6 inv() const {
     Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
     Fq2 t1 = c2.sqr().mul_xi() - c0 * c1;
     Fq2 t2 = c1.sqr() - c0 * c2;
@@ -113,7 +113,7 @@ struct Fq12 {
   Fq6 c0, c1;
   TC_HD static Fq12 one() { return Fq12{Fq6::one(), Fq6::zero()}; }
   TC_HD bool operator==(const Fq12& b) const { return c0 == b.c0 && c1 == b.c1; }
-  TC_HD Fq12 operator*(const Fq12& b) const {
+  TC_HD_NOINLINE Fq12 operator*(const Fq12& b) const {
     Fq6 t0 = c0 * b.c0;
     Fq6 t1 = c1 * b.c1;
     Fq12 r;
@@ -122,18 +122,18 @@ struct Fq12 {
     return r;
   }
   // complex squaring over Fq6: 2 Fq6 mul
-  TC_HD Fq12 sqr() const {
+  TC_HD_NOINLINE Fq12 sqr() const {
     Fq6 ab = c0 * c1;
     Fq6 t = (c0 + c1) * (c0 + c1.mul_by_v()) - ab - ab.mul_by_v();
     return Fq12{t, ab + ab};
   }
   TC_HD Fq12 conj() const { return Fq12{c0, -c1}; }
-  TC_HD Fq12 inv() const {
+  TC_HD_NOINLINE Fq12 inv() const {
     Fq6 t = (c0.sqr() - c1.sqr().mul_by_v()).inv();
     return Fq12{c0 * t, -(c1 * t)};
   }
   // sparse multiplication by (d0 + d1 v) + (d4 v) w -- the Miller-loop line shape
-  TC_HD Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
+  TC_HD_NOINLINE Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
     Fq6 aa = c0.mul_by_01(d0, d1);
     Fq6 bb = c1.mul_by_1(d4);
     Fq2 o = d1 + d4;
@@ -143,7 +143,7 @@ struct Fq12 {
     return r;
   }
   // a^(q^k), k in {1,2,3}
-  TC_HD Fq12 frobenius(int k) const {
+  TC_HD_NOINLINE Fq12 frobenius(int k) const {
     const bool cj = (k & 1);
     Fq12 r;
     r.c0.c0 = cj ? c0.c0.conj() : c0.c0;
@@ -156,7 +156,7 @@ struct Fq12 {
   }
   // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part
   // of the final exponentiation): 9 Fq2 squarings' worth instead of 2 Fq6 mul.
-  TC_HD Fq12 cyclotomic_sqr() const {
+  TC_HD_NOINLINE Fq12 cyclotomic_sqr() const {
     // view as three Fq4 = Fq2[s]/(s^2 - xi) pairs: (c0.c0, c1.c1), (c1.c0, c0.c2), (c0.c1, c1.c2)
     Fq2 z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2;
     Fq2 t0, t1, t2, t3;
