@@ -1,0 +1,163 @@
+"""ctypes loader for Oracle B (oracle/libtc_oracle.so, built from oracle/c/tc_oracle.c).
+TEST INFRASTRUCTURE ONLY -- see the header of c/tc_oracle.c."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtc_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "c", "tc_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.or_fq_mul_count.restype = ctypes.c_uint64
+        for name in ("or_hash_g2", "or_sha3_256", "or_fq_mul_count_reset"):
+            getattr(_lib, name).restype = None
+        sz = ctypes.c_size_t
+        cp = ctypes.c_char_p
+        vp = ctypes.c_void_p
+        _lib.or_hash_g2.argtypes = [cp, sz, cp]
+        _lib.or_hash_g1_g2.argtypes = [cp, cp, sz, cp]
+        _lib.or_xor_with_hash.argtypes = [cp, cp, sz, cp]
+        _lib.or_g2_mul.argtypes = [cp, cp, cp]
+        _lib.or_g1_mul.argtypes = [cp, cp, cp]
+        _lib.or_sign.argtypes = [cp, cp, sz, cp]
+        _lib.or_lagrange.argtypes = [sz, vp, cp]
+        _lib.or_combine_g2.argtypes = [sz, sz, vp, cp, cp]
+        _lib.or_combine_g1.argtypes = [sz, sz, vp, cp, cp]
+        _lib.or_threshold_decrypt.argtypes = [sz, sz, vp, cp, cp, sz, cp]
+        _lib.or_pairing_check.argtypes = [cp, cp, cp, cp]
+        _lib.or_pairing_gt.argtypes = [cp, cp, cp]
+        _lib.or_verify_g2.argtypes = [cp, cp, cp]
+        _lib.or_verify.argtypes = [cp, cp, cp, sz]
+        _lib.or_ciphertext_verify.argtypes = [cp, cp, sz, cp]
+        _lib.or_verify_decryption_share.argtypes = [cp, cp, cp, cp, sz, cp]
+        _lib.or_g1_compress.argtypes = [cp, cp]
+        _lib.or_g2_compress.argtypes = [cp, cp]
+        _lib.or_sha3_256.argtypes = [cp, sz, cp]
+    return _lib
+
+
+def _buf(n):
+    return ctypes.create_string_buffer(n)
+
+
+def _idx(ids):
+    return (ctypes.c_uint64 * len(ids))(*ids)
+
+
+def hash_g2(msg):
+    out = _buf(192)
+    load().or_hash_g2(bytes(msg), len(msg), out)
+    return out.raw
+
+
+def hash_g1_g2(g1, msg):
+    out = _buf(192)
+    rc = load().or_hash_g1_g2(g1, bytes(msg), len(msg), out)
+    return rc, out.raw
+
+
+def xor_with_hash(g1, data):
+    out = _buf(max(1, len(data)))
+    rc = load().or_xor_with_hash(g1, bytes(data), len(data), out)
+    return rc, out.raw[: len(data)]
+
+
+def g2_mul(fr, pt):
+    out = _buf(192)
+    return load().or_g2_mul(fr, pt, out), out.raw
+
+
+def g1_mul(fr, pt):
+    out = _buf(96)
+    return load().or_g1_mul(fr, pt, out), out.raw
+
+
+def sign(fr, msg):
+    out = _buf(192)
+    return load().or_sign(fr, bytes(msg), len(msg), out), out.raw
+
+
+def lagrange(t, ids):
+    out = _buf(32 * (t + 1))
+    rc = load().or_lagrange(t, _idx(ids), out)
+    return rc, [int.from_bytes(out.raw[32 * i: 32 * i + 32], "little") for i in range(t + 1)]
+
+
+def combine_g2(t, ids, shares):
+    out = _buf(192)
+    return load().or_combine_g2(t, len(ids), _idx(ids), b"".join(shares), out), out.raw
+
+
+def combine_g1(t, ids, shares):
+    out = _buf(96)
+    return load().or_combine_g1(t, len(ids), _idx(ids), b"".join(shares), out), out.raw
+
+
+def threshold_decrypt(t, ids, shares, v):
+    out = _buf(max(1, len(v)))
+    rc = load().or_threshold_decrypt(t, len(ids), _idx(ids), b"".join(shares), bytes(v), len(v), out)
+    return rc, out.raw[: len(v)]
+
+
+def pairing_check(a, b, c, d):
+    return load().or_pairing_check(a, b, c, d)
+
+
+def pairing_gt(a, b):
+    out = _buf(576)
+    rc = load().or_pairing_gt(a, b, out)
+    return rc, out.raw
+
+
+def verify_g2(pk, sig, h):
+    return load().or_verify_g2(pk, sig, h)
+
+
+def verify(pk, sig, msg):
+    return load().or_verify(pk, sig, bytes(msg), len(msg))
+
+
+def ciphertext_verify(u, v, w):
+    return load().or_ciphertext_verify(u, bytes(v), len(v), w)
+
+
+def verify_decryption_share(pk_share, share, u, v, w):
+    return load().or_verify_decryption_share(pk_share, share, u, bytes(v), len(v), w)
+
+
+def g1_compress(p):
+    out = _buf(48)
+    return load().or_g1_compress(p, out), out.raw
+
+
+def g2_compress(p):
+    out = _buf(96)
+    return load().or_g2_compress(p, out), out.raw
+
+
+def sha3_256(msg):
+    out = _buf(32)
+    load().or_sha3_256(bytes(msg), len(msg), out)
+    return out.raw
+
+
+def fq_mul_count(reset=False):
+    lib = load()
+    n = lib.or_fq_mul_count()
+    if reset:
+        lib.or_fq_mul_count_reset()
+    return n

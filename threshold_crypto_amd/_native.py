@@ -65,6 +65,13 @@ def load():
         raise NativeLibraryMissing(
             "%s not found: build it with `python -m threshold_crypto_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # libtc_amd.so needs libamdhip64.so.7.  PyTorch-ROCm bundles its own copy (same SONAME); two
+    # HIP/HSA runtimes in one process cannot both own the GPU, so when torch is installed let it
+    # load its runtime first and bind to that one.  Torch is not otherwise used here.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch absent: the system ROCm runtime is used
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.tc_ctx_create.argtypes = [ctypes.POINTER(_ctx), ctypes.c_int]
     lib.tc_ctx_create.restype = ctypes.c_int
