@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--t T] [--signers N]
+
+A "step" is one pass of the hot path over one batch: PublicKeySet::combine_signatures
+(src/lib.rs:608-615) for `batch` independent (message, share-set) jobs -- BASELINE config
+"t=3, N=10, batch=65 536 threshold signatures on 1xMI355X" -- through the C ABI
+(tc_combine_g2_batch) with every input already resident in HBM.  The same batch is then
+verified (PublicKey::verify_g2, src/lib.rs:108-110) and re-signed, and those rates are
+reported next to the headline value.  One process per GPU; for N > 1 the batch is per-rank
+(weak scaling), the key-set parameters are broadcast from rank 0 over RCCL and there is no
+data-path collective (jobs are independent).
+
+Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline leg
+and to spot-check the GPU output of the timed batch bit-for-bit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# frozen reference-algorithm work constants (Fq multiplications+squarings per unit), measured
+# with Oracle B's counter (oracle/c/tc_oracle.c or_fq_mul_count; see DESIGN.md "Work constants")
+W_FQMUL = {"combine_g2_t3": 31148, "g2_mul": 7771, "verify_g2": 41226, "hash_g2": 19604}
+MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient digits (CIOS)
+P_INT_TMACS = 27.2             # measured v_mad_u64_u32 issue rate, tools/ubench_valu (profiles/)
+HBM_PEAK_GBPS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--t", type=int, default=3)
+    ap.add_argument("--signers", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from threshold_crypto_amd.engine import Engine
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range
+
+    eng = Engine(local_rank)
+    t, N, B = args.t, args.signers, args.batch
+    start, _ = shard_range(B * world, world, rank)      # weak scaling: B jobs per rank
+    wl = ThresholdSigWorkload(eng, t, N, B, start=start)
+
+    # key-set parameters (commitment) travel rank 0 -> all ranks over RCCL/xGMI
+    commit = torch.from_numpy(np.frombuffer(b"".join(wl.sks.public_keys(eng).commit), dtype=np.uint8).copy()).to(dev)
+    commit = broadcast_key_set(commit, world)
+    master_pk = commit[:96].contiguous()
+
+    d_idx = torch.from_numpy(wl.idx.view(np.int64)).to(dev)
+    d_shares = torch.from_numpy(wl.shares).to(dev)
+    d_hashes = torch.from_numpy(wl.hashes).to(dev)
+    d_sk = torch.from_numpy(np.stack([np.frombuffer(s._bytes(), dtype=np.uint8) for s in wl.shares_sk[: t + 1]])).to(dev)
+
+    def sync():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.set_timing(True)
+    # ---- headline: combine_signatures ----------------------------------------------------
+    for _ in range(args.warmup):
+        sig, st = eng.combine_g2(t, d_idx, d_shares)
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sig, st = eng.combine_g2(t, d_idx, d_shares)
+        kernel_ms.append(eng.last_kernel_ms())
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world / (dt / args.steps)
+    assert int(st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
+
+    # ---- secondary: verify the combined signatures, re-sign ---------------------------------
+    ok = eng.verify_g2(master_pk, sig, d_hashes)
+    sync()
+    v0 = time.perf_counter()
+    ok = eng.verify_g2(master_pk, sig, d_hashes)
+    verify_kernel_ms = eng.last_kernel_ms()
+    sync()
+    verify_dt = time.perf_counter() - v0
+    n_ok = int(ok.to(torch.int32).sum().item())
+    assert n_ok == B, "combined signatures failed verification under the master key: %d/%d" % (n_ok, B)
+    s0 = time.perf_counter()
+    _sh, _st = eng.g2_mul(d_sk, d_hashes)
+    sign_kernel_ms = eng.last_kernel_ms()
+    sync()
+    sign_dt = time.perf_counter() - s0
+    # size-independent property at full size: the master key's own signature equals the combination
+    msig, _ = eng.g2_mul(torch.from_numpy(wl.master_sk_fr[None].copy()).to(dev), d_hashes)
+    sync()
+    assert bool((msig[:, 0] == sig).all().item()), "combine != master-key signature"
+
+    result = None
+    if rank == 0:
+        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        per_launch_mac = W_FQMUL["combine_g2_t3"] * MAC_PER_FQMUL * B if t == 3 else None
+        roofline = None
+        if per_launch_mac:
+            ach = per_launch_mac / (avg_kernel_ms * 1e-3) / 1e12
+            alg_bytes = ((t + 1) * (192 + 8) + 192) * B
+            roofline = {"bound": "valu_int32_mac", "achieved": round(ach, 3), "peak": P_INT_TMACS, "unit": "TMAC/s",
+                        "frac": round(ach / P_INT_TMACS, 4), "traffic": None,
+                        "kernel": "k_lagrange + k_combine<Fq2>", "kernel_ms": round(avg_kernel_ms, 3),
+                        "algorithmic_bytes_per_launch": alg_bytes,
+                        "hbm_achieved_GBps": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9, 3),
+                        "hbm_peak_GBps": HBM_PEAK_GBPS,
+                        "hbm_frac": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                        "note": "integer-VALU bound (SURVEY 8d): ~1e4 MAC per byte; HBM shown to prove it is not the bound"}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
+        result = {
+            "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (381-bit Montgomery, 12x32)",
+            "data": "synthetic",
+            "config": {"workload": "t=%d,N=%d,batch=%d threshold signatures (combine_signatures, G2), per GPU" % (t, N, B),
+                       "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world},
+            "pairing_verifies_per_s": round(B * world / verify_dt, 1),
+            "pairing_verify_kernel_ms": round(verify_kernel_ms, 3),
+            "share_signs_per_s": round((t + 1) * B * world / sign_dt, 1),
+            "share_sign_kernel_ms": round(sign_kernel_ms, 3),
+            "verified_all": True,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline(wl, gpu_sigs, t, seconds):
+    """Oracle B (plain-C port of the reference algorithm) on the host cores, bounded sample of the
+    SAME jobs; also the bit-exact spot check of the GPU output."""
+    import concurrent.futures
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    c_oracle.load()
+    cores = os.cpu_count() or 1
+    idx, shares = wl.idx, wl.shares
+
+    def one(j):
+        rc, out = c_oracle.combine_g2(t, [int(x) for x in idx[j]], [bytes(shares[j, k]) for k in range(t + 1)])
+        return j, rc, out
+
+    t0 = time.perf_counter()
+    one(0)
+    per = max(time.perf_counter() - t0, 1e-4)
+    n = int(max(cores, min(wl.B, seconds * cores / per)))
+    mism = 0
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=cores) as ex:   # ctypes drops the GIL
+        for j, rc, out in ex.map(one, range(n)):
+            if rc != 0 or out != bytes(gpu_sigs[j]):
+                mism += 1
+    dt = time.perf_counter() - t0
+    if mism:
+        raise AssertionError("GPU combine differs from the CPU oracle on %d of %d sampled jobs" % (mism, n))
+    return {"value": round(n / dt, 2), "unit": "combine_signatures/s", "cores": cores, "kind": "port",
+            "sample": "first %d jobs of the timed batch, %d threads, gcc -O3 x86-64-v3; each checked bit-exact "
+                      "against the GPU output" % (n, cores),
+            "single_job_ms": round(per * 1e3, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,13 @@ int tc_combine_g2_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t*
 /* Same in G1 (96 B points): the interpolate call of PublicKeySet::decrypt, src/lib.rs:618-625 */
 int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                         size_t B, uint8_t* out, uint8_t* status);
+/* out[j] = sum_{k < n} scalars[j*n + k] * points[j*n + k]   (scalars 32 B LE, canonical).
+ * Commitment::evaluate src/poly.rs:497-508 (= PublicKeySet::public_key_share src/lib.rs:570-573) is
+ * this linear combination with scalars (i+1)^k over the commitment coefficients. */
+int tc_g1_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                        uint8_t* status);
+int tc_g2_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                        uint8_t* status);
 /* PublicKeySet::decrypt src/lib.rs:618-626: out bytes[off[j]..off[j+1]] = xor_with_hash(combine_g1, v_j) */
 int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
                      const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status);

@@ -1,0 +1,165 @@
+"""Differential test of the DEVICE source (threshold_crypto_amd/csrc/*.h) compiled for the host
+by g++ (tests/hostsim, a test harness -- not a product path) against the oracle.  This is how
+the kernels' per-lane job bodies are validated in the GPU-less container; the `-m gpu` tests
+then check the same bodies as compiled by hipcc on the MI355X."""
+import ctypes
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+import tc_oracle as o
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
+LIB = os.path.join(HERE, "hostsim", "libtc_hostsim.so")
+CSRC = os.path.join(os.path.dirname(HERE), "threshold_crypto_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def L():
+    newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(newest, os.path.getmtime(SRC)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", LIB], check=True)
+    return ctypes.CDLL(LIB)
+
+
+@pytest.fixture(scope="module")
+def rnd():
+    return random.Random(99)
+
+
+def be(x):
+    return x.to_bytes(48, "big")
+
+
+def buf(n):
+    return ctypes.create_string_buffer(n)
+
+
+def test_field_ops(L, rnd):
+    for a, b in [(0, 0), (1, o.Q - 1), (o.Q - 1, o.Q - 1)] + [(rnd.randrange(o.Q), rnd.randrange(o.Q)) for _ in range(200)]:
+        out = buf(48)
+        assert L.hs_fq_mul(be(a), be(b), out) == 0 and int.from_bytes(out.raw, "big") == a * b % o.Q
+        s, d, n = buf(48), buf(48), buf(48)
+        L.hs_fq_addsub(be(a), be(b), s, d, n)
+        assert (int.from_bytes(s.raw, "big"), int.from_bytes(d.raw, "big"), int.from_bytes(n.raw, "big")) == (
+            (a + b) % o.Q, (a - b) % o.Q, (-a) % o.Q)
+    for a in [0, 1, o.Q - 1, rnd.randrange(o.Q)]:
+        out = buf(48)
+        L.hs_fq_inv(be(a), out)
+        assert int.from_bytes(out.raw, "big") == pow(a, o.Q - 2, o.Q)
+    assert L.hs_fq_mul(be(o.Q), be(1), buf(48)) == -1  # non-canonical input rejected
+
+
+def test_fq2_sqrt(L, rnd):
+    for _ in range(8):
+        a = (rnd.randrange(o.Q), rnd.randrange(o.Q))
+        out = buf(96)
+        r = L.hs_fq2_sqrt(be(a[0]) + be(a[1]), out)
+        assert (r == 1) == (o.f2_sqrt(a) is not None)
+        if r:
+            y = (int.from_bytes(out.raw[:48], "big"), int.from_bytes(out.raw[48:], "big"))
+            assert o.f2_sqr(y) == a
+
+
+def test_sha3_and_chacha(L, rnd):
+    for n in [0, 1, 14, 135, 136, 137, 272, 300]:
+        m = bytes(rnd.randrange(256) for _ in range(n))
+        out = buf(32)
+        L.hs_sha3(m, n, out)
+        assert out.raw == hashlib.sha3_256(m).digest()
+    seed = bytes(range(32))
+    W = (ctypes.c_uint32 * 40)()
+    L.hs_chacha_words(seed, 40, W)
+    rng = o.ChaChaRng(seed)
+    assert list(W) == [rng.next_u32() for _ in range(40)]
+
+
+def test_point_mul(L, rnd):
+    for k in [0, 1, 2, o.R - 1, rnd.randrange(o.R)]:
+        P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        out = buf(96)
+        assert L.hs_g1_mul(o.fr_to_bytes(k), o.g1_uncompressed(P), out) == 0
+        assert out.raw == o.g1_uncompressed(o.E1.mul(P, k))
+        Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+        out = buf(192)
+        assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0
+        assert out.raw == o.g2_uncompressed(o.E2.mul(Q2, k))
+    out = buf(192)
+    assert L.hs_g2_mul(o.fr_to_bytes(5), o.g2_uncompressed(None), out) == 0 and out.raw == o.g2_uncompressed(None)
+    bad = bytearray(o.g2_uncompressed(o.G2_GEN))
+    bad[191] ^= 1
+    assert L.hs_g2_mul(o.fr_to_bytes(5), bytes(bad), out) == 3
+
+
+@pytest.mark.parametrize("t", [0, 1, 3, 4, 6])
+def test_combine(L, rnd, t):
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    H = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    ids = sorted(rnd.sample(range(20), t + 1))
+    idx = (ctypes.c_uint64 * (t + 1))(*ids)
+    sh = [o.E2.mul(H, o.secret_key_share(poly, i)) for i in ids]
+    out = buf(192)
+    assert L.hs_combine_g2(t, idx, b"".join(o.g2_uncompressed(s) for s in sh), out) == 0
+    assert out.raw == o.g2_uncompressed(o.E2.mul(H, poly[0]))
+    U = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    sh1 = [o.E1.mul(U, o.secret_key_share(poly, i)) for i in ids]
+    out = buf(96)
+    assert L.hs_combine_g1(t, idx, b"".join(o.g1_uncompressed(s) for s in sh1), out) == 0
+    assert out.raw == o.g1_uncompressed(o.E1.mul(U, poly[0]))
+    for i in range(t + 1):
+        lam = buf(32)
+        assert L.hs_lagrange(idx, t, i, lam) == 0
+        if t:
+            assert int.from_bytes(lam.raw, "little") == o.lagrange_coeffs(t, [x + 1 for x in ids])[i]
+
+
+def test_combine_duplicate_quirk(L):
+    h = o.E2.mul(o.G2_GEN, 5)
+    pts = [o.E2.mul(h, k) for k in (3, 4, 9)]
+    ids = [1, 1, 4]
+    out = buf(192)
+    assert L.hs_combine_g2(2, (ctypes.c_uint64 * 3)(*ids), b"".join(o.g2_uncompressed(p) for p in pts), out) == 0
+    assert out.raw == o.g2_uncompressed(o.interpolate(o.E2, 2, list(zip(ids, pts))))
+
+
+def test_pairing(L, rnd):
+    a, b = rnd.randrange(o.R), rnd.randrange(o.R)
+    P, Qp = o.E1.mul(o.G1_GEN, a), o.E2.mul(o.G2_GEN, b)
+    out = buf(576)
+    assert L.hs_pairing_gt(o.g1_uncompressed(P), o.g2_uncompressed(Qp), out) == 0
+    flat = [x for f6 in o.pairing(P, Qp) for f2 in f6 for x in f2]
+    assert out.raw == b"".join(be(x) for x in flat)
+    assert L.hs_cyclo_check(o.g1_uncompressed(P), o.g2_uncompressed(Qp)) == 1
+    g1, inf1, inf2 = o.g1_uncompressed(o.G1_GEN), o.g1_uncompressed(None), o.g2_uncompressed(None)
+    good = o.g2_uncompressed(o.E2.mul(o.G2_GEN, a * b % o.R))
+    bad = o.g2_uncompressed(o.E2.mul(o.G2_GEN, (a * b + 1) % o.R))
+    assert L.hs_pairing_check(o.g1_uncompressed(P), o.g2_uncompressed(Qp), g1, good) == 1
+    assert L.hs_pairing_check(o.g1_uncompressed(P), o.g2_uncompressed(Qp), g1, bad) == 0
+    assert L.hs_pairing_check(inf1, o.g2_uncompressed(Qp), g1, inf2) == 1
+    assert L.hs_pairing_check(inf1, o.g2_uncompressed(Qp), g1, good) == 0
+
+
+def test_hash_and_kdf(L, rnd):
+    P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    for m in [b"", b"a", b"Test message", bytes(range(200))]:
+        out = buf(192)
+        L.hs_hash_g2(m, len(m), out)
+        assert out.raw == o.g2_uncompressed(o.hash_g2(m))
+    for v in (bytes(range(33)), bytes(range(64)), bytes(range(70))):
+        out = buf(192)
+        assert L.hs_hash_g1_g2(o.g1_uncompressed(P), v, len(v), out) == 0
+        assert out.raw == o.g2_uncompressed(o.hash_g1_g2(P, v))
+    d = bytes(range(100))
+    out = buf(100)
+    assert L.hs_xor_with_hash(o.g1_uncompressed(P), d, 100, out) == 0 and out.raw == o.xor_with_hash(P, d)
+    out = buf(48)
+    L.hs_compress_g1(o.g1_uncompressed(P), out)
+    assert out.raw == o.g1_compressed(P)
+    Qp = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    out = buf(96)
+    L.hs_compress_g2(o.g2_uncompressed(Qp), out)
+    assert out.raw == o.g2_compressed(Qp)

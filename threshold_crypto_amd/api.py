@@ -1,0 +1,403 @@
+"""Host-side mirror of the threshold_crypto 0.4.0 public API for the accelerated path.
+
+Same names, argument meaning and error behaviour as the Rust crate (file:line cited per
+method, relative to the reference repository), plus `*_batch` forms that hand a whole batch to
+one kernel launch.  The single-item methods are batches of one, so a reference test reads the
+same here.  Every group/pairing/hash computation goes through libtc_amd.so (HIP, gfx950);
+this module only packs bytes, orders shares (BTreeMap order) and maps status codes to the
+reference's error types.  It never imports the oracle and has no CPU fallback.
+
+Values are held in the reference's own canonical encodings: G1 96 B / G2 192 B uncompressed
+(`into_affine().into_uncompressed()`), Fr 32 B little-endian.
+"""
+import numpy as np
+
+from .engine import Engine, pack_messages
+
+PK_SIZE = 48   # src/lib.rs:71
+SIG_SIZE = 96  # src/lib.rs:75
+
+# Fr modulus: only used for key-set bookkeeping on secret polynomials (SecretKeySet), which the
+# reference also does on the CPU outside the hot path (src/poly.rs:358-369).
+_R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+_G1_GEN = bytes.fromhex(
+    "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+    "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")
+
+
+class Error(Exception):
+    """threshold_crypto::error::Error (src/error.rs:7-17)."""
+
+
+class NotEnoughShares(Error):
+    """Error::NotEnoughShares (src/error.rs:9-10)."""
+
+
+class DuplicateEntry(Error):
+    """Error::DuplicateEntry (src/error.rs:12-13)."""
+
+
+class FromBytesError(Exception):
+    """FromBytesError::Invalid (src/error.rs:37-41)."""
+
+
+_STATUS_EXC = {1: NotEnoughShares, 2: DuplicateEntry, 3: FromBytesError}
+
+_default_engine = None
+
+
+def default_engine():
+    """The process-wide Engine on GPU 0 (created on first use; raises without a GPU)."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+def set_default_engine(engine):
+    global _default_engine
+    _default_engine = engine
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def _stack(items, width):
+    out = np.empty((len(items), width), dtype=np.uint8)
+    for i, it in enumerate(items):
+        out[i] = np.frombuffer(bytes(it), dtype=np.uint8)
+    return out
+
+
+def _raise_status(st):
+    st = int(st)
+    if st:
+        raise _STATUS_EXC.get(st, Error)("job status %d" % st)
+
+
+def into_fr_plus_1(i):
+    """src/lib.rs:769-773 for the u64/usize IntoFr impls (src/into_fr.rs:16-26)."""
+    return (int(i) + 1) % _R
+
+
+class _G1Value:
+    __slots__ = ("raw",)
+    SIZE = 96
+
+    def __init__(self, raw):
+        raw = bytes(raw)
+        if len(raw) != self.SIZE:
+            raise ValueError("expected %d bytes" % self.SIZE)
+        self.raw = raw
+
+    def __eq__(self, other):
+        return type(other) is type(self) and other.raw == self.raw
+
+    def __hash__(self):
+        return hash(self.raw)
+
+    def to_bytes(self):
+        """Compressed form (to_bytes, src/lib.rs:149-153)."""
+        out, st = default_engine().g1_compress(_u8(self.raw)[None])
+        _raise_status(st[0])
+        return bytes(out[0])
+
+
+class _G2Value(_G1Value):
+    SIZE = 192
+
+    def to_bytes(self):
+        """Compressed form (to_bytes, src/lib.rs:255-259)."""
+        out, st = default_engine().g2_compress(_u8(self.raw)[None])
+        _raise_status(st[0])
+        return bytes(out[0])
+
+
+class Signature(_G2Value):
+    """struct Signature(G2) (src/lib.rs:202)."""
+
+    def parity(self):
+        """Signature::parity (src/lib.rs:237-243): xor-fold of the uncompressed bytes."""
+        x = 0
+        for b in self.raw:
+            x ^= b
+        return bin(x).count("1") % 2 != 0
+
+
+class SignatureShare(Signature):
+    """struct SignatureShare(pub Signature) (src/lib.rs:266)."""
+
+
+class DecryptionShare(_G1Value):
+    """struct DecryptionShare(G1) (src/lib.rs:517)."""
+
+
+class Ciphertext:
+    """struct Ciphertext(G1, Vec<u8>, G2) (src/lib.rs:473-478)."""
+
+    def __init__(self, u, v, w):
+        self.u, self.v, self.w = bytes(u), bytes(v), bytes(w)
+
+    def verify(self):
+        """Ciphertext::verify (src/lib.rs:508-512)."""
+        return bool(Ciphertext.verify_batch([self])[0])
+
+    @staticmethod
+    def verify_batch(cts, engine=None):
+        e = engine or default_engine()
+        v, off = pack_messages([c.v for c in cts])
+        return e.ciphertext_verify(_stack([c.u for c in cts], 96), v, off, _stack([c.w for c in cts], 192)).astype(bool)
+
+
+class PublicKey(_G1Value):
+    """struct PublicKey(G1) (src/lib.rs:79)."""
+
+    def verify_g2(self, sig, hash_g2_point):
+        """PublicKey::verify_g2 (src/lib.rs:108-110)."""
+        return bool(self.verify_g2_batch([sig], [hash_g2_point])[0])
+
+    def verify(self, sig, msg):
+        """PublicKey::verify (src/lib.rs:115-117)."""
+        return bool(self.verify_batch([sig], [msg])[0])
+
+    def verify_g2_batch(self, sigs, hashes, engine=None):
+        e = engine or default_engine()
+        return e.verify_g2(_u8(self.raw), _stack([s.raw for s in sigs], 192), _stack(hashes, 192)).astype(bool)
+
+    def verify_batch(self, sigs, msgs, engine=None):
+        e = engine or default_engine()
+        flat, off = pack_messages([bytes(m) for m in msgs])
+        return e.verify_sig(_u8(self.raw), _stack([s.raw for s in sigs], 192), flat, off).astype(bool)
+
+
+class PublicKeyShare(PublicKey):
+    """struct PublicKeyShare(PublicKey) (src/lib.rs:159)."""
+
+    def verify_decryption_share(self, share, ct):
+        """PublicKeyShare::verify_decryption_share (src/lib.rs:182-186)."""
+        return bool(PublicKeyShare.verify_decryption_share_batch([self], [share], [ct])[0])
+
+    @staticmethod
+    def verify_decryption_share_batch(pk_shares, shares, cts, engine=None):
+        e = engine or default_engine()
+        v, off = pack_messages([c.v for c in cts])
+        return e.verify_decryption_share(_stack([p.raw for p in pk_shares], 96), _stack([s.raw for s in shares], 96),
+                                         _stack([c.u for c in cts], 96), v, off,
+                                         _stack([c.w for c in cts], 192)).astype(bool)
+
+    @staticmethod
+    def verify_batch_shares(pk_shares, sig_shares, msgs, engine=None):
+        """PublicKeyShare::verify (src/lib.rs:177-179) for many (share key, share, msg) triples."""
+        e = engine or default_engine()
+        flat, off = pack_messages([bytes(m) for m in msgs])
+        return e.verify_sig(_stack([p.raw for p in pk_shares], 96), _stack([s.raw for s in sig_shares], 192), flat,
+                            off).astype(bool)
+
+
+def hash_g2(msg, engine=None):
+    """pub fn hash_g2 (src/lib.rs:691-694): 192-byte uncompressed G2 point."""
+    return hash_g2_batch([msg], engine)[0]
+
+
+def hash_g2_batch(msgs, engine=None):
+    e = engine or default_engine()
+    flat, off = pack_messages([bytes(m) for m in msgs])
+    return [bytes(x) for x in e.hash_g2(flat, off)]
+
+
+class SecretKey:
+    """struct SecretKey(Box<Fr>) (src/lib.rs:302)."""
+
+    def __init__(self, fr):
+        self.fr = int(fr) % _R
+
+    def _bytes(self):
+        return self.fr.to_bytes(32, "little")
+
+    def public_key(self):
+        """SecretKey::public_key (src/lib.rs:367-369)."""
+        out, st = default_engine().g1_mul(_u8(self._bytes())[None], _u8(_G1_GEN)[None])
+        _raise_status(st[0, 0])
+        return PublicKey(out[0, 0])
+
+    def sign_g2(self, hash_g2_point):
+        """SecretKey::sign_g2 (src/lib.rs:372-374)."""
+        out, st = default_engine().g2_mul(_u8(self._bytes())[None], _u8(hash_g2_point)[None])
+        _raise_status(st[0, 0])
+        return Signature(out[0, 0])
+
+    def sign(self, msg):
+        """SecretKey::sign (src/lib.rs:379-381)."""
+        return self.sign_batch([msg])[0]
+
+    def sign_batch(self, msgs, engine=None, cls=Signature):
+        e = engine or default_engine()
+        flat, off = pack_messages([bytes(m) for m in msgs])
+        out, st = e.sign(_u8(self._bytes())[None], flat, off)
+        return [cls(out[j, 0]) for j in range(len(msgs))]
+
+    def decrypt(self, ct):
+        """SecretKey::decrypt (src/lib.rs:384-391): None if the ciphertext is invalid."""
+        if not ct.verify():
+            return None
+        e = default_engine()
+        g, st = e.g1_mul(_u8(self._bytes())[None], _u8(ct.u)[None])
+        _raise_status(st[0, 0])
+        v, off = pack_messages([ct.v])
+        out, st = e.xor_with_hash(np.ascontiguousarray(g[:, 0]), v, off)
+        return bytes(out[: len(ct.v)])
+
+
+class SecretKeyShare(SecretKey):
+    """struct SecretKeyShare(SecretKey) (src/lib.rs:408)."""
+
+    def public_key_share(self):
+        """SecretKeyShare::public_key_share (src/lib.rs:437-439)."""
+        return PublicKeyShare(self.public_key().raw)
+
+    def sign_g2(self, hash_g2_point):
+        """SecretKeyShare::sign_g2 (src/lib.rs:442-444)."""
+        return SignatureShare(SecretKey.sign_g2(self, hash_g2_point).raw)
+
+    def sign(self, msg):
+        """SecretKeyShare::sign (src/lib.rs:447-449)."""
+        return self.sign_batch([msg], cls=SignatureShare)[0]
+
+    def decrypt_share(self, ct):
+        """SecretKeyShare::decrypt_share (src/lib.rs:452-457)."""
+        if not ct.verify():
+            return None
+        return self.decrypt_share_no_verify(ct)
+
+    def decrypt_share_no_verify(self, ct):
+        """SecretKeyShare::decrypt_share_no_verify (src/lib.rs:460-462)."""
+        out, st = default_engine().g1_mul(_u8(self._bytes())[None], _u8(ct.u)[None])
+        _raise_status(st[0, 0])
+        return DecryptionShare(out[0, 0])
+
+
+def sign_shares_batch(secret_key_shares, msgs, engine=None):
+    """S signers x B messages in one launch: result[j][s] = shares[s].sign(msgs[j])."""
+    e = engine or default_engine()
+    flat, off = pack_messages([bytes(m) for m in msgs])
+    fr = _stack([s._bytes() for s in secret_key_shares], 32)
+    out, st = e.sign(fr, flat, off)
+    return [[SignatureShare(out[j, s]) for s in range(len(secret_key_shares))] for j in range(len(msgs))]
+
+
+def _ordered(shares):
+    """The reference iterates a BTreeMap / any IntoIterator of (index, share): dicts are taken in
+    ascending index order (BTreeMap), sequences of pairs in the order given."""
+    if isinstance(shares, dict):
+        return sorted(shares.items())
+    return list(shares)
+
+
+class PublicKeySet:
+    """struct PublicKeySet { commit: Commitment } (src/lib.rs:539-543); commit = list of G1 (96 B)."""
+
+    def __init__(self, commit):
+        self.commit = [bytes(c) for c in commit]
+
+    def threshold(self):
+        """PublicKeySet::threshold (src/lib.rs:560-562) = commit.degree()."""
+        return len(self.commit) - 1
+
+    def public_key(self):
+        """PublicKeySet::public_key (src/lib.rs:565-567)."""
+        return PublicKey(self.commit[0])
+
+    def public_key_share(self, i):
+        """PublicKeySet::public_key_share (src/lib.rs:570-573) = Commitment::evaluate(i + 1)
+        (src/poly.rs:497-508): sum_k (i+1)^k * commit[k], evaluated as one G1 linear combination."""
+        return self.public_key_shares([i])[0]
+
+    def public_key_shares(self, indices, engine=None):
+        e = engine or default_engine()
+        n = len(self.commit)
+        B = len(indices)
+        scal = np.zeros((B, n, 32), dtype=np.uint8)
+        for j, i in enumerate(indices):
+            x = into_fr_plus_1(i)
+            p = 1
+            for k in range(n):
+                scal[j, k] = np.frombuffer(p.to_bytes(32, "little"), dtype=np.uint8)
+                p = p * x % _R
+        pts = np.broadcast_to(_stack(self.commit, 96)[None], (B, n, 96)).copy()
+        out, st = e.lincomb_g1(scal, pts)
+        for s in st:
+            _raise_status(s)
+        return [PublicKeyShare(out[j]) for j in range(B)]
+
+    def combine_signatures(self, shares):
+        """PublicKeySet::combine_signatures (src/lib.rs:608-615)."""
+        sig, st = self.combine_signatures_batch([shares])
+        _raise_status(st[0])
+        return sig[0]
+
+    def combine_signatures_batch(self, jobs, engine=None):
+        """jobs: list of share sets (dict idx->SignatureShare or sequence of pairs), all with the
+        same number of samples.  Returns ([Signature], status[])."""
+        e = engine or default_engine()
+        t = self.threshold()
+        ordered = [_ordered(j) for j in jobs]
+        n = len(ordered[0])
+        if any(len(o) != n for o in ordered):
+            raise ValueError("all jobs of one batch must supply the same number of shares")
+        idx = np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(jobs), n)
+        sh = np.empty((len(jobs), max(n, 1), 192), dtype=np.uint8)
+        for j, o in enumerate(ordered):
+            for k, (_, s) in enumerate(o):
+                sh[j, k] = np.frombuffer(s.raw, dtype=np.uint8)
+        out, st = e.combine_g2(t, idx, sh[:, :n].copy() if n else sh[:, :0].copy())
+        return [Signature(out[j]) for j in range(len(jobs))], st
+
+    def decrypt(self, shares, ct):
+        """PublicKeySet::decrypt (src/lib.rs:618-626)."""
+        out, st = self.decrypt_batch([shares], [ct])
+        _raise_status(st[0])
+        return out[0]
+
+    def decrypt_batch(self, jobs, cts, engine=None):
+        e = engine or default_engine()
+        t = self.threshold()
+        ordered = [_ordered(j) for j in jobs]
+        n = len(ordered[0])
+        idx = np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(jobs), n)
+        sh = np.empty((len(jobs), n, 96), dtype=np.uint8)
+        for j, o in enumerate(ordered):
+            for k, (_, s) in enumerate(o):
+                sh[j, k] = np.frombuffer(s.raw, dtype=np.uint8)
+        v, off = pack_messages([c.v for c in cts])
+        out, st = e.decrypt(t, idx, sh, v, off)
+        res = [bytes(out[int(off[j]): int(off[j + 1])]) for j in range(len(jobs))]
+        return res, st
+
+
+class SecretKeySet:
+    """struct SecretKeySet { poly: Poly } (src/lib.rs:631-635); poly = Fr coefficients."""
+
+    def __init__(self, poly):
+        self.poly = [int(c) % _R for c in poly]
+
+    def threshold(self):
+        """SecretKeySet::threshold (src/lib.rs:664-666)."""
+        return len(self.poly) - 1
+
+    def secret_key_share(self, i):
+        """SecretKeySet::secret_key_share (src/lib.rs:670-673): Poly::evaluate(i + 1), Horner in Fr
+        (src/poly.rs:358-369) -- key generation, host side as in the reference."""
+        x = into_fr_plus_1(i)
+        res = 0
+        for c in reversed(self.poly):
+            res = (res * x + c) % _R
+        return SecretKeyShare(res)
+
+    def public_keys(self, engine=None):
+        """SecretKeySet::public_keys (src/lib.rs:676-680) = Poly::commitment (src/poly.rs:372-377)."""
+        e = engine or default_engine()
+        fr = _stack([c.to_bytes(32, "little") for c in self.poly], 32)
+        out, st = e.g1_mul(fr, _u8(_G1_GEN)[None])
+        return PublicKeySet([bytes(out[0, k]) for k in range(len(self.poly))])

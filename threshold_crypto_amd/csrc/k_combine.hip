@@ -32,6 +32,28 @@ __global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, 
   if (status) status[j] = st;
 }
 
+// one lane per job: sum_i scalar_i * point_i with caller-supplied scalars (32 B LE each)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
+                                                    const uint8_t* __restrict__ points, size_t B,
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  constexpr int PB = PointIO<F>::BYTES;
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  uint8_t st = job_lincomb<F>((int)n, points + j * n * PB, reinterpret_cast<const uint32_t*>(scalars + j * n * 32),
+                              out + j * PB);
+  if (status) status[j] = st;
+}
+
+void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                       uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_lincomb<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, B, out, status);
+}
+void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                       uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, B, out, status);
+}
+
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
                      uint8_t* status) {
   const size_t n = B * (t + 1);

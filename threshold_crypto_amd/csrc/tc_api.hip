@@ -383,6 +383,35 @@ int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* id
   return combine(ctx, false, t, n_per_job, idx, shares_g1, B, out /*non-null marker*/, status, v, off, out);
 }
 
+static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                   uint8_t* status) {
+  TC_REQUIRE(ctx && out && (n == 0 || (scalars && points)));
+  if (B == 0) return TC_OK;
+  const size_t PB = g2 ? 192 : 96;
+  Call k(ctx);
+  const uint8_t* d_sc = k.in(scalars, B * n * 32, /*secret=*/true);
+  const uint8_t* d_pt = k.in(points, B * n * PB);
+  uint8_t* d_out = k.out(out, B * PB);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) {
+    if (g2) tc::launch_lincomb_g2(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
+    else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_g1_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                        uint8_t* status) {
+  return lincomb(ctx, false, n, scalars, points, B, out, status);
+}
+
+int tc_g2_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                        uint8_t* status) {
+  return lincomb(ctx, true, n, scalars, points, B, out, status);
+}
+
 int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                            uint8_t* out, uint8_t* status) {
   TC_REQUIRE(ctx && g1 && off && out);

@@ -56,31 +56,23 @@ TC_HD uint8_t job_lagrange(const uint64_t* idx, int t, int i, uint32_t* out_word
   return TC_JOB_OK;
 }
 
-// out = sum_{i <= t} lambda_i * share_i over the FIRST t+1 samples of the job
-// (interpolate, src/lib.rs:719-767).  lam: (t+1) x 8 canonical words from job_lagrange.
+// out = sum_{i < n} scalar_i * point_i   (scalars: n x 8 canonical LE words, < r)
+// Used by interpolate (below) and by Commitment::evaluate (src/poly.rs:497-508), which is the
+// linear combination sum_k x^k * commit[k].
 template <class F>
-TC_HD uint8_t job_combine(int t, const uint8_t* shares, const uint32_t* lam, uint8_t* out) {
+TC_HD uint8_t job_lincomb(int n, const uint8_t* points, const uint32_t* scalars, uint8_t* out) {
   constexpr int PB = PointIO<F>::BYTES;
-  if (t == 0) {
-    // t == 0: the first sample is returned unchanged (src/lib.rs:735-737)
-    Affine<F> p;
-    if (!PointIO<F>::decode(shares, p)) {
-      PointIO<F>::encode(Affine<F>::infinity(), out);
-      return TC_JOB_INVALID_ENCODING;
-    }
-    PointIO<F>::encode(p, out);
-    return TC_JOB_OK;
-  }
   Jac<F> total = Jac<F>::infinity();
   bool ok = true;
-  TC_NOUNROLL for (int base = 0; base <= t; base += 4) {
-    const int k = (t + 1 - base) < 4 ? (t + 1 - base) : 4;
+  TC_NOUNROLL for (int base = 0; base < n; base += 4) {
+    const int k = (n - base) < 4 ? (n - base) : 4;
     Affine<F> pts[4];
     uint32_t sc[4][8];
     TC_NOUNROLL for (int j = 0; j < 4; j++) {
       if (j < k) {
-        ok &= PointIO<F>::decode(shares + (size_t)(base + j) * PB, pts[j]);
-        for (int w = 0; w < 8; w++) sc[j][w] = lam[(size_t)(base + j) * 8 + w];
+        ok &= PointIO<F>::decode(points + (size_t)(base + j) * PB, pts[j]);
+        for (int w = 0; w < 8; w++) sc[j][w] = scalars[(size_t)(base + j) * 8 + w];
+        ok &= limbs_lt_p<FrParams>(sc[j]);
       } else {
         pts[j] = Affine<F>::infinity();
         for (int w = 0; w < 8; w++) sc[j][w] = 0;
@@ -95,6 +87,23 @@ TC_HD uint8_t job_combine(int t, const uint8_t* shares, const uint32_t* lam, uin
   }
   PointIO<F>::encode(jac_to_affine(total), out);
   return TC_JOB_OK;
+}
+
+// out = sum_{i <= t} lambda_i * share_i over the FIRST t+1 samples of the job
+// (interpolate, src/lib.rs:719-767).  lam: (t+1) x 8 canonical words from job_lagrange.
+template <class F>
+TC_HD uint8_t job_combine(int t, const uint8_t* shares, const uint32_t* lam, uint8_t* out) {
+  if (t == 0) {
+    // t == 0: the first sample is returned unchanged (src/lib.rs:735-737)
+    Affine<F> p;
+    if (!PointIO<F>::decode(shares, p)) {
+      PointIO<F>::encode(Affine<F>::infinity(), out);
+      return TC_JOB_INVALID_ENCODING;
+    }
+    PointIO<F>::encode(p, out);
+    return TC_JOB_OK;
+  }
+  return job_lincomb<F>(t + 1, shares, lam, out);
 }
 
 // ok = e(a, b) == e(c, d)     (src/lib.rs:109, :185, :511)

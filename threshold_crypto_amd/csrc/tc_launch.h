@@ -25,6 +25,11 @@ void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint8_t
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
                        size_t B, uint8_t* out, uint8_t* status);
 
+void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                       uint8_t* status);
+void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+                       uint8_t* status);
+
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok);
 

@@ -173,6 +173,23 @@ class Engine:
     def combine_g1(self, t, idx, shares):
         return self._combine("tc_combine_g1_batch", G1_BYTES, t, idx, shares)
 
+    def _lincomb(self, name, pb, scalars, points):
+        dev = self._mode(scalars, points)
+        B, n = scalars.shape[0], scalars.shape[1]
+        self._check(scalars, (n, FR_BYTES), "scalars")
+        self._check(points, (n, pb), "points")
+        out = self._empty(dev, (B, pb), ref=points)
+        st = self._empty(dev, (B,), ref=points)
+        self._call(name, int(n), _ptr(scalars), _ptr(points), B, _ptr(out), _ptr(st))
+        return out, st
+
+    def lincomb_g1(self, scalars, points):
+        """out[j] = sum_k scalars[j, k] * points[j, k]"""
+        return self._lincomb("tc_g1_lincomb_batch", G1_BYTES, scalars, points)
+
+    def lincomb_g2(self, scalars, points):
+        return self._lincomb("tc_g2_lincomb_batch", G2_BYTES, scalars, points)
+
     def decrypt(self, t, idx, shares_g1, v, off):
         dev = self._mode(idx, shares_g1, v, off)
         B, n = idx.shape
