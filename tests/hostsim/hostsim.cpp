@@ -81,6 +81,61 @@ int hs_cyclo_check(const uint8_t* a, const uint8_t* b) {
   r = r.frobenius(2) * r;
   return (r.cyclotomic_sqr() == r.sqr()) && (r.sqr() == r * r) ? 1 : 0;
 }
+// ---- Fq12-level probes (12 x 48 B big-endian, tower order c0.c0.c0, c0.c0.c1, c0.c1.c0, ...) ----
+static void fq12_read(const uint8_t* in, Fq12& f) {
+  Fq* e = reinterpret_cast<Fq*>(&f);
+  for (int i = 0; i < 12; i++) fq_from_be48(in + 48 * i, false, e[i]);
+}
+static void fq12_write(const Fq12& f, uint8_t* out) {
+  const Fq* e = reinterpret_cast<const Fq*>(&f);
+  for (int i = 0; i < 12; i++) fq_to_be48(e[i], out + 48 * i);
+}
+void hs_fq12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fq12 x, y;
+  fq12_read(a, x);
+  fq12_read(b, y);
+  fq12_write(x * y, out);
+}
+void hs_fq12_sqr(const uint8_t* a, uint8_t* out) {
+  Fq12 x;
+  fq12_read(a, x);
+  fq12_write(x.sqr(), out);
+}
+void hs_fq12_inv(const uint8_t* a, uint8_t* out) {
+  Fq12 x;
+  fq12_read(a, x);
+  fq12_write(x.inv(), out);
+}
+void hs_fq12_frobenius(const uint8_t* a, int k, uint8_t* out) {
+  Fq12 x;
+  fq12_read(a, x);
+  fq12_write(x.frobenius(k), out);
+}
+void hs_fq12_cyclotomic_sqr(const uint8_t* a, uint8_t* out) {
+  Fq12 x;
+  fq12_read(a, x);
+  fq12_write(x.cyclotomic_sqr(), out);
+}
+void hs_fq12_exp_by_x(const uint8_t* a, uint64_t x, uint8_t* out) {
+  Fq12 f;
+  fq12_read(a, f);
+  fq12_write(cyclotomic_exp_by_x(f, x), out);
+}
+void hs_fq12_final_exp(const uint8_t* a, uint8_t* out) {
+  Fq12 x;
+  fq12_read(a, x);
+  fq12_write(final_exponentiation(x), out);
+}
+int hs_miller_loop(const uint8_t* a, const uint8_t* b, uint8_t* out576) {
+  G1Affine p;
+  G2Affine q;
+  if (!g1_decode_uncompressed(a, p) || !g2_decode_uncompressed(b, q)) return -1;
+  G1Affine ps[1] = {p};
+  G2Affine qs[1] = {q};
+  fq12_write(miller_loop<1>(ps, qs), out576);
+  return 0;
+}
+
 void hs_sha3(const uint8_t* msg, size_t len, uint8_t* out32) {
   uint32_t w[8];
   sha3_256_words(msg, len, w);

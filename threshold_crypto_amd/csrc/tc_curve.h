@@ -6,6 +6,11 @@
 
 namespace tc {
 
+// Output conditioning of point coordinates (tc_field.h): one carry pass is enough over Fq;
+// over Fq2 the Karatsuba sums also need the value pulled back towards p.
+TC_HD Fq coord_out(const Fq& a) { return a.norm(); }
+TC_HD Fq2 coord_out(const Fq2& a) { return a.reduce_value(); }
+
 template <class F>
 struct Affine {
   F x, y;
@@ -38,9 +43,10 @@ TC_HD_NOINLINE Jac<F> jac_dbl(const Jac<F>& p) {
   F e = a.dbl() + a;
   F f = e.sqr();
   Jac<F> r;
-  r.z = (p.y * p.z).dbl();
-  r.x = f - d.dbl();
-  r.y = e * (d - r.x) - c.dbl().dbl().dbl();
+  // coordinates are kept carry-normalised between point operations (lazy limbs, tc_field.h)
+  r.z = coord_out((p.y * p.z).dbl());
+  r.x = coord_out(f - d.dbl());
+  r.y = coord_out(e * (d - r.x) - c.dbl().dbl().dbl());
   return r;
 }
 
@@ -65,9 +71,9 @@ TC_HD_NOINLINE Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
   F j = h * i;
   F v = p.x * i;
   Jac<F> r;
-  r.x = rr.sqr() - j - v.dbl();
-  r.y = rr * (v - r.x) - (p.y * j).dbl();
-  r.z = (p.z + h).sqr() - z1z1 - hh;
+  r.x = coord_out(rr.sqr() - j - v.dbl());
+  r.y = coord_out(rr * (v - r.x) - (p.y * j).dbl());
+  r.z = coord_out((p.z + h).sqr() - z1z1 - hh);
   if (p_inf) r = Jac<F>{q.x, q.y, F::one()};
   return r;
 }
@@ -93,9 +99,9 @@ TC_HD_NOINLINE Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   F j = h * i;
   F v = u1 * i;
   Jac<F> r;
-  r.x = rr.sqr() - j - v.dbl();
-  r.y = rr * (v - r.x) - (s1 * j).dbl();
-  r.z = ((p.z + q.z).sqr() - z1z1 - z2z2) * h;
+  r.x = coord_out(rr.sqr() - j - v.dbl());
+  r.y = coord_out(rr * (v - r.x) - (s1 * j).dbl());
+  r.z = coord_out(((p.z + q.z).sqr() - z1z1 - z2z2) * h);
   if (q_inf) r = p;
   if (p_inf) r = q;
   return r;
@@ -135,21 +141,11 @@ TC_HD bool affine_on_curve(const Affine<F>& p, const F& b) {
   return p.y.sqr() == p.x.sqr() * p.x + b;
 }
 
-TC_HD Fq g1_b() {
-  Fq b;
-  TC_UNROLL for (int i = 0; i < 12; i++) b.v.l[i] = FQ_B1[i];
-  return b;
-}
+TC_HD Fq g1_b() { return Fq::from_limbs(FQ26_B1); }
 TC_HD Fq2 g2_b() { return Fq2{g1_b(), g1_b()}; }
 
 TC_HD Affine<Fq> g1_generator() {
-  Affine<Fq> g;
-  TC_UNROLL for (int i = 0; i < 12; i++) {
-    g.x.v.l[i] = G1_GEN_X[i];
-    g.y.v.l[i] = G1_GEN_Y[i];
-  }
-  g.inf = false;
-  return g;
+  return Affine<Fq>{Fq::from_limbs(G1_GEN26_X), Fq::from_limbs(G1_GEN26_Y), false};
 }
 
 using G1Affine = Affine<Fq>;

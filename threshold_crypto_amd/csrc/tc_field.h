@@ -1,25 +1,52 @@
-// Prime-field arithmetic for gfx950: Montgomery form over 32-bit limbs.
-//   Fq  (BLS12-381 base field, 381 bit): 12 x u32, R = 2^384
-//   Fr  (scalar field, 255 bit):          8 x u32, R = 2^256
-// Replaces (on device) pairing::bls12_381::Fq and ff's derived Fr, which the reference
-// reaches through the engine seam at /root/reference/src/lib.rs:60-67.
+// Prime-field arithmetic for gfx950.
 //
-// One field element lives in one lane's VGPRs; the inner product step is the gfx950
-// 32x32+64 -> 64 multiply-add (v_mad_u64_u32).  No MFMA: this is wide-integer modular
-// arithmetic, not a dense contraction.
+//   Fq (BLS12-381 base field, 381 bit) -- the hot field: REDUCED RADIX, 15 signed limbs of
+//      26 bits in 32-bit VGPRs, Montgomery form with R = 2^390.  On gfx950 a VALU carry-out
+//      feeding a VALU carry-in costs two wait states (the compiler pads every v_add_co ->
+//      v_addc pair), so saturated 32-bit limbs make every add/sub/multiply-accumulate a serial,
+//      padded carry chain.  With 26-bit limbs nothing carries:
+//        * a + b, a - b, -a, 2a are 15 independent v_add/v_sub (lazy, no reduction);
+//        * a product column is a chain of v_mad_i64_i32 into one 64-bit accumulator
+//          (15 * 2^52 * 129 < 2^63), the carry into the next column is one 64-bit shift;
+//        * reduction is interleaved per column (product scanning), quotient digit
+//          m_k = column * (-p^-1) mod 2^26.
+//      Limbs may grow to |l_i| < 2^26 * B through lazy additions; a multiplication needs
+//      B_a * B_b <= 128.  `norm()` (one parallel carry pass) brings B back to ~1.
+//   Fr (scalar field, 255 bit) -- off the hot path (Lagrange coefficients only): plain
+//      saturated 8 x u32 Montgomery (R = 2^256), compiler-scheduled.
+//
+// Device replacement for pairing::bls12_381::Fq and ff's derived Fr, which the reference
+// reaches through the engine seam at /root/reference/src/lib.rs:60-67.  No MFMA: this is
+// wide-integer modular arithmetic, not a dense contraction.
 #pragma once
 #include "tc_common.h"
 
+#if defined(TC_BOUND_CHECK)
+#include <execinfo.h>
+#include <stdio.h>
+#include <stdlib.h>
+#endif
+
 namespace tc {
 
+#if defined(TC_BOUND_CHECK)
+// host-only (tests/hostsim built with -DTC_BOUND_CHECK -O0): report the call chain of a
+// multiplication whose operand bounds could overflow a column accumulator
+inline void tc_bound_fail(float a, float b) {
+  void* bt[24];
+  int n = backtrace(bt, 24);
+  fprintf(stderr, "TC_BOUND_CHECK: operand bounds %.2f x %.2f exceed the multiplier's limit\n", a, b);
+  backtrace_symbols_fd(bt, n, 2);
+  abort();
+}
+#endif
+
+// =======================================================================================
+// generic saturated Montgomery over N x u32 (used for Fr; FqParams kept for range checks)
+// =======================================================================================
 struct FqParams {
   static constexpr int N = 12;
   TC_HD static uint32_t p(int i) { return FQ_P[i]; }
-  TC_HD static uint32_t one(int i) { return FQ_ONE[i]; }
-  TC_HD static uint32_t r2(int i) { return FQ_R2[i]; }
-  TC_HD static uint32_t pm2(int i) { return FQ_P_MINUS_2[i]; }
-  static constexpr uint32_t inv = FQ_INV32;
-  static constexpr int bits = 381;
 };
 
 struct FrParams {
@@ -36,31 +63,19 @@ template <class PR>
 struct Mont {
   static constexpr int N = PR::N;
   uint32_t l[N];
-
-  TC_HD static Mont zero() {
-    Mont r;
-    TC_UNROLL for (int i = 0; i < N; i++) r.l[i] = 0;
-    return r;
-  }
-  TC_HD static Mont one() {
-    Mont r;
-    TC_UNROLL for (int i = 0; i < N; i++) r.l[i] = PR::one(i);
-    return r;
-  }
-  TC_HD bool is_zero() const {
-    uint32_t o = 0;
-    TC_UNROLL for (int i = 0; i < N; i++) o |= l[i];
-    return o == 0;
-  }
-  TC_HD bool operator==(const Mont& b) const {
-    uint32_t o = 0;
-    TC_UNROLL for (int i = 0; i < N; i++) o |= (l[i] ^ b.l[i]);
-    return o == 0;
-  }
-  TC_HD bool operator!=(const Mont& b) const { return !(*this == b); }
 };
 
-// r = a - p if a >= p else a     (a < 2p)
+// canonical limbs < p ?
+template <class PR>
+TC_HD bool limbs_lt_p(const uint32_t* limbs) {
+  uint32_t borrow = 0;
+  TC_UNROLL for (int i = 0; i < PR::N; i++) {
+    uint64_t d = (uint64_t)limbs[i] - PR::p(i) - borrow;
+    borrow = (uint32_t)(d >> 63);
+  }
+  return borrow != 0;
+}
+
 template <class PR>
 TC_HD void mont_cond_sub_p(Mont<PR>& a) {
   constexpr int N = PR::N;
@@ -84,8 +99,7 @@ TC_HD Mont<PR> mont_add(const Mont<PR>& a, const Mont<PR>& b) {
     r.l[i] = (uint32_t)s;
     c = (uint32_t)(s >> 32);
   }
-  // both moduli leave the top bit of the top limb clear, so no carry out of limb N-1
-  mont_cond_sub_p(r);
+  mont_cond_sub_p(r);  // the modulus leaves the top bit clear: no carry out of limb N-1
   return r;
 }
 
@@ -109,38 +123,17 @@ TC_HD Mont<PR> mont_sub(const Mont<PR>& a, const Mont<PR>& b) {
   return r;
 }
 
+// CIOS Montgomery product (top limb of the modulus < 2^31: no (N+2)-th limb needed)
 template <class PR>
-TC_HD Mont<PR> mont_neg(const Mont<PR>& a) {
-  constexpr int N = PR::N;
-  Mont<PR> r;
-  uint32_t borrow = 0;
-  uint32_t nz = 0;
-  TC_UNROLL for (int i = 0; i < N; i++) nz |= a.l[i];
-  TC_UNROLL for (int i = 0; i < N; i++) {
-    uint64_t d = (uint64_t)PR::p(i) - a.l[i] - borrow;
-    r.l[i] = nz ? (uint32_t)d : 0u;
-    borrow = (uint32_t)(d >> 63);
-  }
-  return r;
-}
-
-template <class PR>
-TC_HD Mont<PR> mont_dbl(const Mont<PR>& a) {
-  return mont_add(a, a);
-}
-
-// Montgomery product a*b*R^-1 mod p, coarsely-integrated operand scanning (CIOS).  The top
-// limb of both moduli is < 2^31, so the running value never needs an (N+2)-th limb.
-template <class PR>
-TC_HD void mont_mul_body(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+TC_HD_NOINLINE Mont<PR> mont_mul(const Mont<PR>& a, const Mont<PR>& b) {
   constexpr int N = PR::N;
   uint32_t t[N + 1];
   TC_UNROLL for (int i = 0; i <= N; i++) t[i] = 0;
   TC_UNROLL for (int i = 0; i < N; i++) {
     uint64_t c = 0;
-    const uint32_t bi = b[i];
+    const uint32_t bi = b.l[i];
     TC_UNROLL for (int j = 0; j < N; j++) {
-      uint64_t s = (uint64_t)a[j] * bi + t[j] + c;
+      uint64_t s = (uint64_t)a.l[j] * bi + t[j] + c;
       t[j] = (uint32_t)s;
       c = s >> 32;
     }
@@ -160,89 +153,10 @@ TC_HD void mont_mul_body(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   Mont<PR> r;
   TC_UNROLL for (int i = 0; i < N; i++) r.l[i] = t[i];
   mont_cond_sub_p(r);
-  TC_UNROLL for (int i = 0; i < N; i++) out[i] = r.l[i];
-}
-
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TC_INLINE_MUL)
-// On the device the product is a REAL function (not inlined into every tower/curve routine:
-// that makes the pairing kernel's code object several MB and hipcc compile times unbounded).
-// Operands travel as 2N scalar u32 arguments so the AMDGPU calling convention keeps them in
-// VGPRs (aggregates beyond 16 registers would be passed through scratch memory).
-__device__ __attribute__((noinline)) inline Mont<FqParams> fq_mul_call(
-    uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
-    uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
-    uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
-  const uint32_t a[12] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11};
-  const uint32_t b[12] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11};
-  Mont<FqParams> r;
-  mont_mul_body<FqParams>(a, b, r.l);
   return r;
 }
-__device__ __attribute__((noinline)) inline Mont<FrParams> fr_mul_call(
-    uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
-    uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7) {
-  const uint32_t a[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
-  const uint32_t b[8] = {b0, b1, b2, b3, b4, b5, b6, b7};
-  Mont<FrParams> r;
-  mont_mul_body<FrParams>(a, b, r.l);
-  return r;
-}
-TC_HD Mont<FqParams> mont_mul(const Mont<FqParams>& a, const Mont<FqParams>& b) {
-  return fq_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
-                     a.l[11], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9],
-                     b.l[10], b.l[11]);
-}
-TC_HD Mont<FrParams> mont_mul(const Mont<FrParams>& a, const Mont<FrParams>& b) {
-  return fr_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], b.l[0], b.l[1], b.l[2],
-                     b.l[3], b.l[4], b.l[5], b.l[6], b.l[7]);
-}
-#else
-template <class PR>
-TC_HD Mont<PR> mont_mul(const Mont<PR>& a, const Mont<PR>& b) {
-  Mont<PR> r;
-  mont_mul_body<PR>(a.l, b.l, r.l);
-  return r;
-}
-#endif
 
-template <class PR>
-TC_HD Mont<PR> mont_sqr(const Mont<PR>& a) {
-  return mont_mul(a, a);
-}
-
-// canonical integer (little-endian limbs) -> Montgomery form
-template <class PR>
-TC_HD Mont<PR> mont_from_canonical(const uint32_t* limbs) {
-  Mont<PR> a, r2;
-  TC_UNROLL for (int i = 0; i < PR::N; i++) {
-    a.l[i] = limbs[i];
-    r2.l[i] = PR::r2(i);
-  }
-  return mont_mul(a, r2);
-}
-
-// Montgomery form -> canonical integer
-template <class PR>
-TC_HD void mont_to_canonical(const Mont<PR>& a, uint32_t* limbs) {
-  Mont<PR> o;
-  TC_UNROLL for (int i = 0; i < PR::N; i++) o.l[i] = (i == 0) ? 1u : 0u;
-  Mont<PR> r = mont_mul(a, o);
-  TC_UNROLL for (int i = 0; i < PR::N; i++) limbs[i] = r.l[i];
-}
-
-// canonical limbs < p ?
-template <class PR>
-TC_HD bool limbs_lt_p(const uint32_t* limbs) {
-  uint32_t borrow = 0;
-  TC_UNROLL for (int i = 0; i < PR::N; i++) {
-    uint64_t d = (uint64_t)limbs[i] - PR::p(i) - borrow;
-    borrow = (uint32_t)(d >> 63);
-  }
-  return borrow != 0;
-}
-
-// a^e, e given as nlimbs little-endian u32 words via accessor E(i); fixed 4-bit windows,
-// uniform control flow (all lanes run the same exponent).
+// a^e with e given by a word accessor; fixed 4-bit windows, uniform control flow
 template <class F, class EXP>
 TC_HD F field_pow_fixed(const F& a, EXP e, int nbits) {
   F tbl[16];
@@ -262,47 +176,389 @@ TC_HD F field_pow_fixed(const F& a, EXP e, int nbits) {
   return r;
 }
 
-// ---- Fq / Fr value types with operators ---------------------------------------------
-template <class PR>
-struct Fe {
-  Mont<PR> v;
-  static constexpr int N = PR::N;
-  TC_HD static Fe zero() { return Fe{Mont<PR>::zero()}; }
-  TC_HD static Fe one() { return Fe{Mont<PR>::one()}; }
-  TC_HD bool is_zero() const { return v.is_zero(); }
-  TC_HD bool operator==(const Fe& b) const { return v == b.v; }
-  TC_HD bool operator!=(const Fe& b) const { return v != b.v; }
-  TC_HD Fe operator+(const Fe& b) const { return Fe{mont_add(v, b.v)}; }
-  TC_HD Fe operator-(const Fe& b) const { return Fe{mont_sub(v, b.v)}; }
-  TC_HD Fe operator-() const { return Fe{mont_neg(v)}; }
-  TC_HD Fe operator*(const Fe& b) const { return Fe{mont_mul(v, b.v)}; }
-  TC_HD Fe sqr() const { return Fe{mont_sqr(v)}; }
-  TC_HD Fe dbl() const { return Fe{mont_dbl(v)}; }
-  TC_HD static Fe from_canonical(const uint32_t* limbs) { return Fe{mont_from_canonical<PR>(limbs)}; }
-  TC_HD void to_canonical(uint32_t* limbs) const { mont_to_canonical(v, limbs); }
-  // Fermat inverse a^(p-2); 0 -> 0
-  TC_HD_NOINLINE Fe inv() const {
-    return field_pow_fixed(*this, [](int i) { return PR::pm2(i); }, PR::bits);
-  }
-  TC_HD static Fe select(bool c, const Fe& a, const Fe& b) {
-    Fe r;
-    TC_UNROLL for (int i = 0; i < N; i++) r.v.l[i] = c ? a.v.l[i] : b.v.l[i];
+struct Fr {
+  Mont<FrParams> v;
+  static constexpr int N = 8;
+  TC_HD static Fr zero() {
+    Fr r;
+    TC_UNROLL for (int i = 0; i < N; i++) r.v.l[i] = 0;
     return r;
+  }
+  TC_HD static Fr one() {
+    Fr r;
+    TC_UNROLL for (int i = 0; i < N; i++) r.v.l[i] = FR_ONE[i];
+    return r;
+  }
+  TC_HD bool is_zero() const {
+    uint32_t o = 0;
+    TC_UNROLL for (int i = 0; i < N; i++) o |= v.l[i];
+    return o == 0;
+  }
+  TC_HD bool operator==(const Fr& b) const {
+    uint32_t o = 0;
+    TC_UNROLL for (int i = 0; i < N; i++) o |= (v.l[i] ^ b.v.l[i]);
+    return o == 0;
+  }
+  TC_HD bool operator!=(const Fr& b) const { return !(*this == b); }
+  TC_HD Fr operator+(const Fr& b) const { return Fr{mont_add(v, b.v)}; }
+  TC_HD Fr operator-(const Fr& b) const { return Fr{mont_sub(v, b.v)}; }
+  TC_HD Fr operator*(const Fr& b) const { return Fr{mont_mul(v, b.v)}; }
+  TC_HD Fr sqr() const { return Fr{mont_mul(v, v)}; }
+  TC_HD static Fr from_canonical(const uint32_t* limbs) {
+    Mont<FrParams> a, r2;
+    TC_UNROLL for (int i = 0; i < N; i++) {
+      a.l[i] = limbs[i];
+      r2.l[i] = FR_R2[i];
+    }
+    return Fr{mont_mul(a, r2)};
+  }
+  TC_HD void to_canonical(uint32_t* limbs) const {
+    Mont<FrParams> o;
+    TC_UNROLL for (int i = 0; i < N; i++) o.l[i] = (i == 0) ? 1u : 0u;
+    Mont<FrParams> r = mont_mul(v, o);
+    TC_UNROLL for (int i = 0; i < N; i++) limbs[i] = r.l[i];
+  }
+  // Fermat inverse a^(r-2); 0 -> 0
+  TC_HD_NOINLINE Fr inv() const {
+    return field_pow_fixed(*this, [](int i) { return FR_P_MINUS_2[i]; }, 255);
   }
 };
 
-using Fq = Fe<FqParams>;
-using Fr = Fe<FrParams>;
-
-// Fq from u64 (IntoFr for u64, /root/reference/src/into_fr.rs:16-20)
+// Fr from u64 (IntoFr for u64, /root/reference/src/into_fr.rs:16-20)
 TC_HD Fr fr_from_u64(uint64_t x) {
   uint32_t l[8] = {(uint32_t)x, (uint32_t)(x >> 32), 0, 0, 0, 0, 0, 0};
   return Fr::from_canonical(l);
 }
 
+// =======================================================================================
+// Fq: 15 x 26-bit signed limbs, R = 2^390
+// =======================================================================================
+constexpr int FQ_LIMBS = 15;
+constexpr int FQ_RADIX = 26;
+constexpr int32_t FQ_MASK = (1 << FQ_RADIX) - 1;
+constexpr int FQ_MAX_BOUND_PRODUCT = 128;  // B_a * B_b allowed at a multiplication
+
+struct Fq;
+TC_HD Fq fq_mul(const Fq& a, const Fq& b);
+TC_HD Fq fq_sqr(const Fq& a);
+
+struct Fq {
+  int32_t l[FQ_LIMBS];
+#if defined(TC_BOUND_CHECK)
+  // host-only static-analysis aid: every limb lies in [blo, bhi] * 2^26.  The interval is data
+  // independent (it follows the operation sequence), so any test that walks a code path
+  // proves that path never overflows a column accumulator.
+  // bval: |value| <= bval * p.  Lazy sums also grow the VALUE; only a multiplication (or
+  // reduce_value()) brings it back to ~p: a product lands in (-V_a V_b p / 512, p + V_a V_b p / 512).
+  float blo, bhi, bval;
+  TC_HD void set_range(float lo, float hi) { blo = lo; bhi = hi; }
+  TC_HD void set_val(float v) { bval = v; }
+  TC_HD float lo() const { return blo; }
+  TC_HD float hi() const { return bhi; }
+  TC_HD float val() const { return bval; }
+  TC_HD float bound() const { return (-blo > bhi) ? -blo : bhi; }
+#else
+  TC_HD void set_range(float, float) {}
+  TC_HD void set_val(float) {}
+  TC_HD float lo() const { return 0.f; }
+  TC_HD float hi() const { return 0.f; }
+  TC_HD float val() const { return 0.f; }
+  TC_HD float bound() const { return 0.f; }
+#endif
+
+  TC_HD static Fq from_limbs(const int32_t* c) {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = c[i];
+    r.set_range(0.f, 1.f);
+    r.set_val(1.f);
+    return r;
+  }
+  TC_HD static Fq zero() {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = 0;
+    r.set_range(0.f, 0.f);
+    r.set_val(0.f);
+    return r;
+  }
+  TC_HD static Fq one() { return from_limbs(FQ26_ONE); }
+
+  // ---- lazy linear operations: no carries, no reduction --------------------------------
+  TC_HD Fq operator+(const Fq& b) const {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = l[i] + b.l[i];
+    r.set_range(lo() + b.lo(), hi() + b.hi());
+    r.set_val(val() + b.val());
+    return r;
+  }
+  TC_HD Fq operator-(const Fq& b) const {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = l[i] - b.l[i];
+    r.set_range(lo() - b.hi(), hi() - b.lo());
+    r.set_val(val() + b.val());
+    return r;
+  }
+  TC_HD Fq operator-() const {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = -l[i];
+    r.set_range(-hi(), -lo());
+    r.set_val(val());
+    return r;
+  }
+  TC_HD Fq dbl() const {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = l[i] * 2;
+    r.set_range(2.f * lo(), 2.f * hi());
+    r.set_val(2.f * val());
+    return r;
+  }
+  // one parallel carry pass: limbs back to [0, 2^26) + a carry of a few units; the top limb
+  // keeps the sign.  The value is unchanged.
+  TC_HD Fq norm() const {
+    Fq r;
+    r.l[0] = l[0] & FQ_MASK;
+    TC_UNROLL for (int i = 1; i < FQ_LIMBS - 1; i++) r.l[i] = (l[i] & FQ_MASK) + (l[i - 1] >> FQ_RADIX);
+    r.l[FQ_LIMBS - 1] = l[FQ_LIMBS - 1] + (l[FQ_LIMBS - 2] >> FQ_RADIX);
+    r.set_range(-0.01f, 1.01f);
+    r.set_val(val());
+#if defined(TC_BOUND_CHECK)
+    if (val() > 300.f) tc_bound_fail(val(), -1.f);  // the top limb (~ V * 2^17.7) must stay below 2^26 too
+#endif
+    return r;
+  }
+  // Brings the VALUE back to about [0, 2p] by subtracting k*p, k estimated from the top limb
+  // (any integer k keeps the residue), and carries the limbs.  Lazy sums grow the value as
+  // well as the limbs; products shrink it again (|a b| / R), but towers of Karatsuba sums
+  // (Fq2 -> Fq6 -> Fq12) and linear feedback (cyclotomic squaring) can outrun that, so the
+  // big tower/point routines reduce their outputs with this instead of norm().
+  // Requires |value| <= 300 p.  ~105 VALU instructions, no multiplier-sized work.
+  TC_HD Fq reduce_value() const {
+    Fq n = norm();
+    const int32_t k = (int32_t)__builtin_floorf((float)n.l[FQ_LIMBS - 1] * (1.0f / (float)FQ26_P[FQ_LIMBS - 1]));
+    int64_t t[FQ_LIMBS];
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) t[i] = (int64_t)n.l[i] - (int64_t)k * FQ26_P[i];
+    Fq r;
+    r.l[0] = (int32_t)((uint32_t)t[0] & (uint32_t)FQ_MASK);
+    TC_UNROLL for (int i = 1; i < FQ_LIMBS - 1; i++)
+      r.l[i] = (int32_t)((uint32_t)t[i] & (uint32_t)FQ_MASK) + (int32_t)(t[i - 1] >> FQ_RADIX);
+    r.l[FQ_LIMBS - 1] = (int32_t)(t[FQ_LIMBS - 1] + (t[FQ_LIMBS - 2] >> FQ_RADIX));
+    r.set_range(-0.01f, 1.01f);
+    r.set_val(2.1f);
+    return r;
+  }
+  TC_HD Fq operator*(const Fq& b) const { return fq_mul(*this, b); }
+  TC_HD Fq sqr() const { return fq_sqr(*this); }
+  TC_HD static Fq select(bool c, const Fq& a, const Fq& b) {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    r.set_range(a.lo() < b.lo() ? a.lo() : b.lo(), a.hi() > b.hi() ? a.hi() : b.hi());
+    r.set_val(a.val() > b.val() ? a.val() : b.val());
+    return r;
+  }
+
+  TC_HD_NOINLINE bool is_zero() const;
+  TC_HD bool operator==(const Fq& b) const { return (*this - b).is_zero(); }
+  TC_HD bool operator!=(const Fq& b) const { return !(*this == b); }
+  TC_HD_NOINLINE Fq inv() const;  // Fermat a^(p-2); 0 -> 0
+  TC_HD static Fq from_canonical(const uint32_t* words12);
+  TC_HD void to_canonical(uint32_t* words12) const;
+  TC_HD static Fq from_mont384(const uint32_t* words12);
+};
+
+// ---- the multiplier ----------------------------------------------------------------------
+// Product-scanning Montgomery multiplication.  Column k gathers sum a_i b_{k-i} (chain 1, with
+// the carry from column k-1) and sum m_i p_{k-i} (chain 2): two independent v_mad_i64_i32
+// dependency chains, so a lone wave on a SIMD still overlaps multiplier latency.
+//   T = a*b + m*p,  T = 0 mod 2^390,  result = T / 2^390  in (-p/4, 5p/4)
+template <bool SQUARE>
+TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
+  constexpr int N = FQ_LIMBS;
+  int32_t m[N];
+  int32_t a2[N];
+  if (SQUARE) {
+    TC_UNROLL for (int i = 0; i < N; i++) a2[i] = a[i] << 1;
+  }
+  int64_t carry = 0;
+  TC_UNROLL for (int k = 0; k < 2 * N - 1; k++) {
+    const int lo = (k < N) ? 0 : (k - N + 1);
+    const int hi = (k < N) ? k : (N - 1);
+    int64_t s1 = carry;
+    int64_t s2 = 0;
+    if (SQUARE) {
+      // pairs i < j with i + j = k, doubled, plus the diagonal term
+      TC_UNROLL for (int i = lo; i <= hi; i++) {
+        const int j = k - i;
+        if (i < j) s1 += (int64_t)a[i] * a2[j];
+        if (i == j) s1 += (int64_t)a[i] * a[i];
+      }
+    } else {
+      TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)a[i] * b[k - i];
+    }
+    if (k < N) {
+      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      int64_t s = s1 + s2;
+      m[k] = (int32_t)(((uint32_t)s * FQ26_INV) & (uint32_t)FQ_MASK);
+      s += (int64_t)m[k] * FQ26_P[0];
+      carry = s >> FQ_RADIX;
+    } else {
+      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      int64_t s = s1 + s2;
+      out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
+      carry = s >> FQ_RADIX;
+    }
+  }
+  out[N - 1] = (int32_t)carry;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// On the device the multiplier is a REAL function, not inlined into every tower/curve routine
+// (that makes the pairing kernel's code object several MB and hipcc compile times unbounded).
+// Operands travel as scalar i32 arguments so the AMDGPU calling convention keeps all 30 of
+// them in VGPRs (aggregates beyond 16 registers would go through scratch memory); the 15-limb
+// result comes back in VGPRs too.
+struct FqRaw {
+  int32_t l[FQ_LIMBS];
+};
+__device__ __attribute__((noinline)) inline FqRaw fq_mul_call(
+    int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8,
+    int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t a14, int32_t b0, int32_t b1, int32_t b2,
+    int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11,
+    int32_t b12, int32_t b13, int32_t b14) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
+  const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14};
+  FqRaw r;
+  fq_mul_body<false>(a, b, r.l);
+  return r;
+}
+__device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3,
+                                                              int32_t a4, int32_t a5, int32_t a6, int32_t a7,
+                                                              int32_t a8, int32_t a9, int32_t a10, int32_t a11,
+                                                              int32_t a12, int32_t a13, int32_t a14) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
+  FqRaw r;
+  fq_mul_body<true>(a, a, r.l);
+  return r;
+}
+#endif
+
+TC_HD Fq fq_mul(const Fq& a, const Fq& b) {
+#if defined(TC_BOUND_CHECK)
+  if (a.bound() * b.bound() > (float)FQ_MAX_BOUND_PRODUCT) tc_bound_fail(a.bound(), b.bound());
+  if (a.val() > 300.f || b.val() > 300.f) tc_bound_fail(-a.val(), -b.val());  // top limb < 2^26
+#endif
+  Fq r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  FqRaw t = fq_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
+                        a.l[11], a.l[12], a.l[13], a.l[14], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6],
+                        b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12], b.l[13], b.l[14]);
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = t.l[i];
+#else
+  fq_mul_body<false>(a.l, b.l, r.l);
+#endif
+  r.set_range(0.f, 1.f);
+  r.set_val(1.f + a.val() * b.val() / 512.f);  // |a b| / R + p, p / R < 2^-9
+  return r;
+}
+
+TC_HD Fq fq_sqr(const Fq& a) {
+#if defined(TC_BOUND_CHECK)
+  if (a.bound() * a.bound() > (float)FQ_MAX_BOUND_PRODUCT) tc_bound_fail(a.bound(), a.bound());
+  if (a.val() > 300.f) tc_bound_fail(-a.val(), -a.val());
+#endif
+  Fq r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  FqRaw t = fq_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
+                        a.l[11], a.l[12], a.l[13], a.l[14]);
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = t.l[i];
+#else
+  fq_mul_body<true>(a.l, a.l, r.l);
+#endif
+  r.set_range(0.f, 1.f);
+  r.set_val(1.f + a.val() * a.val() / 512.f);
+  return r;
+}
+
+// a / R mod p as the UNIQUE representative in [0, p]: limbs fully carried, all in [0, 2^26).
+// (T = a + m p with m in [0, R): T / R > -1 and <= p for |a| < R.)
+TC_HD void fq_redc_full(const Fq& a, int32_t* out) {
+  const int32_t one[FQ_LIMBS] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Fq an = a.norm();  // any lazily grown input is fine: bring limbs back below 2^27 first
+  // the column loop masks limbs 0..13 and carries into the next column, so the output is
+  // already fully carried: digits in [0, 2^26), top limb >= 0
+  fq_mul_body<false>(an.l, one, out);
+}
+
+TC_HD_NOINLINE bool Fq::is_zero() const {
+  int32_t t[FQ_LIMBS];
+  fq_redc_full(*this, t);
+  int32_t z = 0, e = 0;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    z |= t[i];
+    e |= (t[i] ^ FQ26_P[i]);
+  }
+  return z == 0 || e == 0;
+}
+
+TC_HD_NOINLINE Fq Fq::inv() const {
+  return field_pow_fixed(this->norm(), [](int i) { return FQ_P_MINUS_2[i]; }, 381);
+}
+
+// 12 canonical u32 words (an integer < 2^384) -> 15 plain 26-bit limbs
+TC_HD void words12_to_limbs26(const uint32_t* w, int32_t* l) {
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int bit = 26 * i;
+    const int wi = bit >> 5, sh = bit & 31;
+    uint64_t v = (uint64_t)w[wi] >> sh;
+    if (wi + 1 < 12) v |= (uint64_t)w[wi + 1] << (32 - sh);
+    l[i] = (int32_t)((uint32_t)v & (uint32_t)FQ_MASK);
+  }
+  // limb 14 covers bits 364..389; bits above 383 do not exist in the input
+}
+
+TC_HD void limbs26_to_words12(const int32_t* l, uint32_t* w) {
+  TC_UNROLL for (int i = 0; i < 12; i++) w[i] = 0;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int bit = 26 * i;
+    const int wi = bit >> 5, sh = bit & 31;
+    const uint64_t v = (uint64_t)(uint32_t)l[i] << sh;
+    if (wi < 12) w[wi] |= (uint32_t)v;
+    if (wi + 1 < 12) w[wi + 1] |= (uint32_t)(v >> 32);
+  }
+}
+
+// canonical integer (12 little-endian u32 words, < p) -> Montgomery form
+TC_HD Fq Fq::from_canonical(const uint32_t* words12) {
+  Fq a;
+  words12_to_limbs26(words12, a.l);
+  a.set_range(0.f, 1.f);
+  a.set_val(1.f);
+  return fq_mul(a, Fq::from_limbs(FQ26_R2));
+}
+
+// Montgomery form -> canonical integer in [0, p)
+TC_HD void Fq::to_canonical(uint32_t* words12) const {
+  int32_t t[FQ_LIMBS];
+  fq_redc_full(*this, t);
+  int32_t e = 0;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) e |= (t[i] ^ FQ26_P[i]);
+  if (e == 0) {
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) t[i] = 0;  // the representative p is 0
+  }
+  limbs26_to_words12(t, words12);
+}
+
+// A 384-bit pattern that IS a Montgomery representation w.r.t. 2^384 (what ff_derive's
+// random() yields): value = pattern * 2^-384, so the R = 2^390 form is pattern * 2^6
+// = montmul(pattern, 2^396 mod p).
+TC_HD Fq Fq::from_mont384(const uint32_t* words12) {
+  Fq a;
+  words12_to_limbs26(words12, a.l);
+  a.set_range(0.f, 1.f);
+  a.set_val(1.f);
+  return fq_mul(a, Fq::from_limbs(FQ26_FIX384));
+}
+
 // lexicographic "y > -y" test on the canonical value: y > (p-1)/2
 TC_HD bool fq_canonical_gt_half(const uint32_t* y) {
-  // returns y > (p-1)/2
   uint32_t borrow = 0;
   TC_UNROLL for (int i = 0; i < 12; i++) {
     uint64_t d = (uint64_t)FQ_HALF_P_CANON[i] - y[i] - borrow;

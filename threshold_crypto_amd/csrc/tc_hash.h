@@ -123,14 +123,14 @@ struct ChaChaRng {
 // ff_derive 0.6 random() for Fq: 6 x next_u64 (12 words, limb 0 first), top limb masked to 61
 // bits, accept if < q; the accepted bit pattern IS the Montgomery representation.
 TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
-  Fq r;
+  uint32_t w[12];
   bool ok = false;
   TC_NOUNROLL while (!ok) {
-    for (int i = 0; i < 12; i++) r.v.l[i] = rng.next_u32();
-    r.v.l[11] &= 0x1fffffffu;
-    ok = limbs_lt_p<FqParams>(r.v.l);
+    for (int i = 0; i < 12; i++) w[i] = rng.next_u32();
+    w[11] &= 0x1fffffffu;
+    ok = limbs_lt_p<FqParams>(w);
   }
-  return r;
+  return Fq::from_mont384(w);
 }
 
 // Square root in Fq2 (q = 3 mod 4), Algorithm 9 of eprint 2012/685.  false for non-squares.

@@ -17,6 +17,8 @@ struct Fq2 {
   TC_HD Fq2 operator-() const { return Fq2{-c0, -c1}; }
   TC_HD Fq2 dbl() const { return Fq2{c0.dbl(), c1.dbl()}; }
   TC_HD Fq2 conj() const { return Fq2{c0, -c1}; }
+  TC_HD Fq2 norm() const { return Fq2{c0.norm(), c1.norm()}; }
+  TC_HD Fq2 reduce_value() const { return Fq2{c0.reduce_value(), c1.reduce_value()}; }
   // Karatsuba: 3 Fq mul
   TC_HD Fq2 operator*(const Fq2& b) const {
     Fq aa = c0 * b.c0;
@@ -50,6 +52,8 @@ struct Fq6 {
   TC_HD Fq6 operator+(const Fq6& b) const { return Fq6{c0 + b.c0, c1 + b.c1, c2 + b.c2}; }
   TC_HD Fq6 operator-(const Fq6& b) const { return Fq6{c0 - b.c0, c1 - b.c1, c2 - b.c2}; }
   TC_HD Fq6 operator-() const { return Fq6{-c0, -c1, -c2}; }
+  TC_HD Fq6 norm() const { return Fq6{c0.norm(), c1.norm(), c2.norm()}; }
+  TC_HD Fq6 reduce_value() const { return Fq6{c0.reduce_value(), c1.reduce_value(), c2.reduce_value()}; }
   TC_HD_NOINLINE Fq6 operator*(const Fq6& b) const {
     Fq2 t0 = c0 * b.c0;
     Fq2 t1 = c1 * b.c1;
@@ -58,7 +62,7 @@ struct Fq6 {
     r.c0 = t0 + ((c1 + c2) * (b.c1 + b.c2) - t1 - t2).mul_xi();
     r.c1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1 + t2.mul_xi();
     r.c2 = (c0 + c2) * (b.c0 + b.c2) - t0 - t2 + t1;
-    return r;
+    return r.reduce_value();
   }
   // CH-SQR2 (Chung-Hasan): 2 mul + 3 sqr in Fq2
   TC_HD_NOINLINE Fq6 sqr() const {
@@ -73,7 +77,7 @@ struct Fq6 {
     r.c0 = s0 + s3.mul_xi();
     r.c1 = s1 + s4.mul_xi();
     r.c2 = s1 + s2 + s3 - s0 - s4;
-    return r;
+    return r.reduce_value();
   }
   TC_HD Fq6 mul_by_v() const { return Fq6{c2.mul_xi(), c0, c1}; }
   // sparse: times (b0 + b1 v)
@@ -84,29 +88,24 @@ struct Fq6 {
     r.c0 = ((c1 + c2) * b1 - bb).mul_xi() + aa;
     r.c1 = (c0 + c1) * (b0 + b1) - aa - bb;
     r.c2 = (c0 + c2) * b0 - aa + bb;
-    return r;
+    return r.reduce_value();
   }
   // sparse: times (b1 v)
-  TC_HD_NOINLINE Fq6 mul_by_1(const Fq2& b1) const { return Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1}; }
+  TC_HD_NOINLINE Fq6 mul_by_1(const Fq2& b1) const { return Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1}.reduce_value(); }
   TC_HD_NOINLINE Fq6 inv() const {
     Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
     Fq2 t1 = c2.sqr().mul_xi() - c0 * c1;
     Fq2 t2 = c1.sqr() - c0 * c2;
     Fq2 d = c0 * t0 + (c2 * t1 + c1 * t2).mul_xi();
     Fq2 di = d.inv();
-    return Fq6{t0 * di, t1 * di, t2 * di};
+    return Fq6{t0 * di, t1 * di, t2 * di}.reduce_value();
   }
 };
 
 TC_HD Fq2 frob_coeff(int k, int i) {  // gamma_k[i], i = 1..5
-  Fq2 g;
-  const uint32_t* a0 = (k == 1) ? FROB1_C0[i - 1] : (k == 2) ? FROB2_C0[i - 1] : FROB3_C0[i - 1];
-  const uint32_t* a1 = (k == 1) ? FROB1_C1[i - 1] : (k == 2) ? FROB2_C1[i - 1] : FROB3_C1[i - 1];
-  TC_UNROLL for (int j = 0; j < 12; j++) {
-    g.c0.v.l[j] = a0[j];
-    g.c1.v.l[j] = a1[j];
-  }
-  return g;
+  const int32_t* a0 = (k == 1) ? FROB26_1_C0[i - 1] : (k == 2) ? FROB26_2_C0[i - 1] : FROB26_3_C0[i - 1];
+  const int32_t* a1 = (k == 1) ? FROB26_1_C1[i - 1] : (k == 2) ? FROB26_2_C1[i - 1] : FROB26_3_C1[i - 1];
+  return Fq2{Fq::from_limbs(a0), Fq::from_limbs(a1)};
 }
 
 struct Fq12 {
@@ -119,18 +118,20 @@ struct Fq12 {
     Fq12 r;
     r.c1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1;
     r.c0 = t0 + t1.mul_by_v();
-    return r;
+    return r.reduce_value();
   }
   // complex squaring over Fq6: 2 Fq6 mul
   TC_HD_NOINLINE Fq12 sqr() const {
     Fq6 ab = c0 * c1;
     Fq6 t = (c0 + c1) * (c0 + c1.mul_by_v()) - ab - ab.mul_by_v();
-    return Fq12{t, ab + ab};
+    return Fq12{t, ab + ab}.reduce_value();
   }
   TC_HD Fq12 conj() const { return Fq12{c0, -c1}; }
+  TC_HD Fq12 norm() const { return Fq12{c0.norm(), c1.norm()}; }
+  TC_HD Fq12 reduce_value() const { return Fq12{c0.reduce_value(), c1.reduce_value()}; }
   TC_HD_NOINLINE Fq12 inv() const {
     Fq6 t = (c0.sqr() - c1.sqr().mul_by_v()).inv();
-    return Fq12{c0 * t, -(c1 * t)};
+    return Fq12{c0 * t, -(c1 * t)}.reduce_value();
   }
   // sparse multiplication by (d0 + d1 v) + (d4 v) w -- the Miller-loop line shape
   TC_HD_NOINLINE Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
@@ -140,7 +141,7 @@ struct Fq12 {
     Fq12 r;
     r.c1 = (c1 + c0).mul_by_01(d0, o) - aa - bb;
     r.c0 = bb.mul_by_v() + aa;
-    return r;
+    return r.reduce_value();
   }
   // a^(q^k), k in {1,2,3}
   TC_HD_NOINLINE Fq12 frobenius(int k) const {
@@ -152,7 +153,7 @@ struct Fq12 {
     r.c1.c0 = (cj ? c1.c0.conj() : c1.c0) * frob_coeff(k, 1);
     r.c1.c1 = (cj ? c1.c1.conj() : c1.c1) * frob_coeff(k, 3);
     r.c1.c2 = (cj ? c1.c2.conj() : c1.c2) * frob_coeff(k, 5);
-    return r;
+    return r.reduce_value();
   }
   // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part
   // of the final exponentiation): 9 Fq2 squarings' worth instead of 2 Fq6 mul.
@@ -184,8 +185,10 @@ struct Fq12 {
     z2 = (t3x + z2).dbl() + t3x;
     z3 = (t2 - z3).dbl() + t2;
     Fq12 r;
-    r.c0.c0 = z0; r.c0.c1 = z4; r.c0.c2 = z3;
-    r.c1.c0 = z2; r.c1.c1 = z1; r.c1.c2 = z5;
+    // z' = 3t -+ 2z feeds z back linearly: squaring after squaring the VALUE would double, so
+    // bring it back to ~p here (tc_field.h reduce_value)
+    r.c0.c0 = z0.reduce_value(); r.c0.c1 = z4.reduce_value(); r.c0.c2 = z3.reduce_value();
+    r.c1.c0 = z2.reduce_value(); r.c1.c1 = z1.reduce_value(); r.c1.c2 = z5.reduce_value();
     return r;
   }
 };
