@@ -48,7 +48,7 @@ static const u64 FQ_R2[6] = {0xf4df1f341c341746ull, 0x0a76e6a609d104f1ull, 0x8de
                              0x67eb88a9939d83c0ull, 0x9a793e85b519952dull, 0x11988fe592cae3aaull};
 #define FQ_INV 0x89f3fffcfffcfffdull
 
-static u64 g_fq_mul_count = 0; /* Fq multiplications + squarings performed (work constants) */
+static __thread u64 g_fq_mul_count = 0; /* Fq multiplications + squarings by this thread (work constants) */
 
 static inline u64 adc(u64 a, u64 b, u64 *carry) {
   u128 t = (u128)a + b + *carry;
@@ -1455,4 +1455,51 @@ EXPORT int or_g2_compress(const uint8_t *in192, uint8_t *out96) {
   g2_write_compressed(&p, out96);
   return 0;
 }
+/* ---- multi-threaded batch drivers for the timed CPU baseline (bench.py cpu_baseline) ---------- */
+#include <pthread.h>
+typedef struct {
+  int kind; /* 0 = combine_g2, 1 = verify_g2 */
+  size_t t, n, lo, hi;
+  const u64 *idx;
+  const uint8_t *a, *b, *c;
+  uint8_t *out;
+  int *rc;
+} batch_job;
+static void *batch_worker(void *arg) {
+  batch_job *j = (batch_job *)arg;
+  for (size_t k = j->lo; k < j->hi; k++) {
+    if (j->kind == 0)
+      j->rc[k] = or_combine_g2(j->t, j->n, j->idx + k * j->n, j->a + k * j->n * 192, j->out + k * 192);
+    else
+      j->rc[k] = or_verify_g2(j->a, j->b + k * 192, j->c + k * 192);
+  }
+  return NULL;
+}
+static void run_batch(batch_job proto, size_t B, int nthreads) {
+  tc_init();
+  if (nthreads < 1) nthreads = 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  batch_job *jobs = (batch_job *)malloc(sizeof(batch_job) * (size_t)nthreads);
+  for (int i = 0; i < nthreads; i++) {
+    jobs[i] = proto;
+    jobs[i].lo = B * (size_t)i / (size_t)nthreads;
+    jobs[i].hi = B * (size_t)(i + 1) / (size_t)nthreads;
+    pthread_create(&th[i], NULL, batch_worker, &jobs[i]);
+  }
+  for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  free(th);
+  free(jobs);
+}
+/* B combine_signatures jobs (n samples each), nthreads host threads; rc[k] per job */
+EXPORT void or_combine_g2_batch(size_t t, size_t n, const u64 *idx, const uint8_t *shares, size_t B, uint8_t *out, int *rc,
+                                int nthreads) {
+  batch_job p = {0, t, n, 0, 0, idx, shares, NULL, NULL, out, rc};
+  run_batch(p, B, nthreads);
+}
+/* B verify_g2 checks under one public key; rc[k] = 1 if valid */
+EXPORT void or_verify_g2_batch(const uint8_t *pk, const uint8_t *sigs, const uint8_t *hashes, size_t B, int *rc, int nthreads) {
+  batch_job p = {1, 0, 0, 0, 0, NULL, pk, sigs, hashes, NULL, rc};
+  run_batch(p, B, nthreads);
+}
+
 EXPORT void or_sha3_256(const uint8_t *msg, size_t len, uint8_t *out32) { sha3_256(msg, len, out32); }

@@ -47,6 +47,10 @@ def load():
         _lib.or_g1_compress.argtypes = [cp, cp]
         _lib.or_g2_compress.argtypes = [cp, cp]
         _lib.or_sha3_256.argtypes = [cp, sz, cp]
+        _lib.or_combine_g2_batch.argtypes = [sz, sz, vp, vp, sz, vp, vp, ctypes.c_int]
+        _lib.or_combine_g2_batch.restype = None
+        _lib.or_verify_g2_batch.argtypes = [cp, vp, vp, sz, vp, ctypes.c_int]
+        _lib.or_verify_g2_batch.restype = None
     return _lib
 
 
@@ -161,3 +165,25 @@ def fq_mul_count(reset=False):
     if reset:
         lib.or_fq_mul_count_reset()
     return n
+
+
+def combine_g2_batch(t, idx, shares, nthreads):
+    """idx: (B, n) uint64 numpy, shares: (B, n, 192) uint8 numpy -> (out (B,192) uint8, rc (B,) int32)"""
+    import numpy as np
+    B, n = idx.shape
+    out = np.zeros((B, 192), dtype=np.uint8)
+    rc = np.zeros(B, dtype=np.int32)
+    idx = np.ascontiguousarray(idx)
+    shares = np.ascontiguousarray(shares)
+    load().or_combine_g2_batch(t, n, idx.ctypes.data, shares.ctypes.data, B, out.ctypes.data, rc.ctypes.data, nthreads)
+    return out, rc
+
+
+def verify_g2_batch(pk, sigs, hashes, nthreads):
+    import numpy as np
+    B = sigs.shape[0]
+    rc = np.zeros(B, dtype=np.int32)
+    sigs = np.ascontiguousarray(sigs)
+    hashes = np.ascontiguousarray(hashes)
+    load().or_verify_g2_batch(bytes(pk), sigs.ctypes.data, hashes.ctypes.data, B, rc.ctypes.data, nthreads)
+    return rc

@@ -70,12 +70,6 @@ def load():
     # libtc_amd.so needs libamdhip64.so.7.  PyTorch-ROCm bundles its own copy (same SONAME); two
     # HIP/HSA runtimes in one process cannot both own the GPU, so when torch is installed let it
     # load its runtime first and bind to that one.  Torch is not otherwise used here.
-    # The combine / pairing kernels keep per-lane tables and Fq12 state in scratch (several KB per
-    # lane).  ROCr treats a dispatch whose scratch exceeds HSA_SCRATCH_SINGLE_LIMIT (default
-    # 140 MB) as "large": allocated and released around every dispatch.  288 GB of HBM is there to
-    # be used: keep the scratch arena resident.  Must be set before the runtime initialises.
-    os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT", str(2 ** 31 - 1))
-    os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT_ASYNC", str(16 * 2 ** 30))
     try:
         import torch  # noqa: F401
     except Exception:  # torch absent: the system ROCm runtime is used

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 (rocpd sqlite) output directories into small text/CSV files for profiles/.
+usage: python tools/rocpd_summary.py <dir-with-results.db> [<more dirs>...] > summary.csv"""
+import glob
+import sqlite3
+import sys
+
+
+def kernels(db):
+    c = sqlite3.connect(db)
+    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(scratch_size), "
+         "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) from kernels "
+         "group by name order by sum(duration) desc")
+    return list(c.execute(q))
+
+
+def counters(db):
+    c = sqlite3.connect(db)
+    try:
+        cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+        if not cols:
+            return []
+        q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+             "group by kernel_name, counter_name order by kernel_name")
+        return list(c.execute(q))
+    except sqlite3.Error:
+        return []
+
+
+for d in sys.argv[1:]:
+    for db in sorted(glob.glob(d + "/**/*.db", recursive=True)):
+        print("# %s" % db)
+        print("kernel,calls,total_ms,avg_ms,min_ms,max_ms,scratch_B_per_lane,vgpr,agpr,sgpr,grid,wg")
+        for r in kernels(db):
+            name = r[0].split("(")[0].replace(",", ";")
+            print("%s,%d,%.3f,%.3f,%.3f,%.3f,%s,%s,%s,%s,%s,%s" % (name, r[1], r[2] / 1e6, r[3] / 1e6, r[4] / 1e6, r[5] / 1e6,
+                                                                  r[6], r[7], r[8], r[9], r[10], r[11]))
+        cs = counters(db)
+        if cs:
+            print("kernel,counter,samples,avg_value,sum_value")
+            for r in cs:
+                print("%s,%s,%d,%.1f,%.1f" % (r[0].split("(")[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
