@@ -163,3 +163,32 @@ def test_hash_and_kdf(L, rnd):
     out = buf(96)
     L.hs_compress_g2(o.g2_uncompressed(Qp), out)
     assert out.raw == o.g2_compressed(Qp)
+
+
+def test_combine_fast_path_equals_general_path(L, rnd):
+    """The small-index fast path ([D^-1](sum c_i S_i), tc_threshold.h) and the general Lagrange
+    path give the same bytes; large / repeated indices fall back to the general path."""
+    for t, ids in [(1, [0, 1]), (1, [7, 200]), (2, [0, 5, 9]), (3, [0, 1, 2, 3]), (3, [2, 5, 7, 9]), (3, [0, 199, 150, 3]),
+                   (3, [65534, 3, 9, 11]), (3, [70000, 3, 9, 11]), (3, [2 ** 40, 1, 2, 3]), (3, [4, 4, 6, 8]),
+                   (3, [60000, 61000, 62000, 63000])]:
+        poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+        H = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+        sh = [o.E2.mul(H, o.poly_evaluate(poly, (i + 1) % o.R)) for i in ids]
+        blob = b"".join(o.g2_uncompressed(s) for s in sh)
+        idx = (ctypes.c_uint64 * (t + 1))(*ids)
+        fast, gen = buf(192), buf(192)
+        L.hs_force_general_combine(0)
+        assert L.hs_combine_g2(t, idx, blob, fast) == 0
+        L.hs_force_general_combine(1)
+        assert L.hs_combine_g2(t, idx, blob, gen) == 0
+        L.hs_force_general_combine(0)
+        assert fast.raw == gen.raw == o.g2_uncompressed(o.interpolate(o.E2, t, list(zip(ids, sh)))), (t, ids)
+
+
+def test_gls_and_cofactor_probe(L, rnd):
+    """GLS scalar multiplication edge scalars; cofactor clearing is covered by test_hash_and_kdf."""
+    Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    for k in [0, 1, o.BLS_X - 1, o.BLS_X, o.BLS_X + 1, o.BLS_X ** 2, o.BLS_X ** 3, o.R - 1, (1 << 254) + 12345]:
+        out = buf(192)
+        assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0
+        assert out.raw == o.g2_uncompressed(o.E2.mul(Q2, k)), hex(k)

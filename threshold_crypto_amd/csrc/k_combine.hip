@@ -7,18 +7,28 @@ namespace tc {
 // one lane per (job, sample position): lambda_i of job j
 __global__ __launch_bounds__(kBlock) void k_lagrange(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t,
                                                      size_t B, uint32_t* __restrict__ lam,
-                                                     uint8_t* __restrict__ status) {
+                                                     uint8_t* __restrict__ status, int g2) {
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t k = t + 1;
   if (tid >= B * k) return;
   const size_t j = tid / k, i = tid % k;
+  if (g2 && combine_g2_small_applies(idx + j * n_per_job, (int)t)) return;  // the fast path owns the job
   uint8_t st = job_lagrange(idx + j * n_per_job, (int)t, (int)i, lam + tid * 8);
   if (st && status) status[j] = st;
 }
 
+TC_D bool combine_fast(const Fq&, size_t, const uint64_t*, const uint8_t*, uint8_t*, uint8_t*) { return false; }
+TC_D bool combine_fast(const Fq2&, size_t t, const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* st) {
+  if (t == 1) return job_combine_g2_small<2>(idx, shares, out, st);
+  if (t == 2) return job_combine_g2_small<3>(idx, shares, out, st);
+  if (t == 3) return job_combine_g2_small<4>(idx, shares, out, st);
+  return false;
+}
+
 // one lane per job: sum_i lambda_i * share_i
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, const uint8_t* __restrict__ shares,
+__global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
+                                                    const uint8_t* __restrict__ shares,
                                                     const uint32_t* __restrict__ lam, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   constexpr int PB = PointIO<F>::BYTES;
@@ -28,7 +38,9 @@ __global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, 
     PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
     return;
   }
-  uint8_t st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
+  uint8_t st = TC_JOB_OK;
+  if (!combine_fast(F::zero(), t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st))
+    st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
   if (status) status[j] = st;
 }
 
@@ -55,17 +67,17 @@ void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const u
 }
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
-                     uint8_t* status) {
+                     uint8_t* status, bool g2) {
   const size_t n = B * (t + 1);
-  if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status);
+  if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status, g2 ? 1 : 0);
 }
-void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
-                       size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_combine<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, shares, lam, B, out, status);
+void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_combine<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status);
 }
-void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint8_t* shares, const uint32_t* lam,
-                       size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, shares, lam, B, out, status);
+void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status);
 }
 
 }  // namespace tc

@@ -351,9 +351,9 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
   }
   k.begin_timing();
   if (!k.failed) {
-    if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st);
-    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_sh, d_lam, B, d_pt, d_st);
-    else tc::launch_combine_g1(ctx->stream, t, n, d_sh, d_lam, B, d_pt, d_st);
+    if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, g2);
+    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st);
+    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
   }
   k.end_timing();

@@ -5,6 +5,7 @@
 // pairing 0.16 G2::random as published; it is the one implementation-defined part of the path.
 #pragma once
 #include "tc_codec.h"
+#include "tc_gls.h"
 
 namespace tc {
 
@@ -185,7 +186,7 @@ TC_HD G2Jac g2_random_from_seed(const uint32_t* seed_words) {
       bool greatest = (rng.next_u32() & 1u) != 0;
       have = g2_point_from_x(x, greatest, cand);
     }
-    res = jac_mul_affine_uniform(cand, [](int i) { return G2_COFACTOR[i]; }, G2_COFACTOR_BITS);
+    res = g2_clear_cofactor(cand);  // = [h2] cand, the value scale_by_cofactor returns
     done = !res.is_inf();
   }
   return res;

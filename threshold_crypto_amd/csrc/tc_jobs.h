@@ -3,6 +3,7 @@
 // tests/hostsim calls the same bodies from a host loop (test harness only).
 #pragma once
 #include "tc_codec.h"
+#include "tc_gls.h"
 #include "tc_hash.h"
 #include "tc_pairing.h"
 #include "tc_threshold.h"
@@ -27,6 +28,16 @@ struct PointIO<Fq2> {
   TC_HD static void encode(const Affine<Fq2>& p, uint8_t* b) { g2_encode_uncompressed(p, b); }
 };
 
+// [k] p.  G1: the 255-bit double-and-add ladder (wave-uniform scalar => uniform control flow).
+// G2: 4-dimensional GLS through psi (tc_gls.h): 64 doublings instead of 255.  Operands must
+// lie in the prime-order subgroup, as every G1/G2 value the reference holds does.
+TC_HD Jac<Fq> point_mul_scalar(const Affine<Fq>& p, const uint32_t* k) {
+  return jac_mul_affine_uniform(p, [&](int i) { return k[i]; }, 255);
+}
+TC_HD Jac<Fq2> point_mul_scalar(const Affine<Fq2>& p, const uint32_t* k) {
+  return g2_mul_gls(G2Jac::from_affine(p), k);
+}
+
 // out = fr * pt           (CurveAffine::mul: sign_g2 src/lib.rs:373, decrypt_share :461)
 // The scalar is shared by all lanes of a wave (one secret key share per wave), so the
 // bit-serial double-and-add below has wave-uniform control flow.
@@ -40,8 +51,7 @@ TC_HD uint8_t job_point_mul(const uint8_t* fr_le32, const uint8_t* pt, uint8_t* 
     PointIO<F>::encode(Affine<F>::infinity(), out);
     return TC_JOB_INVALID_ENCODING;
   }
-  Jac<F> r = jac_mul_affine_uniform(p, [&](int i) { return k[i]; }, 255);
-  PointIO<F>::encode(jac_to_affine(r), out);
+  PointIO<F>::encode(jac_to_affine(point_mul_scalar(p, k)), out);
   return TC_JOB_OK;
 }
 
@@ -87,6 +97,41 @@ TC_HD uint8_t job_lincomb(int n, const uint8_t* points, const uint32_t* scalars,
   }
   PointIO<F>::encode(jac_to_affine(total), out);
   return TC_JOB_OK;
+}
+
+// G2 combination through the small-index fast path (tc_threshold.h); false => not applicable
+template <int K>
+TC_HD bool job_combine_g2_small(const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* status) {
+  uint64_t c_abs[K], d_abs;
+  bool c_neg[K], d_neg;
+  if (!lagrange_small_coeffs<K>(idx, c_abs, c_neg, &d_abs, &d_neg)) return false;
+  G2Affine pts[K];
+  bool ok = true;
+  TC_NOUNROLL for (int k = 0; k < K; k++) {
+    ok &= g2_decode_uncompressed(shares + (size_t)k * 192, pts[k]);
+    if (c_neg[k]) pts[k].y = -pts[k].y;
+  }
+  if (!ok) {
+    g2_encode_uncompressed(G2Affine::infinity(), out);
+    *status = TC_JOB_INVALID_ENCODING;
+    return true;
+  }
+  G2Jac a = straus_small<Fq2, K>(pts, c_abs);
+  uint32_t dinv[8];
+  fr_inverse_of_small(d_abs, d_neg, dinv);
+  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(a, dinv)), out);
+  *status = TC_JOB_OK;
+  return true;
+}
+
+// true when job_combine_g2_small will handle the job (so the Lagrange kernel can skip it)
+TC_HD bool combine_g2_small_applies(const uint64_t* idx, int t) {
+  uint64_t c_abs[4], d_abs;
+  bool c_neg[4], d_neg;
+  if (t == 1) return lagrange_small_coeffs<2>(idx, c_abs, c_neg, &d_abs, &d_neg);
+  if (t == 2) return lagrange_small_coeffs<3>(idx, c_abs, c_neg, &d_abs, &d_neg);
+  if (t == 3) return lagrange_small_coeffs<4>(idx, c_abs, c_neg, &d_abs, &d_neg);
+  return false;
 }
 
 // out = sum_{i <= t} lambda_i * share_i over the FIRST t+1 samples of the job

@@ -50,4 +50,95 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
   return acc;
 }
 
+// ---- small-index fast path ------------------------------------------------------------------
+// Share indices are node numbers, so the abscissae x_i = idx_i + 1 are small integers and the
+// Lagrange coefficients are ratios of SMALL integers:
+//     lambda_i = num_i / den_i,  num_i = prod_{j != i} x_j,  den_i = prod_{j != i} (x_j - x_i).
+// With D = prod_j den_j and the integers c_i = num_i * prod_{j != i} den_j (a few tens of bits),
+//     sum_i lambda_i S_i = [D^-1 mod r] ( sum_i c_i S_i ),
+// i.e. one short joint ladder over |c_i| followed by ONE full-size (GLS) multiplication,
+// instead of t+1 full-size ones.  Same group element, same bytes.  Returns false -- caller
+// uses the general path -- when indices repeat (the reference's by-value filtering then
+// applies, src/lib.rs:758), are large, or a product leaves 63 bits.
+template <int K>
+TC_HD bool lagrange_small_coeffs(const uint64_t* idx, uint64_t* c_abs, bool* c_neg, uint64_t* d_abs, bool* d_neg) {
+  int64_t x[K];
+  TC_UNROLL for (int i = 0; i < K; i++) {
+    if (idx[i] >= 65535) return false;
+    x[i] = (int64_t)idx[i] + 1;
+  }
+  int64_t den[K];
+  TC_UNROLL for (int i = 0; i < K; i++) {
+    int64_t d = 1;
+    TC_UNROLL for (int j = 0; j < K; j++) {
+      if (j == i) continue;
+      const int64_t diff = x[j] - x[i];
+      if (diff == 0) return false;
+      if (__builtin_mul_overflow(d, diff, &d)) return false;
+    }
+    den[i] = d;
+  }
+  int64_t D = 1;
+  TC_UNROLL for (int i = 0; i < K; i++)
+    if (__builtin_mul_overflow(D, den[i], &D)) return false;
+  TC_UNROLL for (int i = 0; i < K; i++) {
+    int64_t c = 1;
+    TC_UNROLL for (int j = 0; j < K; j++) {
+      if (j == i) continue;
+      if (__builtin_mul_overflow(c, x[j], &c)) return false;
+      if (__builtin_mul_overflow(c, den[j], &c)) return false;
+    }
+    c_neg[i] = c < 0;
+    c_abs[i] = (uint64_t)(c < 0 ? -c : c);
+  }
+  *d_neg = D < 0;
+  *d_abs = (uint64_t)(D < 0 ? -D : D);
+  return true;
+}
+
+// D^-1 mod r as 8 canonical LE words
+TC_HD void fr_inverse_of_small(uint64_t d_abs, bool d_neg, uint32_t* out_words) {
+  Fr d = fr_from_u64(d_abs);
+  if (d_neg) d = Fr::zero() - d;
+  d.inv().to_canonical(out_words);
+}
+
+// the ladder below starts at the highest set bit of any scalar in the WAVE so that all lanes
+// run the same trip count
+TC_HD uint32_t wave_max_u32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  TC_UNROLL for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
+  }
+#endif
+  return v;
+}
+
+// sum_k c_k * P_k for K <= 4 points and 64-bit scalars
+template <class F, int K>
+TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
+  Jac<F> tbl[1 << K];
+  tbl[0] = Jac<F>::infinity();
+  TC_NOUNROLL for (int m = 1; m < (1 << K); m++) {
+    int low = 0;
+    while (!((m >> low) & 1)) low++;
+    tbl[m] = jac_add_mixed(tbl[m & (m - 1)], pts[low]);
+  }
+  uint64_t any = 0;
+  TC_UNROLL for (int k = 0; k < K; k++) any |= c[k];
+  uint32_t bits = 0;
+  while (bits < 64 && (any >> bits)) bits++;
+  bits = wave_max_u32(bits);
+  if (bits > 64) bits = 64;  // lanes that left for the general path contribute undefined values
+  Jac<F> acc = Jac<F>::infinity();
+  TC_NOUNROLL for (int bit = (int)bits - 1; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    uint32_t m = 0;
+    TC_UNROLL for (int k = 0; k < K; k++) m |= (uint32_t)((c[k] >> bit) & 1ull) << k;
+    if (m) acc = jac_add(acc, tbl[m]);
+  }
+  return acc;
+}
+
 }  // namespace tc
