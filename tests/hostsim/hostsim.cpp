@@ -6,6 +6,13 @@
 using namespace tc;
 
 extern "C" {
+#if defined(TC_COUNT_OPS)
+void hs_op_counts(uint64_t* mul, uint64_t* sqr, int reset) {
+  *mul = g_tc_mul_count;
+  *sqr = g_tc_sqr_count;
+  if (reset) g_tc_mul_count = g_tc_sqr_count = 0;
+}
+#endif
 int hs_fq_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   Fq x, y;
   if (!fq_from_be48(a, false, x) || !fq_from_be48(b, false, y)) return -1;

@@ -1,0 +1,193 @@
+"""The reference's own tests (src/lib.rs:793-1008, doc-test :583-607, examples/threshold_sig.rs)
+replayed through the host-side API mirror (threshold_crypto_amd/api.py) on the GPU, with the
+oracle as the independent checker.  Names and flow follow the Rust tests line by line."""
+import random
+
+import numpy as np
+import pytest
+
+import tc_oracle as o
+from threshold_crypto_amd import api
+from threshold_crypto_amd.api import (Ciphertext, DecryptionShare, NotEnoughShares, PublicKeySet, SecretKey, SecretKeySet,
+                                      SignatureShare)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _engine(engine):
+    api.set_default_engine(engine)
+    yield
+
+
+@pytest.fixture(scope="module")
+def rnd():
+    return random.Random(4242)
+
+
+def random_sk_set(t, rnd):
+    return SecretKeySet([rnd.randrange(o.R) for _ in range(t + 1)])
+
+
+def test_doc_test_combine_signatures(rnd):
+    """src/lib.rs:583-607."""
+    sk_set = random_sk_set(3, rnd)
+    sk_shares = [sk_set.secret_key_share(i) for i in range(6)]
+    pk_set = sk_set.public_keys()
+    msg = b"Happy birthday! If this is signed, at least four people remembered!"
+    sig_shares = {i: sk_shares[i].sign(msg) for i in range(4)}
+    for i, sig_share in sig_shares.items():
+        assert pk_set.public_key_share(i).verify(sig_share, msg)
+    sig = pk_set.combine_signatures(sig_shares)
+    assert pk_set.public_key().verify(sig, msg)
+    # oracle: the combination is the master key's signature
+    assert sig.raw == o.g2_uncompressed(o.sign(sk_set.poly[0], msg))
+
+
+def test_threshold_sig(rnd):
+    """test_threshold_sig, src/lib.rs:822-873."""
+    sk_set = random_sk_set(3, rnd)
+    pk_set = sk_set.public_keys()
+    pk_master = pk_set.public_key()
+    assert pk_master.raw != pk_set.public_key_share(0).raw and pk_master.raw != pk_set.public_key_share(2).raw
+    assert pk_set.threshold() == 3
+    msg = b"Totally real news"
+    sigs = {i: sk_set.secret_key_share(i).sign(msg) for i in (5, 8, 7, 10)}
+    for i, sig in sigs.items():
+        assert pk_set.public_key_share(i).verify(sig, msg)
+    sig = pk_set.combine_signatures(sigs)
+    assert pk_set.public_key().verify(sig, msg)
+    sigs2 = {i: sk_set.secret_key_share(i).sign(msg) for i in (42, 43, 44, 45)}
+    sig2 = pk_set.combine_signatures(sigs2)
+    assert sig == sig2
+    with pytest.raises(NotEnoughShares):
+        pk_set.combine_signatures({i: sigs[i] for i in (5, 8, 7)})
+    # more than t+1 shares: the first t+1 in BTreeMap order are used (take(t+1), src/lib.rs:728)
+    more = dict(sigs)
+    more[11] = sk_set.secret_key_share(11).sign(msg)
+    assert pk_set.combine_signatures(more) == sig
+
+
+def test_simple_sig(rnd):
+    """test_simple_sig, src/lib.rs:810-820."""
+    sk0, sk1 = SecretKey(rnd.randrange(o.R)), SecretKey(rnd.randrange(o.R))
+    pk0, pk1 = sk0.public_key(), sk1.public_key()
+    msg0, msg1 = b"Real news", b"Fake news"
+    assert pk0.verify(sk0.sign(msg0), msg0)
+    assert not pk1.verify(sk0.sign(msg0), msg0)
+    assert not pk0.verify(sk0.sign(msg0), msg1)
+    assert pk0.raw == o.g1_uncompressed(o.public_key(sk0.fr))
+
+
+def test_simple_enc_and_threshold_enc(rnd):
+    """test_simple_enc (src/lib.rs:875-897) and test_threshold_enc (:907-939); ciphertexts are built
+    by the oracle's encrypt (encryption is a 'next' row), decrypted on the GPU."""
+    sk_bob = SecretKey(rnd.randrange(o.R))
+    pk_bob = o.public_key(sk_bob.fr)
+    msg = b"Muffins in the canteen today! Don't tell Eve!"
+    u, v, w = o.encrypt_with_r(pk_bob, rnd.randrange(1, o.R), msg)
+    ct = Ciphertext(o.g1_uncompressed(u), v, o.g2_uncompressed(w))
+    assert ct.verify()
+    assert sk_bob.decrypt(ct) == msg
+    assert SecretKey(rnd.randrange(o.R)).decrypt(ct) != msg
+    fake = Ciphertext(ct.u, bytes([ct.v[0] ^ 1]) + ct.v[1:], ct.w)
+    assert not fake.verify() and sk_bob.decrypt(fake) is None
+    # threshold
+    sk_set = random_sk_set(3, rnd)
+    pk_set = sk_set.public_keys()
+    u, v, w = o.encrypt_with_r(o.g1_from_uncompressed(pk_set.public_key().raw, check=False), rnd.randrange(1, o.R), b"Totally real news")
+    ct = Ciphertext(o.g1_uncompressed(u), v, o.g2_uncompressed(w))
+    assert ct.verify()
+    shares = {}
+    for i in (8, 4, 7, 9):
+        sh = sk_set.secret_key_share(i).decrypt_share(ct)
+        assert isinstance(sh, DecryptionShare)
+        assert pk_set.public_key_share(i).verify_decryption_share(sh, ct)
+        shares[i] = sh
+    assert pk_set.decrypt(shares, ct) == b"Totally real news"
+    bad = dict(shares)
+    bad[8] = shares[4]
+    assert not pk_set.public_key_share(8).verify_decryption_share(bad[8], ct)
+    with pytest.raises(NotEnoughShares):
+        pk_set.decrypt({i: shares[i] for i in (8, 4, 7)}, ct)
+    fake = Ciphertext(ct.u, bytes([ct.v[0] ^ 1]) + ct.v[1:], ct.w)
+    assert sk_set.secret_key_share(2).decrypt_share(fake) is None
+
+
+def test_hash_g2_properties_and_oracle(rnd):
+    """test_hash_g2 (src/lib.rs:941-952): deterministic, message-sensitive; plus oracle equality."""
+    msg = bytes(rnd.randrange(256) for _ in range(1000))
+    msg_end0 = msg + b"\x00"
+    msg_end1 = msg + b"\x01"
+    h = api.hash_g2_batch([msg, msg, msg_end0, msg_end1])
+    assert h[0] == h[1] and h[0] != h[2] and h[2] != h[3]
+    assert h[0] == o.g2_uncompressed(o.hash_g2(msg))
+
+
+def test_from_to_bytes_sizes(rnd):
+    """test_from_to_bytes / test_size (src/lib.rs:984-993,1049-1053): 48 / 96 byte encodings."""
+    sk = SecretKey(rnd.randrange(o.R))
+    sig = sk.sign(b"Please sign here: ______")
+    pk = sk.public_key()
+    assert len(pk.to_bytes()) == api.PK_SIZE == 48 and len(sig.to_bytes()) == api.SIG_SIZE == 96
+    assert pk.to_bytes() == o.g1_compressed(o.public_key(sk.fr))
+    assert o.g2_from_compressed(sig.to_bytes()) == o.sign(sk.fr, b"Please sign here: ______")
+    assert sig.parity() == o.signature_parity(o.sign(sk.fr, b"Please sign here: ______"))
+
+
+def test_share_validation_loop_of_threshold_sig_example(rnd):
+    """examples/threshold_sig.rs:115-131: validate every share under its public key share, drop
+    the invalid ones, combine the rest."""
+    t, n = 2, 6
+    sk_set = random_sk_set(t, rnd)
+    pk_set = sk_set.public_keys()
+    msg = b"a block"
+    shares = {i: sk_set.secret_key_share(i).sign(msg) for i in range(n)}
+    shares[3] = SignatureShare(sk_set.secret_key_share(4).sign(msg).raw)  # node 3 lies
+    pk_shares = pk_set.public_key_shares(list(range(n)))
+    ok = api.PublicKeyShare.verify_batch_shares(pk_shares, [shares[i] for i in range(n)], [msg] * n)
+    assert ok.tolist() == [True, True, True, False, True, True]
+    good = {i: shares[i] for i in range(n) if ok[i]}
+    assert pk_set.public_key().verify(pk_set.combine_signatures(good), msg)
+    assert [p.raw for p in pk_shares] == [o.g1_uncompressed(o.public_key(sk_set.secret_key_share(i).fr)) for i in range(n)]
+
+
+def test_larger_threshold_general_path(engine, rnd):
+    """t = 9 (three Straus chunks, general Lagrange path) and indices beyond the fast path's range."""
+    t = 9
+    sk_set = random_sk_set(t, rnd)
+    pk_set = sk_set.public_keys()
+    h = api.hash_g2(b"big committee")
+    ids = sorted(rnd.sample(range(200), t + 1))
+    shares = {i: sk_set.secret_key_share(i).sign_g2(h) for i in ids}
+    sig = pk_set.combine_signatures(shares)
+    assert sig.raw == o.g2_uncompressed(o.E2.mul(o.g2_from_uncompressed(h, check=False), sk_set.poly[0]))
+    big = {i + 10 ** 12: SignatureShare(o.g2_uncompressed(o.E2.mul(o.g2_from_uncompressed(h, check=False), o.poly_evaluate(sk_set.poly, (i + 10 ** 12 + 1) % o.R))))
+           for i in range(t + 1)}
+    assert pk_set.combine_signatures(big) == sig
+
+
+def test_full_batch_properties(engine, rnd):
+    """Size-independent properties on a 4 096-job batch (the same checks bench.py applies at
+    65 536): combine == master-key signature, verifies, corrupted jobs are caught."""
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    t, N, B = 3, 10, 4096
+    wl = ThresholdSigWorkload(engine, t, N, B)
+    sig, st = engine.combine_g2(t, wl.idx, wl.shares)
+    assert not st.any()
+    msig, _ = engine.g2_mul(wl.master_sk_fr[None].copy(), wl.hashes)
+    assert (msig[:, 0] == sig).all()
+    bad = sig.copy()
+    bad[::16] = np.roll(sig, -1, axis=0)[::16]  # every 16th job gets its neighbour's signature
+    ok = engine.verify_g2(wl.master_pk, bad, wl.hashes)
+    want = np.ones(B, dtype=np.uint8)
+    want[::16] = 0
+    assert (ok == want).all()
+    assert engine.verify_sig(wl.master_pk, sig, wl.msg_flat, wl.msg_off).all()
+    # a second, disjoint subset of signers gives the same signatures (uniqueness)
+    idx2 = (9 - wl.idx[:, ::-1]).astype(np.uint64)  # complement-mirror keeps rows ascending
+    fr = np.stack([np.frombuffer(s._bytes(), dtype=np.uint8) for s in wl.shares_sk])
+    allsh, _ = engine.g2_mul(fr, np.ascontiguousarray(wl.hashes[:512]))
+    rows = np.arange(512)[:, None]
+    sig2, st2 = engine.combine_g2(t, np.ascontiguousarray(idx2[:512]), np.ascontiguousarray(allsh[rows, idx2[:512].astype(np.int64)]))
+    assert not st2.any() and (sig2 == sig[:512]).all()

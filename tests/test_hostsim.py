@@ -192,3 +192,40 @@ def test_gls_and_cofactor_probe(L, rnd):
         out = buf(192)
         assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0
         assert out.raw == o.g2_uncompressed(o.E2.mul(Q2, k)), hex(k)
+
+
+def test_bound_check_build(rnd):
+    """Static bound analysis of the lazy-limb arithmetic (tc_field.h): rebuild the device source
+    with -DTC_BOUND_CHECK (limb intervals + value bounds carried through every operation, abort
+    on any multiplication that could overflow a column accumulator) and walk every job body.
+    The bounds are data-independent, so one pass per code path is a proof for that path."""
+    lib = os.path.join(HERE, "hostsim", "libtc_hostsim_bc.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DTC_BOUND_CHECK", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", lib], check=True)
+    code = r'''
+import sys, ctypes, random
+sys.path.insert(0, %r)
+import tc_oracle as o
+L = ctypes.CDLL(%r)
+rnd = random.Random(5)
+buf = ctypes.create_string_buffer
+P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)); Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+k = rnd.randrange(o.R)
+out = buf(96); assert L.hs_g1_mul(o.fr_to_bytes(k), o.g1_uncompressed(P), out) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(P, k))
+out = buf(192); assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0 and out.raw == o.g2_uncompressed(o.E2.mul(Q2, k))
+for t, ids in [(3, [1, 4, 6, 9]), (5, [0, 2, 3, 6, 9, 11]), (3, [2**40, 1, 2, 3])]:
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    sh = [o.E2.mul(Q2, o.poly_evaluate(poly, (i + 1) %% o.R)) for i in ids]
+    out = buf(192); assert L.hs_combine_g2(t, (ctypes.c_uint64 * (t + 1))(*ids), b"".join(o.g2_uncompressed(s) for s in sh), out) == 0
+    assert out.raw == o.g2_uncompressed(o.E2.mul(Q2, poly[0]))
+    sh1 = [o.E1.mul(P, o.poly_evaluate(poly, (i + 1) %% o.R)) for i in ids]
+    out = buf(96); assert L.hs_combine_g1(t, (ctypes.c_uint64 * (t + 1))(*ids), b"".join(o.g1_uncompressed(s) for s in sh1), out) == 0
+a = rnd.randrange(o.R)
+assert L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(Q2), o.g1_uncompressed(o.G1_GEN), o.g2_uncompressed(o.E2.mul(Q2, a))) == 1
+for m in (b"", b"bound check", bytes(200)):
+    out = buf(192); L.hs_hash_g2(m, len(m), out); assert out.raw == o.g2_uncompressed(o.hash_g2(m))
+out = buf(192); assert L.hs_hash_g1_g2(o.g1_uncompressed(P), b"x" * 70, 70, out) == 0
+out = buf(48); L.hs_compress_g1(o.g1_uncompressed(P), out); assert out.raw == o.g1_compressed(P)
+print("BOUNDS-OK")
+''' % (os.path.join(os.path.dirname(HERE), "oracle"), lib)
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BOUNDS-OK" in r.stdout, r.stderr[-2000:]

@@ -238,6 +238,12 @@ constexpr int FQ_RADIX = 26;
 constexpr int32_t FQ_MASK = (1 << FQ_RADIX) - 1;
 constexpr int FQ_MAX_BOUND_PRODUCT = 128;  // B_a * B_b allowed at a multiplication
 
+#if defined(TC_COUNT_OPS)
+// host-only (tests/hostsim): multiplications / squarings executed, for the "ours M/unit"
+// column of DESIGN.md and bench.py's executed-MAC roofline
+inline uint64_t g_tc_mul_count = 0, g_tc_sqr_count = 0;
+#endif
+
 struct Fq;
 TC_HD Fq fq_mul(const Fq& a, const Fq& b);
 TC_HD Fq fq_sqr(const Fq& a);
@@ -453,6 +459,9 @@ TC_HD Fq fq_mul(const Fq& a, const Fq& b) {
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = t.l[i];
 #else
   fq_mul_body<false>(a.l, b.l, r.l);
+#if defined(TC_COUNT_OPS)
+  g_tc_mul_count++;
+#endif
 #endif
   r.set_range(0.f, 1.f);
   r.set_val(1.f + a.val() * b.val() / 512.f);  // |a b| / R + p, p / R < 2^-9
@@ -471,6 +480,9 @@ TC_HD Fq fq_sqr(const Fq& a) {
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = t.l[i];
 #else
   fq_mul_body<true>(a.l, a.l, r.l);
+#if defined(TC_COUNT_OPS)
+  g_tc_sqr_count++;
+#endif
 #endif
   r.set_range(0.f, 1.f);
   r.set_val(1.f + a.val() * a.val() / 512.f);
