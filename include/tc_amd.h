@@ -146,6 +146,12 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share_g1, si
 int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status);
 int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* out96, uint8_t* status);
 
+/* compressed -> uncompressed with the CHECKED decode of PublicKey::from_bytes src/lib.rs:140-146 and
+ * Signature::from_bytes :246-252 (serde: src/serde_impl.rs:187-218): flags, range, on-curve and
+ * order-r subgroup membership; status = TC_JOB_INVALID_ENCODING (FromBytesError::Invalid) otherwise. */
+int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status);
+int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out192, uint8_t* status);
+
 #ifdef __cplusplus
 }
 #endif

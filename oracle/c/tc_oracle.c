@@ -1502,4 +1502,72 @@ EXPORT void or_verify_g2_batch(const uint8_t *pk, const uint8_t *sigs, const uin
   run_batch(p, B, nthreads);
 }
 
+/* checked decode of the compressed forms: EncodedPoint::into_affine (on-curve + [r]P == 0), the
+ * check behind PublicKey::from_bytes (src/lib.rs:140-146) / Signature::from_bytes (:246-252) */
+static const u64 Q_P1_D4[6] = {0xee7fbfffffffeaabull, 0x07aaffffac54ffffull, 0xd9cc34a83dac3d89ull,
+                               0xd91dd2e13ce144afull, 0x92c6e9ed90d2eb35ull, 0x0680447a8e5ff9a6ull};
+static void fq_pow(fq *a, const u64 *e, int nlimbs) {
+  fq res;
+  fq_one(&res);
+  for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+    fq_sqr(&res);
+    if ((e[i / 64] >> (i % 64)) & 1) fq_mul(&res, a);
+  }
+  *a = res;
+}
+EXPORT int or_g1_decompress(const uint8_t *in48, uint8_t *out96) {
+  tc_init();
+  g1_aff p;
+  if (!(in48[0] & 0x80)) return 3;
+  if (in48[0] & 0x40) {
+    if (in48[0] & 0x3f) return 3;
+    for (int i = 1; i < 48; i++) if (in48[i]) return 3;
+    p.inf = 1; fq_zero(&p.x); fq_one(&p.y);
+    g1_write(&p, out96);
+    return 0;
+  }
+  int greatest = (in48[0] & 0x20) != 0;
+  if (!fq_read_be(&p.x, in48, 1)) return 3;
+  fq rhs = p.x, b, y, negy;
+  fq_sqr(&rhs); fq_mul(&rhs, &p.x); fq_b_g1(&b); fq_add(&rhs, &b);
+  y = rhs;
+  fq_pow(&y, Q_P1_D4, 6);
+  fq y2 = y;
+  fq_sqr(&y2);
+  if (!fq_eq(&y2, &rhs)) return 3;
+  negy = y; fq_neg(&negy);
+  p.y = ((fq_cmp(&y, &negy) > 0) == greatest) ? y : negy;
+  p.inf = 0;
+  g1_jac t;
+  g1_mul_bits(&t, &p, FR_MOD, 4);
+  if (!g1_jac_is_zero(&t)) return 3;
+  g1_write(&p, out96);
+  return 0;
+}
+EXPORT int or_g2_decompress(const uint8_t *in96, uint8_t *out192) {
+  tc_init();
+  g2_aff p;
+  if (!(in96[0] & 0x80)) return 3;
+  if (in96[0] & 0x40) {
+    if (in96[0] & 0x3f) return 3;
+    for (int i = 1; i < 96; i++) if (in96[i]) return 3;
+    p.inf = 1; fq2_zero(&p.x); fq2_one(&p.y);
+    g2_write(&p, out192);
+    return 0;
+  }
+  int greatest = (in96[0] & 0x20) != 0;
+  if (!fq_read_be(&p.x.c1, in96, 1) || !fq_read_be(&p.x.c0, in96 + 48, 0)) return 3;
+  fq2 rhs = p.x, b, y, negy;
+  fq2_sqr(&rhs); fq2_mul(&rhs, &p.x); fq2_b_g2(&b); fq2_add(&rhs, &b);
+  if (!fq2_sqrt(&y, &rhs)) return 3;
+  negy = y; fq2_neg(&negy);
+  p.y = ((fq2_cmp(&y, &negy) > 0) == greatest) ? y : negy;
+  p.inf = 0;
+  g2_jac t;
+  g2_mul_bits(&t, &p, FR_MOD, 4);
+  if (!g2_jac_is_zero(&t)) return 3;
+  g2_write(&p, out192);
+  return 0;
+}
+
 EXPORT void or_sha3_256(const uint8_t *msg, size_t len, uint8_t *out32) { sha3_256(msg, len, out32); }

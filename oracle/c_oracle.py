@@ -47,6 +47,8 @@ def load():
         _lib.or_g1_compress.argtypes = [cp, cp]
         _lib.or_g2_compress.argtypes = [cp, cp]
         _lib.or_sha3_256.argtypes = [cp, sz, cp]
+        _lib.or_g1_decompress.argtypes = [cp, cp]
+        _lib.or_g2_decompress.argtypes = [cp, cp]
         _lib.or_combine_g2_batch.argtypes = [sz, sz, vp, vp, sz, vp, vp, ctypes.c_int]
         _lib.or_combine_g2_batch.restype = None
         _lib.or_verify_g2_batch.argtypes = [cp, vp, vp, sz, vp, ctypes.c_int]
@@ -187,3 +189,13 @@ def verify_g2_batch(pk, sigs, hashes, nthreads):
     hashes = np.ascontiguousarray(hashes)
     load().or_verify_g2_batch(bytes(pk), sigs.ctypes.data, hashes.ctypes.data, B, rc.ctypes.data, nthreads)
     return rc
+
+
+def g1_decompress(b):
+    out = _buf(96)
+    return load().or_g1_decompress(bytes(b), out), out.raw
+
+
+def g2_decompress(b):
+    out = _buf(192)
+    return load().or_g2_decompress(bytes(b), out), out.raw

@@ -172,6 +172,8 @@ int hs_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* ou
 int hs_xor_with_hash(const uint8_t* g1, const uint8_t* data, size_t len, uint8_t* out) {
   return job_xor_with_hash(g1, data, len, out);
 }
+int hs_decompress_g1(const uint8_t* in, uint8_t* out) { return job_decompress<Fq>(in, out); }
+int hs_decompress_g2(const uint8_t* in, uint8_t* out) { return job_decompress<Fq2>(in, out); }
 int hs_compress_g1(const uint8_t* in, uint8_t* out) { return job_compress<Fq>(in, out); }
 int hs_compress_g2(const uint8_t* in, uint8_t* out) { return job_compress<Fq2>(in, out); }
 }

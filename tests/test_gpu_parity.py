@@ -291,3 +291,27 @@ def test_device_resident_io(engine, rnd):
     torch.cuda.synchronize()
     engine.sync()
     assert (dev.cpu().numpy() == host).all() and not st.cpu().numpy().any()
+
+
+def test_checked_decompress(engine, rnd):
+    """from_bytes (src/lib.rs:140-146, 246-252) in batch: valid, infinity, off-curve, out-of-subgroup."""
+    import c_oracle
+    g1 = [o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)) for _ in range(66)] + [None]
+    g2 = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(66)] + [None]
+    c1 = np.stack([u8(o.g1_compressed(p)) for p in g1])
+    c2 = np.stack([u8(o.g2_compressed(p)) for p in g2])
+    while True:
+        P0 = o.g2_get_point_from_x((rnd.randrange(o.Q), rnd.randrange(o.Q)), False)
+        if P0 is not None:
+            break
+    c2[3] = u8(o.g2_compressed(P0))        # on the twist, outside G2
+    c2[4, 0] &= 0x7F                        # compression flag missing
+    c1[5, 47] ^= 1                          # off the curve or outside G1 (checked against Oracle B)
+    out1, st1 = engine.g1_decompress(c1)
+    out2, st2 = engine.g2_decompress(c2)
+    want1 = [0] * 67
+    want1[5] = c_oracle.g1_decompress(bytes(c1[5]))[0]
+    assert st1.tolist() == want1 and st1[5] == 3
+    assert st2.tolist() == [0, 0, 0, 3, 3] + [0] * 62
+    for j in (0, 1, 2, 6, 40, 66):
+        assert bytes(out1[j]) == o.g1_uncompressed(g1[j]) and bytes(out2[j]) == o.g2_uncompressed(g2[j])

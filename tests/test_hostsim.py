@@ -229,3 +229,35 @@ print("BOUNDS-OK")
 ''' % (os.path.join(os.path.dirname(HERE), "oracle"), lib)
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BOUNDS-OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_checked_decompress(L, rnd):
+    """Compressed decode with on-curve + subgroup checks (psi test for G2, [r]P for G1)."""
+    for _ in range(3):
+        P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        out = buf(96)
+        assert L.hs_decompress_g1(o.g1_compressed(P), out) == 0 and out.raw == o.g1_uncompressed(P)
+        Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+        out = buf(192)
+        assert L.hs_decompress_g2(o.g2_compressed(Q2), out) == 0 and out.raw == o.g2_uncompressed(Q2)
+    out = buf(192)
+    assert L.hs_decompress_g2(o.g2_compressed(None), out) == 0 and out.raw == o.g2_uncompressed(None)
+    n = 0
+    while n < 3:  # on the twist, not in G2: the psi membership test must reject
+        P0 = o.g2_get_point_from_x((rnd.randrange(o.Q), rnd.randrange(o.Q)), bool(n & 1))
+        if P0 is None:
+            continue
+        assert L.hs_decompress_g2(o.g2_compressed(P0), buf(192)) == 3
+        n += 1
+    n = 0
+    while n < 2:  # on E(Fq), not in G1
+        x = rnd.randrange(o.Q)
+        rhs = (x ** 3 + 4) % o.Q
+        y = pow(rhs, (o.Q + 1) // 4, o.Q)
+        if y * y % o.Q != rhs or o.E1.mul((x, y), o.R) is None:
+            continue
+        assert L.hs_decompress_g1(o.g1_compressed((x, y)), buf(96)) == 3
+        n += 1
+    bad = bytearray(o.g2_compressed(o.G2_GEN))
+    bad[0] &= 0x7f
+    assert L.hs_decompress_g2(bytes(bad), buf(192)) == 3

@@ -173,3 +173,26 @@ def test_ref_test_simple_sig_and_enc(rnd):
     z = bytes(20)
     assert xor(o.xor_with_hash(g0, z), o.xor_with_hash(g0, b"\x55" * 20)) == b"\x55" * 20
     assert o.xor_with_hash(g0, z) != o.xor_with_hash(g1, z) and len(o.xor_with_hash(g0, bytes(5))) == 5
+
+
+def test_checked_decompress_both_oracles(rnd):
+    """from_bytes (src/lib.rs:140-146, 246-252): valid points round-trip; off-curve x, points outside
+    the order-r subgroup and bad flags are FromBytesError::Invalid."""
+    for _ in range(3):
+        P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+        assert c.g1_decompress(o.g1_compressed(P)) == (0, o.g1_uncompressed(P))
+        assert c.g2_decompress(o.g2_compressed(Q2)) == (0, o.g2_uncompressed(Q2))
+    assert c.g1_decompress(o.g1_compressed(None)) == (0, o.g1_uncompressed(None))
+    assert c.g2_decompress(o.g2_compressed(None)) == (0, o.g2_uncompressed(None))
+    while True:  # a point of E'(Fq2) outside G2
+        P0 = o.g2_get_point_from_x((rnd.randrange(o.Q), rnd.randrange(o.Q)), False)
+        if P0 is not None:
+            break
+    assert o.E2.mul(P0, o.R) is not None
+    assert c.g2_decompress(o.g2_compressed(P0))[0] == 3
+    with pytest.raises(o.DecodeError):
+        o.g2_from_compressed(o.g2_compressed(P0))
+    bad = bytearray(o.g1_compressed(o.G1_GEN))
+    bad[0] &= 0x7f
+    assert c.g1_decompress(bytes(bad))[0] == 3

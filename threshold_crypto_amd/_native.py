@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtc_amd.so")
+LIB_PATH = os.environ.get("TC_AMD_LIB") or os.path.join(_HERE, "libtc_amd.so")  # TC_AMD_LIB: experiment builds
 
 TC_OK = 0
 TC_ERR_INVALID_ARG = -1
@@ -44,6 +44,8 @@ PROTOTYPES = {
     "tc_verify_decryption_share_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p],
     "tc_g1_compress_batch": [_u8p, _sz, _u8p, _u8p],
     "tc_g2_compress_batch": [_u8p, _sz, _u8p, _u8p],
+    "tc_g1_decompress_batch": [_u8p, _sz, _u8p, _u8p],
+    "tc_g2_decompress_batch": [_u8p, _sz, _u8p, _u8p],
 }
 
 CONTEXT_SYMBOLS = ["tc_ctx_create", "tc_ctx_destroy", "tc_ctx_set_device_io", "tc_ctx_set_stream", "tc_sync",

@@ -115,8 +115,23 @@ class _G2Value(_G1Value):
         return bytes(out[0])
 
 
+def _from_bytes(cls, data, size, fn_name):
+    data = bytes(data)
+    if len(data) != size:
+        raise FromBytesError("expected %d bytes" % size)
+    out, st = getattr(default_engine(), fn_name)(_u8(data)[None])
+    if int(st[0]):
+        raise FromBytesError("invalid encoding")
+    return cls(out[0])
+
+
 class Signature(_G2Value):
     """struct Signature(G2) (src/lib.rs:202)."""
+
+    @classmethod
+    def from_bytes(cls, data):
+        """Signature::from_bytes (src/lib.rs:246-252): checked decode of the 96-byte form."""
+        return _from_bytes(cls, data, SIG_SIZE, "g2_decompress")
 
     def parity(self):
         """Signature::parity (src/lib.rs:237-243): xor-fold of the uncompressed bytes."""
@@ -153,6 +168,11 @@ class Ciphertext:
 
 class PublicKey(_G1Value):
     """struct PublicKey(G1) (src/lib.rs:79)."""
+
+    @classmethod
+    def from_bytes(cls, data):
+        """PublicKey::from_bytes (src/lib.rs:140-146): checked decode of the 48-byte form."""
+        return _from_bytes(cls, data, PK_SIZE, "g1_decompress")
 
     def verify_g2(self, sig, hash_g2_point):
         """PublicKey::verify_g2 (src/lib.rs:108-110)."""

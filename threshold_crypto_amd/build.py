@@ -18,10 +18,13 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "libtc_amd.so")
+# experiments: TC_BUILD_FLAGS="-DTC_INLINE_JAC" TC_BUILD_SUFFIX="_inl" builds libtc_amd_inl.so
+EXTRA_FLAGS = os.environ.get("TC_BUILD_FLAGS", "").split()
+SUFFIX = os.environ.get("TC_BUILD_SUFFIX", "")
+LIB = os.path.join(HERE, "libtc_amd%s.so" % SUFFIX)
 UNITS = ["tc_api", "k_mul", "k_combine", "k_pairing", "k_hash"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wno-unused-result"] + EXTRA_FLAGS
 
 
 def _hipcc():
@@ -66,7 +69,7 @@ def build(force=False, jobs=None, timeout=1500, verbose=True):
     os.makedirs(BUILD, exist_ok=True)
     base = _headers_digest()
     keys = {u: _unit_key(u, base) for u in UNITS}
-    stamp = os.path.join(BUILD, "lib.stamp")
+    stamp = os.path.join(BUILD, "lib%s.stamp" % SUFFIX)
     want = " ".join(keys[u] for u in UNITS)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == want:
         return LIB
@@ -83,11 +86,12 @@ def build(force=False, jobs=None, timeout=1500, verbose=True):
     os.replace(LIB + ".tmp", LIB)
     with open(stamp, "w") as f:
         f.write(want)
-    # drop stale objects
-    keep = {os.path.basename(o) for o in objs.values()}
-    for name in os.listdir(BUILD):
-        if name.endswith(".o") and name not in keep:
-            os.remove(os.path.join(BUILD, name))
+    # drop stale objects (default build only; experiment builds share the directory)
+    if not SUFFIX:
+        keep = {os.path.basename(o) for o in objs.values()}
+        for name in os.listdir(BUILD):
+            if name.endswith(".o") and name not in keep and os.path.getmtime(os.path.join(BUILD, name)) < time.time() - 86400:
+                os.remove(os.path.join(BUILD, name))
     if verbose:
         print("[tc build] linked", LIB, flush=True)
     return LIB

@@ -28,6 +28,15 @@ __global__ __launch_bounds__(kBlock) void k_compress(const uint8_t* __restrict__
   if (status) status[j] = st;
 }
 
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_decompress(const uint8_t* __restrict__ in, size_t B,
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  uint8_t st = job_decompress<F>(in + j * PointIO<F>::CBYTES, out + j * PointIO<F>::BYTES);
+  if (status) status[j] = st;
+}
+
 __global__ void k_fill_g1_generator(uint8_t* out96) {
   if (threadIdx.x == 0 && blockIdx.x == 0) g1_encode_uncompressed(g1_generator(), out96);
 }
@@ -45,6 +54,12 @@ void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* ou
 }
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_compress<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
+}
+void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_decompress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
+}
+void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_fill_g1_generator(hipStream_t st, uint8_t* out96) {
   hipLaunchKernelGGL(k_fill_g1_generator, dim3(1), dim3(64), 0, st, out96);

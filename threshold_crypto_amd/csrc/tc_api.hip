@@ -572,4 +572,30 @@ int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* o
   return k.finish();
 }
 
+int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status) {
+  TC_REQUIRE(ctx && in48 && out96);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  const uint8_t* d_in = k.in(in48, B * 48);
+  uint8_t* d_out = k.out(out96, B * 96);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_g1_decompress(ctx->stream, d_in, B, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out192, uint8_t* status) {
+  TC_REQUIRE(ctx && in96 && out192);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  const uint8_t* d_in = k.in(in96, B * 96);
+  uint8_t* d_out = k.out(out192, B * 192);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_g2_decompress(ctx->stream, d_in, B, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
 }  // extern "C"

@@ -22,6 +22,14 @@
 #define TC_CONST static constexpr
 #endif
 
+// Jacobian point operations: real functions by default (code size, compile time); -DTC_INLINE_JAC
+// inlines them into the scalar-multiplication loops so the accumulator stays in registers.
+#if defined(TC_INLINE_JAC)
+#define TC_JAC_ATTR TC_HD
+#else
+#define TC_JAC_ATTR TC_HD_NOINLINE
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TC_UNROLL _Pragma("unroll")
 #define TC_NOUNROLL _Pragma("nounroll")

@@ -35,7 +35,7 @@ struct Jac {
 
 // dbl-2009-l (a = 0): 2M + 5S.  Doubling the identity (z = 0) yields z3 = 0 again.
 template <class F>
-TC_HD_NOINLINE Jac<F> jac_dbl(const Jac<F>& p) {
+TC_JAC_ATTR Jac<F> jac_dbl(const Jac<F>& p) {
   F a = p.x.sqr();
   F b = p.y.sqr();
   F c = b.sqr();
@@ -52,7 +52,7 @@ TC_HD_NOINLINE Jac<F> jac_dbl(const Jac<F>& p) {
 
 // madd-2007-bl with the exceptional cases handled (p = inf, q = inf, p = +-q).
 template <class F>
-TC_HD_NOINLINE Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
+TC_JAC_ATTR Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
   if (q.inf) return p;
   F z1z1 = p.z.sqr();
   F u2 = q.x * z1z1;
@@ -80,7 +80,7 @@ TC_HD_NOINLINE Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
 
 // add-2007-bl with the exceptional cases handled.
 template <class F>
-TC_HD_NOINLINE Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   const bool p_inf = p.is_inf();
   const bool q_inf = q.is_inf();
   F z1z1 = p.z.sqr();

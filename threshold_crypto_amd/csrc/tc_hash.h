@@ -6,6 +6,7 @@
 #pragma once
 #include "tc_codec.h"
 #include "tc_gls.h"
+#include "tc_sqrt.h"
 
 namespace tc {
 
@@ -132,27 +133,6 @@ TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
     ok = limbs_lt_p<FqParams>(w);
   }
   return Fq::from_mont384(w);
-}
-
-// Square root in Fq2 (q = 3 mod 4), Algorithm 9 of eprint 2012/685.  false for non-squares.
-TC_HD_NOINLINE bool fq2_sqrt(const Fq2& a, Fq2& out) {
-  if (a.is_zero()) {
-    out = Fq2::zero();
-    return true;
-  }
-  const Fq2 minus_one = -Fq2::one();
-  Fq2 a1 = field_pow_fixed(a, [](int i) { return FQ_P_MINUS_3_DIV_4[i]; }, 379);
-  Fq2 alpha = a1.sqr() * a;
-  Fq2 a0 = alpha.conj() * alpha;
-  if (a0 == minus_one) return false;
-  a1 = a1 * a;
-  if (alpha == minus_one) {
-    out = Fq2{-a1.c1, a1.c0};  // times u
-    return true;
-  }
-  Fq2 b = field_pow_fixed(alpha + Fq2::one(), [](int i) { return FQ_P_MINUS_1_DIV_2[i]; }, 380);
-  out = b * a1;
-  return true;
 }
 
 // G2Affine::get_point_from_x(x, greatest) of pairing 0.16

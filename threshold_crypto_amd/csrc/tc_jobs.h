@@ -233,4 +233,25 @@ TC_HD uint8_t job_compress<Fq2>(const uint8_t* in, uint8_t* out) {
   return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
 }
 
+// compressed -> uncompressed with the reference's CHECKED decode (from_bytes,
+// src/lib.rs:140-146, 246-252): on the curve and in the order-r subgroup, else Invalid
+template <class F>
+TC_HD uint8_t job_decompress(const uint8_t* in, uint8_t* out);
+template <>
+TC_HD uint8_t job_decompress<Fq>(const uint8_t* in, uint8_t* out) {
+  G1Affine p;
+  bool ok = g1_decode_compressed(in, p);
+  if (!ok) p = G1Affine::infinity();
+  g1_encode_uncompressed(p, out);
+  return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+}
+template <>
+TC_HD uint8_t job_decompress<Fq2>(const uint8_t* in, uint8_t* out) {
+  G2Affine p;
+  bool ok = g2_decode_compressed(in, p);
+  if (!ok) p = G2Affine::infinity();
+  g2_encode_uncompressed(p, out);
+  return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+}
+
 }  // namespace tc

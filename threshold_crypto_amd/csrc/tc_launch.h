@@ -17,6 +17,8 @@ void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t
                    uint8_t* status);
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
+void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
+void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
                      uint8_t* status, bool g2);

@@ -1,0 +1,107 @@
+// Square roots in Fq and Fq2 (q = 3 mod 4), compressed-point decoding and subgroup checks.
+//   * hash_g2 needs "is x^3 + b a square, and a root of it" (G2Affine::get_point_from_x of
+//     pairing 0.16; /root/reference/src/lib.rs:693);
+//   * from_bytes (/root/reference/src/lib.rs:140-146, 246-252) needs the checked decode of the
+//     48 / 96-byte compressed forms: on-curve AND in the order-r subgroup.
+// The reference's Fq2::sqrt is Algorithm 9 of eprint 2012/685 (two Fq2 exponentiations).  Which
+// root comes out is not observable -- callers re-select by lexicographic order -- so the device
+// takes roots through the norm instead: three Fq exponentiations at most, and a non-square is
+// rejected after ONE of them (that is the common case inside hash_g2's retry loop).
+#pragma once
+#include "tc_codec.h"
+#include "tc_gls.h"
+
+namespace tc {
+
+// a^((q-3)/4).  For a square a != 0:  a * w is a square root of a and w = 1 / (a * w).
+TC_HD_NOINLINE Fq fq_pow_qm3d4(const Fq& a) {
+  return field_pow_fixed(a.norm(), [](int i) { return FQ_P_MINUS_3_DIV_4[i]; }, 379);
+}
+
+// root of a in Fq; false if a is not a square.  inv_root (optional) receives 1/root.
+TC_HD bool fq_sqrt(const Fq& a, Fq& root, Fq* inv_root = nullptr) {
+  Fq w = fq_pow_qm3d4(a);
+  root = w * a;
+  if (inv_root) *inv_root = w;
+  return root.sqr() == a;
+}
+
+TC_HD Fq fq_half(const Fq& a) { return a * Fq::from_limbs(FQ26_INV2); }
+
+// root of a in Fq2; false if a is not a square
+TC_HD_NOINLINE bool fq2_sqrt(const Fq2& a, Fq2& out) {
+  if (a.c1.is_zero()) {
+    // a = a0 in Fq: exactly one of a0, -a0 is a square in Fq (-1 is a non-residue)
+    Fq s;
+    if (fq_sqrt(a.c0, s)) out = Fq2{s, Fq::zero()};
+    else out = Fq2{Fq::zero(), s};  // s^2 = -a0, (s u)^2 = a0
+    return true;
+  }
+  const Fq norm = a.c0.sqr() + a.c1.sqr();
+  Fq n;
+  if (!fq_sqrt(norm, n)) return false;  // a is a square in Fq2 iff its norm is one in Fq
+  Fq delta = fq_half(a.c0 + n);
+  Fq x0, x0inv;
+  if (!fq_sqrt(delta, x0, &x0inv)) {
+    delta = (delta - n).norm();  // (a0 - n) / 2: exactly one of the two is a square (a1 != 0)
+    fq_sqrt(delta, x0, &x0inv);
+  }
+  out = Fq2{x0, fq_half(a.c1 * x0inv)};
+  return true;
+}
+
+// [r] P == infinity by the plain ladder (r is wave-uniform).  Used for G1.
+TC_HD bool g1_in_subgroup(const G1Affine& p) {
+  if (p.inf) return true;
+  G1Jac acc = jac_mul_affine_uniform(p, [](int i) { return FR_P[i]; }, 255);
+  return acc.is_inf();
+}
+
+// P in G2  <=>  psi(P) = [x] P   (M. Scott, "A note on group membership tests for G1, G2 and GT
+// on BLS pairing-friendly curves", 2021): one 64-bit ladder instead of a 255-bit one.
+TC_HD bool g2_in_subgroup(const G2Affine& p) {
+  if (p.inf) return true;
+  G2Jac xp = g2_mul_by_x_abs(G2Jac::from_affine(p));  // [|x|] P = -[x] P
+  return jac_add_mixed(xp, g2_psi(p)).is_inf();        // psi(P) + [|x|] P == 0
+}
+
+// ---- checked decode of the compressed forms (EncodedPoint::into_affine) ------------------------
+TC_HD bool g1_decode_compressed(const uint8_t* b, G1Affine& p) {
+  const uint8_t f = b[0];
+  if (!(f & 0x80)) return false;
+  if (f & 0x40) {
+    uint32_t o = f & 0x3f;
+    for (int i = 1; i < 48; i++) o |= b[i];
+    p = G1Affine::infinity();
+    return o == 0;
+  }
+  Fq x, y;
+  if (!fq_from_be48(b, true, x)) return false;
+  if (!fq_sqrt(x.sqr() * x + g1_b(), y)) return false;
+  const bool greatest = (f & 0x20) != 0;
+  if (fq_lex_largest(y) != greatest) y = -y;
+  p = G1Affine{x, y.norm(), false};
+  return g1_in_subgroup(p);
+}
+
+TC_HD bool g2_decode_compressed(const uint8_t* b, G2Affine& p) {
+  const uint8_t f = b[0];
+  if (!(f & 0x80)) return false;
+  if (f & 0x40) {
+    uint32_t o = f & 0x3f;
+    for (int i = 1; i < 96; i++) o |= b[i];
+    p = G2Affine::infinity();
+    return o == 0;
+  }
+  Fq2 x, y;
+  bool ok = fq_from_be48(b, true, x.c1);
+  ok &= fq_from_be48(b + 48, false, x.c0);
+  if (!ok) return false;
+  if (!fq2_sqrt(x.sqr() * x + g2_b(), y)) return false;
+  const bool greatest = (f & 0x20) != 0;
+  if (fq2_lex_largest(y) != greatest) y = -y;
+  p = G2Affine{x, y.norm(), false};
+  return g2_in_subgroup(p);
+}
+
+}  // namespace tc

@@ -269,3 +269,20 @@ class Engine:
         st = self._empty(dev, (B,), ref=pts)
         self._call("tc_g2_compress_batch", _ptr(pts), B, _ptr(out), _ptr(st))
         return out, st
+
+    def g1_decompress(self, comp):
+        """checked decode of 48-byte compressed G1 (from_bytes): status 3 = invalid"""
+        dev = self._mode(comp)
+        B = comp.shape[0]
+        out = self._empty(dev, (B, G1_BYTES), ref=comp)
+        st = self._empty(dev, (B,), ref=comp)
+        self._call("tc_g1_decompress_batch", _ptr(comp), B, _ptr(out), _ptr(st))
+        return out, st
+
+    def g2_decompress(self, comp):
+        dev = self._mode(comp)
+        B = comp.shape[0]
+        out = self._empty(dev, (B, G2_BYTES), ref=comp)
+        st = self._empty(dev, (B,), ref=comp)
+        self._call("tc_g2_decompress_batch", _ptr(comp), B, _ptr(out), _ptr(st))
+        return out, st
