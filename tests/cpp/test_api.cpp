@@ -1,0 +1,105 @@
+// Replays test_threshold_sig / test_threshold_enc / test_from_to_bytes of the reference
+// (src/lib.rs:822-873, 907-939, 984-993) through the C++ host mirror include/threshold_crypto.hpp.
+// Built and run by tests/test_gpu_cpp_api.py on the GPU box; key material and expected values come
+// from a fixture file the Python test writes with the oracle.
+//   fixture: u32 t, u32 n | n x 32 B share scalars | (t+1) x 96 B commitment | u32 msg_len, msg |
+//            192 B expected combined signature | ciphertext: 96 B u, u32 vlen, v, 192 B w | u32 plen, plaintext
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include "threshold_crypto.hpp"
+
+using namespace threshold_crypto;
+
+#define CHECK(c)                                                        \
+  do {                                                                  \
+    if (!(c)) {                                                         \
+      std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); \
+      std::exit(1);                                                     \
+    }                                                                   \
+  } while (0)
+
+template <class T>
+static void rd(std::ifstream& f, T* p, std::size_t n) {
+  f.read(reinterpret_cast<char*>(p), (std::streamsize)n);
+  if (!f) { std::fprintf(stderr, "short fixture\n"); std::exit(2); }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  std::ifstream f(argv[1], std::ios::binary);
+  std::uint32_t t, n, len;
+  rd(f, &t, 4); rd(f, &n, 4);
+  std::vector<SecretKeyShare> shares;
+  for (std::uint32_t i = 0; i < n; i++) { FrBytes fr; rd(f, fr.data(), 32); shares.emplace_back(fr); }
+  std::vector<G1Bytes> commit(t + 1);
+  for (auto& c : commit) rd(f, c.data(), 96);
+  rd(f, &len, 4); std::string msg(len, '\0'); rd(f, &msg[0], len);
+  Signature expected; rd(f, expected.g2.data(), 192);
+  Ciphertext ct; rd(f, ct.u.data(), 96); rd(f, &len, 4); ct.v.resize(len); rd(f, ct.v.data(), len); rd(f, ct.w.data(), 192);
+  rd(f, &len, 4); Bytes plain(len); rd(f, plain.data(), len);
+
+  PublicKeySet pk_set(commit);
+  CHECK(pk_set.threshold() == t);
+
+  // -- test_threshold_sig ----------------------------------------------------------------------
+  std::map<std::uint64_t, SignatureShare> sigs;
+  for (std::uint64_t i : {5, 8, 7, 10}) {
+    sigs[i] = shares[i].sign(msg);
+    CHECK(pk_set.public_key_share(i).verify(sigs[i], msg));
+    CHECK(pk_set.public_key_share(i).pk == shares[i].public_key_share().pk);
+  }
+  Signature sig = pk_set.combine_signatures(sigs);
+  CHECK(sig == expected);
+  CHECK(pk_set.public_key().verify(sig, msg));
+  CHECK(!pk_set.public_key().verify(sig, msg + "!"));
+  std::map<std::uint64_t, SignatureShare> sigs2;
+  for (std::uint64_t i : {1, 2, 3, 4}) sigs2[i] = shares[i].sign(msg);
+  CHECK(pk_set.combine_signatures(sigs2) == sig);
+  sigs.erase(10);
+  bool threw = false;
+  try { pk_set.combine_signatures(sigs); } catch (const ErrorException& e) { threw = e.code == Error::NotEnoughShares; }
+  CHECK(threw);
+  // batch form: S signers x B messages, then B combines in one launch
+  Messages m;
+  for (int j = 0; j < 70; j++) m.push(msg + std::to_string(j));
+  std::vector<const SecretKeyShare*> signers;
+  for (std::uint32_t i = 0; i < n; i++) signers.push_back(&shares[i]);
+  auto all = sign_shares_batch(signers, m);
+  std::vector<std::map<std::uint64_t, SignatureShare>> jobs(m.size());
+  for (std::size_t j = 0; j < m.size(); j++)
+    for (std::uint64_t i : {0 + j % 3, 4 + j % 2, 6ul, 9ul}) jobs[j][i] = all[j][i];
+  std::vector<std::uint8_t> st;
+  auto combined = pk_set.combine_signatures_batch(jobs, st);
+  for (auto s : st) CHECK(s == 0);
+  auto ok = pk_set.public_key().verify_batch(combined, m);
+  for (bool b : ok) CHECK(b);
+
+  // -- test_from_to_bytes -----------------------------------------------------------------------
+  CHECK(Signature::from_bytes(sig.to_bytes()) == sig);
+  CHECK(PublicKey::from_bytes(pk_set.public_key().to_bytes()) == pk_set.public_key());
+  auto bad = sig.to_bytes();
+  bad[0] &= 0x7f;
+  threw = false;
+  try { Signature::from_bytes(bad); } catch (const FromBytesError&) { threw = true; }
+  CHECK(threw);
+  CHECK(hash_g2(msg) == hash_g2(msg) && hash_g2(msg) != hash_g2(msg + "x"));
+
+  // -- test_threshold_enc -------------------------------------------------------------------------
+  CHECK(ct.verify());
+  std::map<std::uint64_t, DecryptionShare> dsh;
+  for (std::uint64_t i : {8, 4, 7, 9}) {
+    auto d = shares[i].decrypt_share(ct);
+    CHECK(d.has_value());
+    CHECK(pk_set.public_key_share(i).verify_decryption_share(*d, ct));
+    dsh[i] = *d;
+  }
+  CHECK(pk_set.decrypt(dsh, ct) == plain);
+  Ciphertext fake = ct;
+  fake.v[0] ^= 1;
+  CHECK(!fake.verify());
+  CHECK(!shares[2].decrypt_share(fake).has_value());
+  std::puts("CPP-API-OK");
+  return 0;
+}

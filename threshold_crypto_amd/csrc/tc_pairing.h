@@ -17,7 +17,7 @@ struct LineCoeffs {
 };
 
 // Algorithm 26 of eprint 2010/354 (Jacobian doubling + tangent line), a = 0.
-TC_HD_NOINLINE LineCoeffs miller_doubling_step(G2Jac& r) {
+TC_MILLER_ATTR LineCoeffs miller_doubling_step(G2Jac& r) {
   Fq2 tmp0 = r.x.sqr();
   Fq2 tmp1 = r.y.sqr();
   Fq2 tmp2 = tmp1.sqr();
@@ -40,7 +40,7 @@ TC_HD_NOINLINE LineCoeffs miller_doubling_step(G2Jac& r) {
 }
 
 // Algorithm 27 of eprint 2010/354 (mixed addition + chord line).
-TC_HD_NOINLINE LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
+TC_MILLER_ATTR LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
   Fq2 zsq = r.z.sqr();
   Fq2 ysq = q.y.sqr();
   Fq2 t0 = zsq * q.x;
