@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--signers", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (hashing verify, threshold decryption)")
     args = ap.parse_args()
 
     import numpy as np
@@ -129,6 +130,48 @@ def main():
     sync()
     assert bool((msig[:, 0] == sig).all().item()), "combine != master-key signature"
 
+    # ---- secondary legs: verify incl. hashing (config 3 with hash on device), config 4 ------------
+    extras = {}
+    if not args.no_extras:
+        d_msgs = torch.from_numpy(wl.msg_flat).to(dev)
+        d_off = torch.from_numpy(wl.msg_off.view(np.int64)).to(dev)
+        ok = eng.verify_sig(master_pk, sig, d_msgs, d_off)
+        sync()
+        e0 = time.perf_counter()
+        ok = eng.verify_sig(master_pk, sig, d_msgs, d_off)
+        sync()
+        extras["verifies_with_hash_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
+        assert int(ok.to(torch.int32).sum().item()) == B
+        e0 = time.perf_counter()
+        hh = eng.hash_g2(d_msgs, d_off)
+        extras["hash_g2_kernel_ms"] = round(eng.last_kernel_ms(), 3)
+        sync()
+        extras["hash_g2_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
+        assert bool((hh == d_hashes).all().item())
+        from threshold_crypto_amd.workload import ThresholdEncWorkload
+        we = ThresholdEncWorkload(eng, t, N, B, start=start)
+        du, dv, dw = torch.from_numpy(we.u).to(dev), torch.from_numpy(we.v).to(dev), torch.from_numpy(we.w).to(dev)
+        doff = torch.from_numpy(we.off.view(np.int64)).to(dev)
+        didx, dsh = torch.from_numpy(we.idx.view(np.int64)).to(dev), torch.from_numpy(we.shares).to(dev)
+        okc = eng.ciphertext_verify(du, dv, doff, dw)
+        out, dst = eng.decrypt(t, didx, dsh, dv, doff)
+        sync()
+        e0 = time.perf_counter()
+        okc = eng.ciphertext_verify(du, dv, doff, dw)
+        extras["ciphertext_verify_kernel_ms"] = round(eng.last_kernel_ms(), 3)
+        sync()
+        e1 = time.perf_counter()
+        out, dst = eng.decrypt(t, didx, dsh, dv, doff)
+        extras["threshold_decrypt_kernel_ms"] = round(eng.last_kernel_ms(), 3)
+        sync()
+        e2 = time.perf_counter()
+        extras["ciphertext_verifies_per_s"] = round(B * world / (e1 - e0), 1)
+        extras["threshold_decrypts_per_s"] = round(B * world / (e2 - e1), 1)
+        extras["threshold_decryptions_incl_ciphertext_verify_per_s"] = round(B * world / (e2 - e0), 1)
+        assert int(okc.to(torch.int32).sum().item()) == B and int(dst.to(torch.int32).sum().item()) == 0
+        assert bytes(out.cpu().numpy()[: 32 * 64]) == b"".join(we.plain[:64]), "threshold decryption returned wrong plaintext"
+        assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item())
+
     result = None
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
@@ -166,6 +209,7 @@ def main():
             "share_signs_per_s": round((t + 1) * B * world / sign_dt, 1),
             "share_sign_kernel_ms": round(sign_kernel_ms, 3),
             "verified_all": True,
+            "extras": extras,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -191,3 +191,22 @@ def test_full_batch_properties(engine, rnd):
     rows = np.arange(512)[:, None]
     sig2, st2 = engine.combine_g2(t, np.ascontiguousarray(idx2[:512]), np.ascontiguousarray(allsh[rows, idx2[:512].astype(np.int64)]))
     assert not st2.any() and (sig2 == sig[:512]).all()
+
+
+def test_encryption_workload_matches_oracle_and_decrypts(engine):
+    """The threshold-encryption workload (encrypt_with_rng composed from batch entry points,
+    src/lib.rs:128-137) equals the oracle's ciphertexts; ciphertexts verify; threshold decryption
+    returns the plaintexts."""
+    from threshold_crypto_amd.workload import ThresholdEncWorkload, _sha3_scalars, SEED
+    t, N, B = 3, 10, 70
+    we = ThresholdEncWorkload(engine, t, N, B)
+    pk = o.g1_from_uncompressed(bytes(we.master_pk), check=False)
+    rs = _sha3_scalars(b"tc/enc", B, SEED)
+    for j in (0, 1, 69):
+        r = int.from_bytes(bytes(rs[j]), "little")
+        u, v, w = o.encrypt_with_r(pk, r, we.plain[j])
+        assert bytes(we.u[j]) == o.g1_uncompressed(u) and bytes(we.w[j]) == o.g2_uncompressed(w)
+        assert bytes(we.v[32 * j: 32 * j + 32]) == v
+    assert engine.ciphertext_verify(we.u, we.v, we.off, we.w).all()
+    out, st = engine.decrypt(t, we.idx, we.shares, we.v, we.off)
+    assert not st.any() and bytes(out[: 32 * B]) == b"".join(we.plain)

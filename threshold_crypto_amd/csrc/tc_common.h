@@ -30,6 +30,15 @@
 #else
 #define TC_JAC_ATTR TC_HD
 #endif
+// Fq6 routines: real functions by default; -DTC_INLINE_FQ6 inlines them into the Fq12 routines
+// (one level less of by-reference operand traffic) and drops their intermediate reductions.
+#if defined(TC_INLINE_FQ6)
+#define TC_FQ6_ATTR TC_HD
+#define TC_FQ6_OUT(x) (x).norm()
+#else
+#define TC_FQ6_ATTR TC_HD_NOINLINE
+#define TC_FQ6_OUT(x) (x).reduce_value()
+#endif
 // Miller-loop doubling / addition steps: same switch (-DTC_INLINE_MILLER).
 #if defined(TC_INLINE_MILLER)
 #define TC_MILLER_ATTR TC_HD

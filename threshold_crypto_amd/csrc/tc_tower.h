@@ -54,7 +54,7 @@ struct Fq6 {
   TC_HD Fq6 operator-() const { return Fq6{-c0, -c1, -c2}; }
   TC_HD Fq6 norm() const { return Fq6{c0.norm(), c1.norm(), c2.norm()}; }
   TC_HD Fq6 reduce_value() const { return Fq6{c0.reduce_value(), c1.reduce_value(), c2.reduce_value()}; }
-  TC_HD_NOINLINE Fq6 operator*(const Fq6& b) const {
+  TC_FQ6_ATTR Fq6 operator*(const Fq6& b) const {
     Fq2 t0 = c0 * b.c0;
     Fq2 t1 = c1 * b.c1;
     Fq2 t2 = c2 * b.c2;
@@ -62,10 +62,10 @@ struct Fq6 {
     r.c0 = t0 + ((c1 + c2) * (b.c1 + b.c2) - t1 - t2).mul_xi();
     r.c1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1 + t2.mul_xi();
     r.c2 = (c0 + c2) * (b.c0 + b.c2) - t0 - t2 + t1;
-    return r.reduce_value();
+    return TC_FQ6_OUT(r);
   }
   // CH-SQR2 (Chung-Hasan): 2 mul + 3 sqr in Fq2
-  TC_HD_NOINLINE Fq6 sqr() const {
+  TC_FQ6_ATTR Fq6 sqr() const {
     Fq2 s0 = c0.sqr();
     Fq2 ab = c0 * c1;
     Fq2 s1 = ab.dbl();
@@ -77,21 +77,21 @@ struct Fq6 {
     r.c0 = s0 + s3.mul_xi();
     r.c1 = s1 + s4.mul_xi();
     r.c2 = s1 + s2 + s3 - s0 - s4;
-    return r.reduce_value();
+    return TC_FQ6_OUT(r);
   }
   TC_HD Fq6 mul_by_v() const { return Fq6{c2.mul_xi(), c0, c1}; }
   // sparse: times (b0 + b1 v)
-  TC_HD_NOINLINE Fq6 mul_by_01(const Fq2& b0, const Fq2& b1) const {
+  TC_FQ6_ATTR Fq6 mul_by_01(const Fq2& b0, const Fq2& b1) const {
     Fq2 aa = c0 * b0;
     Fq2 bb = c1 * b1;
     Fq6 r;
     r.c0 = ((c1 + c2) * b1 - bb).mul_xi() + aa;
     r.c1 = (c0 + c1) * (b0 + b1) - aa - bb;
     r.c2 = (c0 + c2) * b0 - aa + bb;
-    return r.reduce_value();
+    return TC_FQ6_OUT(r);
   }
   // sparse: times (b1 v)
-  TC_HD_NOINLINE Fq6 mul_by_1(const Fq2& b1) const { return Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1}.reduce_value(); }
+  TC_FQ6_ATTR Fq6 mul_by_1(const Fq2& b1) const { return TC_FQ6_OUT((Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1})); }
   TC_HD_NOINLINE Fq6 inv() const {
     Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
     Fq2 t1 = c2.sqr().mul_xi() - c0 * c1;

@@ -87,3 +87,49 @@ class ThresholdSigWorkload:
 def _g1_gen():
     from .api import _G1_GEN
     return _G1_GEN
+
+
+def _sha3_scalars(tag, B, seed, start=0):
+    out = np.empty((B, 32), dtype=np.uint8)
+    for j in range(B):
+        d = hashlib.sha3_256(tag + seed.to_bytes(8, "little") + (start + j).to_bytes(8, "little")).digest()
+        out[j] = np.frombuffer((int.from_bytes(d, "little") % _R).to_bytes(32, "little"), dtype=np.uint8)
+    return out
+
+
+class ThresholdEncWorkload:
+    """BASELINE config "t, N, batch threshold decryptions": ciphertexts under the master key
+    (PublicKey::encrypt_with_rng, src/lib.rs:128-137, composed from the batch entry points with
+    r_j = LE(SHA3-256("tc/enc" || seed || j)) mod r and 32-byte plaintexts SHA3-256("tc/pt" || j)),
+    and the t+1 selected decryption shares of every job."""
+
+    def __init__(self, engine, t, N, B, seed=SEED, start=0, chunk=16384):
+        self.t, self.N, self.B = t, N, B
+        self.sks = key_set(t, seed)
+        sk_shares = [self.sks.secret_key_share(i) for i in range(N)]
+        fr = np.stack([np.frombuffer(s._bytes(), dtype=np.uint8) for s in sk_shares])
+        g1 = np.frombuffer(_g1_gen(), dtype=np.uint8)
+        pk, _ = engine.g1_mul(np.frombuffer(self.sks.poly[0].to_bytes(32, "little"), dtype=np.uint8)[None].copy(), g1[None].copy())
+        self.master_pk = np.ascontiguousarray(pk[0, 0])
+        r = _sha3_scalars(b"tc/enc", B, seed, start)[:, None, :]                       # (B, 1, 32)
+        self.plain = [hashlib.sha3_256(b"tc/pt" + (start + j).to_bytes(8, "little")).digest() for j in range(B)]
+        pt_flat, off = pack_messages(self.plain)
+        self.off = off
+        tile = lambda p: np.ascontiguousarray(np.broadcast_to(p[None, None, :], (B, 1, p.shape[0])))
+        self.u, st = engine.lincomb_g1(np.ascontiguousarray(r), tile(g1))              # u = r * g1
+        g, st2 = engine.lincomb_g1(np.ascontiguousarray(r), tile(self.master_pk))      # g = r * pk
+        assert not st.any() and not st2.any()
+        self.v, st3 = engine.xor_with_hash(g, pt_flat, off)                            # v = m ^ H(g)
+        h, st4 = engine.hash_g1_g2(self.u, self.v, off)
+        self.w, st5 = engine.lincomb_g2(np.ascontiguousarray(r), np.ascontiguousarray(h[:, None, :]))  # w = r * H(u, v)
+        assert not st3.any() and not st4.any() and not st5.any()
+        self.idx = signer_subsets(B, N, t, seed ^ 0x5EED, start)
+        sel = np.empty((B, t + 1, 96), dtype=np.uint8)
+        for lo in range(0, B, chunk):
+            hi = min(B, lo + chunk)
+            allsh, st6 = engine.g1_mul(fr, np.ascontiguousarray(self.u[lo:hi]))       # (b, N, 96)
+            assert not st6.any()
+            rows = np.arange(hi - lo)[:, None]
+            sel[lo:hi] = allsh[rows, self.idx[lo:hi].astype(np.int64)]
+        self.shares = sel
+        self.plain_flat = pt_flat
