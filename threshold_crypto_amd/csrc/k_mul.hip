@@ -6,8 +6,11 @@ namespace tc {
 
 // One curve op per lane.  Lane order is signer-major (tid = s*B + j) so that the 64 lanes of
 // a wave share the signer's scalar: the bit-serial double-and-add stays wave-uniform.
+#ifndef TC_POINT_MUL_WAVES
+#define TC_POINT_MUL_WAVES 1  // min waves per SIMD the register allocator must leave room for
+#endif
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_point_mul(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts,
+__global__ __launch_bounds__(kBlock, TC_POINT_MUL_WAVES) void k_point_mul(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts,
                                                       size_t S, size_t B, uint8_t* __restrict__ out,
                                                       uint8_t* __restrict__ status) {
   constexpr int PB = PointIO<F>::BYTES;

@@ -121,7 +121,7 @@ struct Fq12 {
     return r.reduce_value();
   }
   // complex squaring over Fq6: 2 Fq6 mul
-  TC_HD_NOINLINE Fq12 sqr() const {
+  TC_FQ12_ATTR Fq12 sqr() const {
     Fq6 ab = c0 * c1;
     Fq6 t = (c0 + c1) * (c0 + c1.mul_by_v()) - ab - ab.mul_by_v();
     return Fq12{t, ab + ab}.reduce_value();
@@ -134,7 +134,7 @@ struct Fq12 {
     return Fq12{c0 * t, -(c1 * t)}.reduce_value();
   }
   // sparse multiplication by (d0 + d1 v) + (d4 v) w -- the Miller-loop line shape
-  TC_HD_NOINLINE Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
+  TC_FQ12_ATTR Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
     Fq6 aa = c0.mul_by_01(d0, d1);
     Fq6 bb = c1.mul_by_1(d4);
     Fq2 o = d1 + d4;
