@@ -261,3 +261,34 @@ def test_checked_decompress(L, rnd):
     bad = bytearray(o.g2_compressed(o.G2_GEN))
     bad[0] &= 0x7f
     assert L.hs_decompress_g2(bytes(bad), buf(192)) == 3
+
+
+def test_g1_glv_and_phi_subgroup_test(L, rnd):
+    """G1 GLV multiplication at the decomposition boundaries, and the phi-based membership test
+    (phi(P) = [-x^2]P, Scott 2021/1130) against points of EVERY prime order dividing the G1
+    cofactor h1 = 3 * (11 * 10177 * 859267 * 52437899)^2, alone and mixed with a G1 point."""
+    x2 = o.BLS_X ** 2
+    for k in [0, 1, x2 - 1, x2, x2 + 1, o.R - 1, rnd.randrange(o.R)]:
+        P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        out = buf(96)
+        assert L.hs_g1_mul(o.fr_to_bytes(k), o.g1_uncompressed(P), out) == 0
+        assert out.raw == o.g1_uncompressed(o.E1.mul(P, k)), hex(k)
+    N = o.H1 * o.R
+
+    def rand_pt():
+        while True:
+            x = rnd.randrange(o.Q)
+            rhs = (x ** 3 + 4) % o.Q
+            y = pow(rhs, (o.Q + 1) // 4, o.Q)
+            if y * y % o.Q == rhs:
+                return (x, y)
+    assert o.H1 == 3 * (11 * 10177 * 859267 * 52437899) ** 2
+    for l in (3, 11, 10177, 859267, 52437899):
+        while True:
+            T = o.E1.mul(rand_pt(), N // l if l == 3 else N // (l * l))   # E(Fq)[l] is not cyclic for l^2 | h1
+            if T is not None:
+                break
+        assert o.E1.mul(T, l) is None
+        assert L.hs_decompress_g1(o.g1_compressed(T), buf(96)) == 3, l
+        M = o.E1.add(T, o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)))
+        assert L.hs_decompress_g1(o.g1_compressed(M), buf(96)) == 3, l

@@ -121,4 +121,61 @@ TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa) {
   return g2_joint_mul4(base, G2_COFACTOR_FIX_DIGITS);
 }
 
+// ---- G1: 2-dimensional GLV through phi(x, y) = (beta x, y) --------------------------------------
+//   on G1:  phi(P) = [-x^2] P,  so with k = k1 + k2 x^2  (k1 = k mod x^2, k2 = k div x^2, both
+//   below 2^128):   [k] P = [k1] P + [k2] (-phi(P)):  one joint 128-bit ladder over {P, -phi P, P - phi P}
+//   instead of the 255-bit one.
+TC_HD G1Affine g1_phi(const G1Affine& p) {
+  if (p.inf) return p;
+  return G1Affine{p.x * Fq::from_limbs(G1_BETA), p.y, false};
+}
+
+typedef unsigned __int128 tc_u128;
+
+// k (8 LE u32 words, < r) -> (k1, k2) with k = k1 + k2 * x^2; binary long division
+TC_HD void glv_decompose(const uint32_t* k, tc_u128* k1, tc_u128* k2) {
+  const tc_u128 X2 = ((tc_u128)BLS_X2_HI << 64) | BLS_X2_LO;
+  tc_u128 rem = 0, q = 0;
+  TC_NOUNROLL for (int bit = 255; bit >= 0; bit--) {
+    const bool top = (rem >> 127) != 0;
+    rem = (rem << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
+    q <<= 1;  // quotient < 2^128 because k < r < x^4
+    if (top || rem >= X2) {
+      rem -= X2;
+      q |= 1;
+    }
+  }
+  *k1 = rem;
+  *k2 = q;
+}
+
+// [k] P for P in G1, k < r
+TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
+  if (p.inf) return G1Jac::infinity();
+  tc_u128 k1, k2;
+  glv_decompose(k, &k1, &k2);
+  G1Affine q = g1_phi(p);
+  q.y = -q.y;  // -phi(P) = [x^2] P
+  const G1Jac pq = jac_add_mixed(G1Jac::from_affine(p), q);
+  G1Jac acc = G1Jac::infinity();
+  TC_NOUNROLL for (int bit = 127; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
+    if (m == 1) acc = jac_add_mixed(acc, p);
+    else if (m == 2) acc = jac_add_mixed(acc, q);
+    else if (m == 3) acc = jac_add(acc, pq);
+  }
+  return acc;
+}
+
+// [|x|] P on G1 by the 64-bit ladder
+TC_HD_NOINLINE G1Jac g1_mul_by_x_abs(const G1Jac& p) {
+  G1Jac acc = p;
+  TC_NOUNROLL for (int bit = 62; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    if ((BLS_X_ABS >> bit) & 1ull) acc = jac_add(acc, p);
+  }
+  return acc;
+}
+
 }  // namespace tc

@@ -28,12 +28,10 @@ struct PointIO<Fq2> {
   TC_HD static void encode(const Affine<Fq2>& p, uint8_t* b) { g2_encode_uncompressed(p, b); }
 };
 
-// [k] p.  G1: the 255-bit double-and-add ladder (wave-uniform scalar => uniform control flow).
-// G2: 4-dimensional GLS through psi (tc_gls.h): 64 doublings instead of 255.  Operands must
-// lie in the prime-order subgroup, as every G1/G2 value the reference holds does.
-TC_HD Jac<Fq> point_mul_scalar(const Affine<Fq>& p, const uint32_t* k) {
-  return jac_mul_affine_uniform(p, [&](int i) { return k[i]; }, 255);
-}
+// [k] p.  G1: 2-dimensional GLV through phi (128 doublings); G2: 4-dimensional GLS through psi
+// (64 doublings) -- tc_gls.h -- instead of the reference's 255-bit ladder.  Operands must lie in
+// the prime-order subgroup, as every G1/G2 value the reference holds does.
+TC_HD Jac<Fq> point_mul_scalar(const Affine<Fq>& p, const uint32_t* k) { return g1_mul_glv(p, k); }
 TC_HD Jac<Fq2> point_mul_scalar(const Affine<Fq2>& p, const uint32_t* k) {
   return g2_mul_gls(G2Jac::from_affine(p), k);
 }

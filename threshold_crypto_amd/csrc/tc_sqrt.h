@@ -50,11 +50,13 @@ TC_HD_NOINLINE bool fq2_sqrt(const Fq2& a, Fq2& out) {
   return true;
 }
 
-// [r] P == infinity by the plain ladder (r is wave-uniform).  Used for G1.
+// P in G1  <=>  phi(P) = [-x^2] P   (M. Scott, eprint 2021/1130, the G1 test for BLS12 curves):
+// two 64-bit ladders instead of the 255-bit [r]P.  tests/ cross-check it against [r]P on points of
+// every prime order dividing the G1 cofactor.
 TC_HD bool g1_in_subgroup(const G1Affine& p) {
   if (p.inf) return true;
-  G1Jac acc = jac_mul_affine_uniform(p, [](int i) { return FR_P[i]; }, 255);
-  return acc.is_inf();
+  G1Jac x2p = g1_mul_by_x_abs(g1_mul_by_x_abs(G1Jac::from_affine(p)));  // [x^2] P
+  return jac_add_mixed(x2p, g1_phi(p)).is_inf();                         // phi(P) + [x^2] P == 0
 }
 
 // P in G2  <=>  psi(P) = [x] P   (M. Scott, "A note on group membership tests for G1, G2 and GT
