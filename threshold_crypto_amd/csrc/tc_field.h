@@ -381,7 +381,7 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
   int32_t m[N];
   int32_t a2[N];
   if (SQUARE) {
-    TC_UNROLL for (int i = 0; i < N; i++) a2[i] = a[i] << 1;
+    TC_UNROLL for (int i = 0; i < N; i++) a2[i] = a[i] * 2;
   }
   int64_t carry = 0;
   TC_UNROLL for (int k = 0; k < 2 * N - 1; k++) {
