@@ -141,6 +141,19 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share_g1, si
                                      const uint8_t* share_g1, const uint8_t* u_g1, const uint8_t* v,
                                      const uint64_t* off, const uint8_t* w_g2, size_t B, uint8_t* ok);
 
+/* ---- the steps either side of the path ------------------------------------------------------- */
+/* (u[j], v[j], w[j]) = pk.encrypt_with_rng(rng, msg[j]) with the rng's `Fr::random` draw r[j] supplied
+ * by the caller (32 B LE): u = r g1, v = msg ^ keystream(r pk), w = r hash_g1_g2(u, v).
+ * PublicKey::encrypt_with_rng src/lib.rs:128-137.  v has the layout of msgs (same offsets). */
+int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk_g1, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
+                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status);
+/* out[j] = pk_set.public_key_share(idx[j]) = Commitment::evaluate(idx[j] + 1): Horner in G1 over the
+ * (t+1) x 96 B commitment.  PublicKeySet::public_key_share src/lib.rs:570-573, src/poly.rs:497-508.
+ * With tc_verify_sig_batch (pk_stride = 96) this is the share-validation loop of
+ * examples/threshold_sig.rs:115-131 in two launches. */
+int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
+                              uint8_t* status);
+
 /* ---- wire formats --------------------------------------------------------------------------- */
 /* uncompressed -> compressed: PublicKey::to_bytes src/lib.rs:149-153, Signature::to_bytes :255-259 */
 int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status);

@@ -172,6 +172,12 @@ int hs_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* ou
 int hs_xor_with_hash(const uint8_t* g1, const uint8_t* data, size_t len, uint8_t* out) {
   return job_xor_with_hash(g1, data, len, out);
 }
+int hs_encrypt(const uint8_t* pk, const uint8_t* r, const uint8_t* msg, size_t len, uint8_t* u, uint8_t* v, uint8_t* w) {
+  return job_encrypt(pk, r, msg, len, u, v, w);
+}
+int hs_commitment_evaluate(const uint8_t* commit, int t, uint64_t idx, uint8_t* out) {
+  return job_commitment_evaluate(commit, t, idx, out);
+}
 int hs_decompress_g1(const uint8_t* in, uint8_t* out) { return job_decompress<Fq>(in, out); }
 int hs_decompress_g2(const uint8_t* in, uint8_t* out) { return job_decompress<Fq2>(in, out); }
 int hs_compress_g1(const uint8_t* in, uint8_t* out) { return job_compress<Fq>(in, out); }

@@ -210,3 +210,27 @@ def test_encryption_workload_matches_oracle_and_decrypts(engine):
     assert engine.ciphertext_verify(we.u, we.v, we.off, we.w).all()
     out, st = engine.decrypt(t, we.idx, we.shares, we.v, we.off)
     assert not st.any() and bytes(out[: 32 * B]) == b"".join(we.plain)
+
+
+def test_encrypt_and_public_key_shares_entry_points(engine, rnd):
+    """tc_encrypt_batch (encrypt_with_rng, src/lib.rs:128-137) and tc_public_key_share_batch
+    (public_key_share, :570-573): oracle equality, decryptability, and the share-validation loop of
+    examples/threshold_sig.rs:115-131 in two launches."""
+    sk_set = random_sk_set(3, rnd)
+    pk_set = sk_set.public_keys()
+    pk = pk_set.public_key()
+    msgs = [bytes(rnd.randrange(256) for _ in range(n)) for n in (0, 1, 31, 64, 65, 200)] * 11
+    rs = [rnd.randrange(1, o.R) for _ in msgs]
+    cts = pk.encrypt_with_r_batch(rs, msgs)
+    opk = o.g1_from_uncompressed(pk.raw, check=False)
+    for j in (0, 3, 5, 65):
+        u, v, w = o.encrypt_with_r(opk, rs[j], msgs[j])
+        assert (cts[j].u, cts[j].v, cts[j].w) == (o.g1_uncompressed(u), v, o.g2_uncompressed(w))
+    assert Ciphertext.verify_batch(cts).all()
+    assert SecretKey(sk_set.poly[0]).decrypt(cts[4]) == msgs[4]
+    n = 7
+    pks = pk_set.public_key_shares(list(range(n)))
+    assert [p.raw for p in pks] == [o.g1_uncompressed(o.public_key(sk_set.secret_key_share(i).fr)) for i in range(n)]
+    msg = b"validate me"
+    shares = [sk_set.secret_key_share(i).sign(msg) for i in range(n)]
+    assert api.PublicKeyShare.verify_batch_shares(pks, shares, [msg] * n).all()

@@ -315,3 +315,30 @@ def test_checked_decompress(engine, rnd):
     assert st2.tolist() == [0, 0, 0, 3, 3] + [0] * 62
     for j in (0, 1, 2, 6, 40, 66):
         assert bytes(out1[j]) == o.g1_uncompressed(g1[j]) and bytes(out2[j]) == o.g2_uncompressed(g2[j])
+
+
+def test_config5_shape_t67_n200(engine, rnd):
+    """BASELINE config 5 shape (t=67, N=200) at a small batch: 68-point combination through the
+    chunked general path, against Oracle B; sign -> combine -> verify round trip."""
+    import c_oracle
+    t, N, B = 67, 200, 6
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    sks = [o.secret_key_share(poly, i) for i in range(N)]
+    msgs = [b"tc/msg" + j.to_bytes(8, "little") for j in range(B)]
+    flat, off = pack_messages(msgs)
+    hashes = engine.hash_g2(flat, off)
+    idx = np.stack([np.array(sorted(rnd.sample(range(N), t + 1)), dtype=np.uint64) for _ in range(B)])
+    shares = np.zeros((B, t + 1, 192), dtype=np.uint8)
+    for j in range(B):
+        sel = frs([sks[int(i)] for i in idx[j]])
+        out, st = engine.g2_mul(sel, hashes[j:j + 1].copy())
+        assert not st.any()
+        shares[j] = out[0]
+    sig, st = engine.combine_g2(t, idx, shares)
+    assert not st.any()
+    for j in (0, B - 1):
+        rc, want = c_oracle.combine_g2(t, [int(i) for i in idx[j]], [bytes(shares[j, k]) for k in range(t + 1)])
+        assert rc == 0 and bytes(sig[j]) == want
+    pk = u8(o.g1_uncompressed(o.public_key(poly[0])))
+    assert engine.verify_g2(pk, sig, hashes).all()
+    assert engine.verify_sig(pk, sig, flat, off).all()

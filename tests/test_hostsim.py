@@ -292,3 +292,24 @@ def test_g1_glv_and_phi_subgroup_test(L, rnd):
         assert L.hs_decompress_g1(o.g1_compressed(T), buf(96)) == 3, l
         M = o.E1.add(T, o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)))
         assert L.hs_decompress_g1(o.g1_compressed(M), buf(96)) == 3, l
+
+
+def test_encrypt_and_commitment_evaluate(L, rnd):
+    """PublicKey::encrypt_with_rng (src/lib.rs:128-137) with the Fr draw given, and
+    Commitment::evaluate (src/poly.rs:497-508) = public_key_share, against the oracle."""
+    sk = rnd.randrange(o.R)
+    pk = o.public_key(sk)
+    for msg in (b"", b"Muffins in the canteen today!", bytes(range(100))):
+        r = rnd.randrange(1, o.R)
+        u, v, w = buf(96), buf(max(1, len(msg))), buf(192)
+        assert L.hs_encrypt(o.g1_uncompressed(pk), o.fr_to_bytes(r), msg, len(msg), u, v, w) == 0
+        eu, ev, ew = o.encrypt_with_r(pk, r, msg)
+        assert u.raw == o.g1_uncompressed(eu) and v.raw[: len(msg)] == ev and w.raw == o.g2_uncompressed(ew)
+    for t in (0, 1, 3):
+        poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+        commit = o.commitment(poly)
+        blob = b"".join(o.g1_uncompressed(c) for c in commit)
+        for i in (0, 1, 7, 199, 2 ** 40 + 3, 2 ** 64 - 2):
+            out = buf(96)
+            assert L.hs_commitment_evaluate(blob, t, ctypes.c_uint64(i), out) == 0
+            assert out.raw == o.g1_uncompressed(o.public_key_share(commit, i)), (t, i)

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "tc_verify_sig_batch": [_u8p, _sz, _u8p, _u8p, _u64p, _sz, _u8p],
     "tc_ciphertext_verify_batch": [_u8p, _u8p, _u64p, _u8p, _sz, _u8p],
     "tc_verify_decryption_share_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p],
+    "tc_encrypt_batch": [_u8p, _sz, _u8p, _u8p, _u64p, _sz, _u8p, _u8p, _u8p, _u8p],
+    "tc_public_key_share_batch": [_u8p, _sz, _u64p, _sz, _u8p, _u8p],
     "tc_g1_compress_batch": [_u8p, _sz, _u8p, _u8p],
     "tc_g2_compress_batch": [_u8p, _sz, _u8p, _u8p],
     "tc_g1_decompress_batch": [_u8p, _sz, _u8p, _u8p],

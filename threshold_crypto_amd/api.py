@@ -174,6 +174,19 @@ class PublicKey(_G1Value):
         """PublicKey::from_bytes (src/lib.rs:140-146): checked decode of the 48-byte form."""
         return _from_bytes(cls, data, PK_SIZE, "g1_decompress")
 
+    def encrypt_with_r(self, r, msg):
+        """PublicKey::encrypt_with_rng (src/lib.rs:128-137) with the rng's Fr draw `r` given."""
+        return self.encrypt_with_r_batch([r], [msg])[0]
+
+    def encrypt_with_r_batch(self, rs, msgs, engine=None):
+        e = engine or default_engine()
+        flat, off = pack_messages([bytes(m) for m in msgs])
+        rr = _stack([(int(x) % _R).to_bytes(32, "little") for x in rs], 32)
+        u, v, w, st = e.encrypt(_u8(self.raw), rr, flat, off)
+        for s_ in st:
+            _raise_status(s_)
+        return [Ciphertext(u[j], bytes(v[int(off[j]): int(off[j + 1])]), w[j]) for j in range(len(msgs))]
+
     def verify_g2(self, sig, hash_g2_point):
         """PublicKey::verify_g2 (src/lib.rs:108-110)."""
         return bool(self.verify_g2_batch([sig], [hash_g2_point])[0])
@@ -336,6 +349,11 @@ class PublicKeySet:
 
     def public_key_shares(self, indices, engine=None):
         e = engine or default_engine()
+        if all(0 <= int(i) < 2 ** 64 - 1 for i in indices):
+            out, st = e.public_key_shares(_stack(self.commit, 96), np.array([int(i) for i in indices], dtype=np.uint64))
+            for s_ in st:
+                _raise_status(s_)
+            return [PublicKeyShare(out[j]) for j in range(len(indices))]
         n = len(self.commit)
         B = len(indices)
         scal = np.zeros((B, n, 32), dtype=np.uint8)

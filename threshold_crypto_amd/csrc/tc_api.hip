@@ -572,6 +572,45 @@ int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* o
   return k.finish();
 }
 
+int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
+                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) {
+  TC_REQUIRE(ctx && pk && r && off && out_u && out_v && out_w);
+  TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
+  if (B == 0) return TC_OK;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || msgs);
+  const uint8_t* d_pk = k.in(pk, pk_stride ? (B - 1) * pk_stride + 96 : 96);
+  const uint8_t* d_r = k.in(r, B * 32, /*secret=*/true);
+  const uint8_t* d_msgs = k.in(msgs, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  uint8_t* d_u = k.out(out_u, B * 96);
+  uint8_t* d_v = k.out(out_v, (size_t)total);
+  uint8_t* d_w = k.out(out_w, B * 192);
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed) tc::launch_encrypt(ctx->stream, d_pk, pk_stride, d_r, d_msgs, d_off, B, d_u, d_v, d_w, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
+                              uint8_t* status) {
+  TC_REQUIRE(ctx && commit && idx && out);
+  TC_REQUIRE(t < (1u << 20));
+  if (M == 0) return TC_OK;
+  Call k(ctx);
+  const uint8_t* d_c = k.in(commit, (t + 1) * 96);
+  const uint64_t* d_idx = k.in(idx, M);
+  uint8_t* d_out = k.out(out, M * 96);
+  uint8_t* d_st = k.out(status, M);
+  k.begin_timing();
+  if (!k.failed) tc::launch_commitment_evaluate(ctx->stream, d_c, t, d_idx, M, d_out, d_st);
+  k.end_timing();
+  return k.finish();
+}
+
 int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status) {
   TC_REQUIRE(ctx && in48 && out96);
   if (B == 0) return TC_OK;

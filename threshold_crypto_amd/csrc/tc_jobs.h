@@ -231,6 +231,67 @@ TC_HD uint8_t job_compress<Fq2>(const uint8_t* in, uint8_t* out) {
   return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
 }
 
+// (u, v, w) = pk.encrypt_with_rng(rng, msg) with the rng's Fr draw r supplied by the caller
+// (src/lib.rs:128-137):  u = r g1;  v = msg ^ keystream(r pk);  w = r hash_g1_g2(u, v)
+TC_HD uint8_t job_encrypt(const uint8_t* pk96, const uint8_t* r_le32, const uint8_t* msg, size_t len, uint8_t* out_u,
+                          uint8_t* out_v, uint8_t* out_w) {
+  uint32_t k[8];
+  G1Affine pk;
+  bool ok = fr_from_le32(r_le32, k);
+  ok &= g1_decode_uncompressed(pk96, pk);
+  if (!ok) {
+    g1_encode_uncompressed(G1Affine::infinity(), out_u);
+    g2_encode_uncompressed(G2Affine::infinity(), out_w);
+    for (size_t i = 0; i < len; i++) out_v[i] = 0;
+    return TC_JOB_INVALID_ENCODING;
+  }
+  const G1Affine u = jac_to_affine(g1_mul_glv(g1_generator(), k));
+  g1_encode_uncompressed(u, out_u);
+  uint8_t g[96];
+  g1_encode_uncompressed(jac_to_affine(g1_mul_glv(pk, k)), g);
+  job_xor_with_hash(g, msg, len, out_v);
+  uint8_t h[192];
+  job_hash_g1_g2(out_u, out_v, len, h);
+  G2Affine hp;
+  g2_decode_uncompressed(h, hp);
+  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(G2Jac::from_affine(hp), k)), out_w);
+  return TC_JOB_OK;
+}
+
+// Commitment::evaluate(i + 1) (src/poly.rs:497-508) = PublicKeySet::public_key_share(i)
+// (src/lib.rs:570-573): Horner in G1, result = result * x + c_k from the top coefficient down,
+// x = idx + 1 as a 64-bit ladder (x = 2^64 is handled by the general scalar path of the caller).
+TC_HD uint8_t job_commitment_evaluate(const uint8_t* commit, int t, uint64_t idx, uint8_t* out96) {
+  const uint64_t x = idx + 1;
+  G1Affine c;
+  if (x == 0 || !g1_decode_uncompressed(commit + (size_t)t * 96, c)) {
+    g1_encode_uncompressed(G1Affine::infinity(), out96);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  G1Jac res = G1Jac::from_affine(c);
+  bool ok = true;
+  TC_NOUNROLL for (int kk = t - 1; kk >= 0; kk--) {
+    // res = res * x
+    G1Jac acc = G1Jac::infinity();
+    bool started = false;
+    TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
+      if (started) acc = jac_dbl(acc);
+      if ((x >> bit) & 1ull) {
+        acc = started ? jac_add(acc, res) : res;
+        started = true;
+      }
+    }
+    ok &= g1_decode_uncompressed(commit + (size_t)kk * 96, c);
+    res = jac_add_mixed(acc, c);
+  }
+  if (!ok) {
+    g1_encode_uncompressed(G1Affine::infinity(), out96);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  g1_encode_uncompressed(jac_to_affine(res), out96);
+  return TC_JOB_OK;
+}
+
 // compressed -> uncompressed with the reference's CHECKED decode (from_bytes,
 // src/lib.rs:140-146, 246-252): on the curve and in the order-r subgroup, else Invalid
 template <class F>

@@ -39,6 +39,10 @@ void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, c
                        uint8_t* out, uint8_t* status);
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                           uint8_t* out, uint8_t* status);
+void launch_encrypt(hipStream_t st, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
+                    const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status);
+void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
+                                uint8_t* status);
 void launch_fill_g1_generator(hipStream_t st, uint8_t* out96);
 
 }  // namespace tc

@@ -286,3 +286,26 @@ class Engine:
         st = self._empty(dev, (B,), ref=comp)
         self._call("tc_g2_decompress_batch", _ptr(comp), B, _ptr(out), _ptr(st))
         return out, st
+
+    def encrypt(self, pk, r, msgs, off):
+        """PublicKey::encrypt_with_rng with the Fr draws supplied: returns (u, v, w, status)."""
+        dev = self._mode(pk, r, msgs, off)
+        B = off.shape[0] - 1
+        self._check(r, (FR_BYTES,), "r")
+        u = self._empty(dev, (B, G1_BYTES), ref=r)
+        v = self._empty(dev, tuple(msgs.shape), ref=r)
+        w = self._empty(dev, (B, G2_BYTES), ref=r)
+        st = self._empty(dev, (B,), ref=r)
+        self._call("tc_encrypt_batch", _ptr(pk), self._stride(pk, G1_BYTES), _ptr(r), _ptr(msgs), _ptr(off), B, _ptr(u),
+                   _ptr(v), _ptr(w), _ptr(st))
+        return u, v, w, st
+
+    def public_key_shares(self, commit, idx):
+        """Commitment::evaluate(idx + 1) for every index: (M, 96)."""
+        dev = self._mode(commit, idx)
+        M = idx.shape[0]
+        t = commit.shape[0] - 1
+        out = self._empty(dev, (M, G1_BYTES), ref=commit)
+        st = self._empty(dev, (M,), ref=commit)
+        self._call("tc_public_key_share_batch", _ptr(commit), int(t), _ptr(idx), M, _ptr(out), _ptr(st))
+        return out, st
