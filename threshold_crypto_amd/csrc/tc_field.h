@@ -257,7 +257,12 @@ struct Fq {
   // bval: |value| <= bval * p.  Lazy sums also grow the VALUE; only a multiplication (or
   // reduce_value()) brings it back to ~p: a product lands in (-V_a V_b p / 512, p + V_a V_b p / 512).
   float blo, bhi, bval;
-  TC_HD void set_range(float lo, float hi) { blo = lo; bhi = hi; }
+  TC_HD void set_range(float lo, float hi) {
+    blo = lo;
+    bhi = hi;
+    // the limbs themselves are int32: |l_i| < 2^31 = 32 * 2^26 (keep a margin for norm()'s carry-in)
+    if (lo < -31.f || hi > 31.f) tc_bound_fail(lo, hi);
+  }
   TC_HD void set_val(float v) { bval = v; }
   TC_HD float lo() const { return blo; }
   TC_HD float hi() const { return bhi; }

@@ -135,37 +135,35 @@ TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
   return Fq::from_mont384(w);
 }
 
-// G2Affine::get_point_from_x(x, greatest) of pairing 0.16
-TC_HD bool g2_point_from_x(const Fq2& x, bool greatest, G2Affine& p) {
-  Fq2 rhs = x.sqr() * x + g2_b();
-  Fq2 y;
-  if (!fq2_sqrt(rhs, y)) return false;
-  Fq2 negy = -y;
-  // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
-  bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
-  p.x = x;
-  p.y = (y_lt_negy ^ greatest) ? y : negy;
-  p.inf = false;
-  return true;
-}
-
-// G2::random(ChaChaRng::from_seed(seed)) followed by into_affine() is left to the caller:
-// returns the Jacobian point h2 * (x, y).
+// G2::random(ChaChaRng::from_seed(seed)) of pairing 0.16, up to the final into_affine():
+//   loop { x = Fq2::random; greatest = next_u32() % 2 != 0;
+//          if let Some(p) = get_point_from_x(x, greatest) { p = p.scale_by_cofactor(); if !p.is_zero() return p } }
+// with get_point_from_x = { y = sqrt(x^3 + b)?; pick y or -y: the lexicographically larger iff greatest }.
+// The retry loop only runs the squareness test (one Fq exponentiation per attempt); the root,
+// the sign selection and the cofactor clearing happen once per lane after every lane of the
+// wave has found its x, so the slowest lane's extra attempts cost the others little.
 TC_HD G2Jac g2_random_from_seed(const uint32_t* seed_words) {
   ChaChaRng rng;
   rng.init(seed_words);
   G2Jac res = G2Jac::infinity();
   bool done = false;
   TC_NOUNROLL while (!done) {
-    G2Affine cand;
+    Fq2 x, rhs;
+    Fq n;
+    bool greatest = false;
     bool have = false;
     TC_NOUNROLL while (!have) {
-      Fq2 x;
       x.c0 = fq_random(rng);
       x.c1 = fq_random(rng);
-      bool greatest = (rng.next_u32() & 1u) != 0;
-      have = g2_point_from_x(x, greatest, cand);
+      greatest = (rng.next_u32() & 1u) != 0;
+      rhs = x.sqr() * x + g2_b();
+      have = fq2_sqrt_begin(rhs, n);
     }
+    const Fq2 y = fq2_sqrt_finish(rhs, n);
+    const Fq2 negy = -y;
+    // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
+    const bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
+    G2Affine cand{x, (y_lt_negy ^ greatest) ? y : negy.norm(), false};
     res = g2_clear_cofactor(cand);  // = [h2] cand, the value scale_by_cofactor returns
     done = !res.is_inf();
   }

@@ -28,25 +28,39 @@ TC_HD bool fq_sqrt(const Fq& a, Fq& root, Fq* inv_root = nullptr) {
 
 TC_HD Fq fq_half(const Fq& a) { return a * Fq::from_limbs(FQ26_INV2); }
 
-// root of a in Fq2; false if a is not a square
-TC_HD_NOINLINE bool fq2_sqrt(const Fq2& a, Fq2& out) {
+// Square root in Fq2 in two steps, so that rejection sampling (hash_g2) can run only the cheap
+// squareness test inside its retry loop and finish the root once, after the loop, for all lanes
+// of the wave together:
+//   begin : a is a square in Fq2  <=>  its norm a0^2 + a1^2 is a square in Fq; n = sqrt(norm)
+//   finish: x0 = sqrt((a0 +- n) / 2), x1 = a1 / (2 x0)
+TC_HD bool fq2_sqrt_begin(const Fq2& a, Fq& n) {
   if (a.c1.is_zero()) {
-    // a = a0 in Fq: exactly one of a0, -a0 is a square in Fq (-1 is a non-residue)
-    Fq s;
-    if (fq_sqrt(a.c0, s)) out = Fq2{s, Fq::zero()};
-    else out = Fq2{Fq::zero(), s};  // s^2 = -a0, (s u)^2 = a0
-    return true;
+    n = Fq::zero();
+    return true;  // a = a0 in Fq: one of a0, -a0 is a square in Fq, so a is a square in Fq2
   }
-  const Fq norm = a.c0.sqr() + a.c1.sqr();
-  Fq n;
-  if (!fq_sqrt(norm, n)) return false;  // a is a square in Fq2 iff its norm is one in Fq
+  return fq_sqrt(a.c0.sqr() + a.c1.sqr(), n);
+}
+
+TC_HD_NOINLINE Fq2 fq2_sqrt_finish(const Fq2& a, const Fq& n) {
+  if (a.c1.is_zero()) {
+    Fq s;
+    if (fq_sqrt(a.c0, s)) return Fq2{s, Fq::zero()};
+    return Fq2{Fq::zero(), s};  // s^2 = -a0, (s u)^2 = a0
+  }
   Fq delta = fq_half(a.c0 + n);
   Fq x0, x0inv;
   if (!fq_sqrt(delta, x0, &x0inv)) {
     delta = (delta - n).norm();  // (a0 - n) / 2: exactly one of the two is a square (a1 != 0)
     fq_sqrt(delta, x0, &x0inv);
   }
-  out = Fq2{x0, fq_half(a.c1 * x0inv)};
+  return Fq2{x0, fq_half(a.c1 * x0inv)};
+}
+
+// root of a in Fq2; false if a is not a square
+TC_HD bool fq2_sqrt(const Fq2& a, Fq2& out) {
+  Fq n;
+  if (!fq2_sqrt_begin(a, n)) return false;
+  out = fq2_sqrt_finish(a, n);
   return true;
 }
 
