@@ -34,7 +34,7 @@ MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient d
 EXECUTED = {"combine_g2_t3_fast": (5746, 389), "combine_g2_t3_general": (14861, 389), "g2_mul": (4174, 389),
             "verify_g2": (19441, 393), "hash_g2": (6937, 1640)}   # tools/count_ops.py
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
-# profiles/r01_c_*_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
+# profiles/r01_c_shipped_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
 # (register-spill / window-table) traffic, ~550x the algorithmic bytes.
 PROFILED_TRAFFIC_BYTES = {65536: int((2 * 14133573.0 + 7473319.7) * 1024)}
@@ -198,7 +198,7 @@ def main():
             roofline = {"bound": "valu_int32_mac", "achieved": round(ach, 3), "peak": P_INT_TMACS, "unit": "TMAC/s",
                         "frac": round(ach / P_INT_TMACS, 4),
                         "traffic": PROFILED_TRAFFIC_BYTES.get(B) if world == 1 else None,
-                        "traffic_is": "bytes per launch, L2<->fabric (scratch spills), profiles/r01_c_*_summary.csv",
+                        "traffic_is": "bytes per launch, L2<->fabric (scratch spills), profiles/r01_c_shipped_rocprofv3_summary.csv",
                         "achieved_is": "reference-algorithm work (31148 Fq-mul x 300 MAC per combine, SURVEY 8d) / kernel "
                                        "time; exceeds 1.0 because the kernel needs 5x fewer multiplications than the "
                                        "reference algorithm",
