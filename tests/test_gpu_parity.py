@@ -342,3 +342,34 @@ def test_config5_shape_t67_n200(engine, rnd):
     pk = u8(o.g1_uncompressed(o.public_key(poly[0])))
     assert engine.verify_g2(pk, sig, hashes).all()
     assert engine.verify_sig(pk, sig, flat, off).all()
+
+
+def test_empty_batches_and_long_messages(engine, rnd):
+    """B = 0 is a no-op for every entry point; messages far beyond one SHA3 block hash correctly."""
+    z8 = np.zeros((0, 192), dtype=np.uint8)
+    out, st = engine.combine_g2(3, np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 4, 192), dtype=np.uint8))
+    assert out.shape == (0, 192) and st.shape == (0,)
+    out, st = engine.g2_mul(frs([5]), z8)
+    assert out.shape == (0, 1, 192)
+    assert engine.pairing_check(np.zeros((0, 96), np.uint8), z8, np.zeros((0, 96), np.uint8), z8, B=0).shape == (0,)
+    flat, off = pack_messages([])
+    assert engine.hash_g2(flat, off).shape == (0, 192)
+    msgs = [bytes(rnd.randrange(256) for _ in range(n)) for n in (4096, 10000, 136 * 7, 136 * 7 + 1)]
+    flat, off = pack_messages(msgs)
+    out = engine.hash_g2(flat, off)
+    for j, m in enumerate(msgs):
+        assert bytes(out[j]) == o.g2_uncompressed(o.hash_g2(m)), len(m)
+    # hash_g1_g2 with a long v (> 64 bytes is pre-hashed, src/lib.rs:700-704)
+    P = o.E1.mul(o.G1_GEN, 31337)
+    h, st = engine.hash_g1_g2(g1s([P] * 2), *pack_messages([msgs[0], msgs[1]]))
+    assert not st.any() and bytes(h[1]) == o.g2_uncompressed(o.hash_g1_g2(P, msgs[1]))
+
+
+def test_not_enough_shares_in_device_mode(engine, rnd):
+    """n_per_job <= t in device-resident mode: status NotEnoughShares for every job, no kernel launched."""
+    import torch
+    idx = torch.zeros((5, 2), dtype=torch.int64, device="cuda")
+    sh = torch.zeros((5, 2, 192), dtype=torch.uint8, device="cuda")
+    out, st = engine.combine_g2(3, idx, sh)
+    engine.sync()
+    assert st.cpu().tolist() == [1] * 5

@@ -269,6 +269,8 @@ class SecretKey:
         e = engine or default_engine()
         flat, off = pack_messages([bytes(m) for m in msgs])
         out, st = e.sign(_u8(self._bytes())[None], flat, off)
+        for s_ in st.reshape(-1):
+            _raise_status(s_)
         return [cls(out[j, 0]) for j in range(len(msgs))]
 
     def decrypt(self, ct):
@@ -317,6 +319,8 @@ def sign_shares_batch(secret_key_shares, msgs, engine=None):
     flat, off = pack_messages([bytes(m) for m in msgs])
     fr = _stack([s._bytes() for s in secret_key_shares], 32)
     out, st = e.sign(fr, flat, off)
+    for s_ in st.reshape(-1):
+        _raise_status(s_)
     return [[SignatureShare(out[j, s]) for s in range(len(secret_key_shares))] for j in range(len(msgs))]
 
 

@@ -223,8 +223,9 @@ const char* tc_last_error(const tc_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 
 // ---- hashing ------------------------------------------------------------------------------
 int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out_g2) {
-  TC_REQUIRE(ctx && off && out_g2);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && off && out_g2);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -240,8 +241,9 @@ int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size
 
 int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
                         uint8_t* out_g2, uint8_t* status) {
-  TC_REQUIRE(ctx && g1 && off && out_g2);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && g1 && off && out_g2);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -260,8 +262,9 @@ int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, con
 // ---- scalar multiplication -----------------------------------------------------------------
 static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                      uint8_t* status) {
-  TC_REQUIRE(ctx && fr && pts && out);
+  TC_REQUIRE(ctx);
   if (S == 0 || B == 0) return TC_OK;
+  TC_REQUIRE(ctx && fr && pts && out);
   const size_t PB = g2 ? 192 : 96;
   Call k(ctx);
   const uint8_t* d_fr = k.in(fr, S * 32, /*secret=*/true);
@@ -289,8 +292,9 @@ int tc_g1_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S
 
 int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uint64_t* off, size_t S, size_t B,
                   uint8_t* out_g2, uint8_t* status) {
-  TC_REQUIRE(ctx && fr && off && out_g2);
+  TC_REQUIRE(ctx);
   if (S == 0 || B == 0) return TC_OK;
+  TC_REQUIRE(ctx && fr && off && out_g2);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -313,9 +317,10 @@ int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uin
 // ---- combination -----------------------------------------------------------------------------
 static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx, const uint8_t* shares, size_t B,
                    uint8_t* out, uint8_t* status, const uint8_t* v, const uint64_t* off, uint8_t* plain) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && out && status);
   TC_REQUIRE(t < (1u << 20));
-  if (B == 0) return TC_OK;
   const size_t PB = g2 ? 192 : 96;
   Call k(ctx);
   if (n <= t) {
@@ -385,8 +390,9 @@ int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* id
 
 static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                    uint8_t* status) {
-  TC_REQUIRE(ctx && out && (n == 0 || (scalars && points)));
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && out && (n == 0 || (scalars && points)));
   const size_t PB = g2 ? 192 : 96;
   Call k(ctx);
   const uint8_t* d_sc = k.in(scalars, B * n * 32, /*secret=*/true);
@@ -414,8 +420,9 @@ int tc_g2_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uin
 
 int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                            uint8_t* out, uint8_t* status) {
-  TC_REQUIRE(ctx && g1 && off && out);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && g1 && off && out);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -434,9 +441,10 @@ int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, 
 // ---- pairing checks ---------------------------------------------------------------------------
 int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                            size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && a && b && c && d && ok);
   TC_REQUIRE((sa == 0 || sa >= 96) && (sc == 0 || sc >= 96) && (sb == 0 || sb >= 192) && (sd == 0 || sd >= 192));
-  if (B == 0) return TC_OK;
   Call k(ctx);
   auto span = [&](size_t stride, size_t bytes) { return stride ? (B - 1) * stride + bytes : bytes; };
   const uint8_t* da = k.in(a, span(sa, 96));
@@ -452,9 +460,10 @@ int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8
 
 int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* sig, const uint8_t* hash,
                        size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk && sig && hash && ok);
   TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
-  if (B == 0) return TC_OK;
   Call k(ctx);
   const uint8_t* d_pk = k.in(pk, pk_stride ? (B - 1) * pk_stride + 96 : 96);
   const uint8_t* d_sig = k.in(sig, B * 192);
@@ -469,9 +478,10 @@ int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const u
 
 int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* sig, const uint8_t* msgs,
                         const uint64_t* off, size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk && sig && off && ok);
   TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
-  if (B == 0) return TC_OK;
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -493,8 +503,9 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
 
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, const uint64_t* off,
                                const uint8_t* w, size_t B, uint8_t* ok) {
-  TC_REQUIRE(ctx && u && off && w && ok);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && u && off && w && ok);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -519,9 +530,10 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
 int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_t pk_stride, const uint8_t* share,
                                      const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
                                      size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk_share && share && u && off && w && ok);
   TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
-  if (B == 0) return TC_OK;
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -547,8 +559,9 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
 
 // ---- wire formats ------------------------------------------------------------------------------
 int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status) {
-  TC_REQUIRE(ctx && in96 && out48);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && in96 && out48);
   Call k(ctx);
   const uint8_t* d_in = k.in(in96, B * 96);
   uint8_t* d_out = k.out(out48, B * 48);
@@ -560,8 +573,9 @@ int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* ou
 }
 
 int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* out96, uint8_t* status) {
-  TC_REQUIRE(ctx && in192 && out96);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && in192 && out96);
   Call k(ctx);
   const uint8_t* d_in = k.in(in192, B * 192);
   uint8_t* d_out = k.out(out96, B * 96);
@@ -574,9 +588,10 @@ int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* o
 
 int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
                      const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk && r && off && out_u && out_v && out_w);
   TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
-  if (B == 0) return TC_OK;
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
@@ -597,9 +612,10 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uin
 
 int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                               uint8_t* status) {
+  TC_REQUIRE(ctx);
+  if (M == 0) return TC_OK;
   TC_REQUIRE(ctx && commit && idx && out);
   TC_REQUIRE(t < (1u << 20));
-  if (M == 0) return TC_OK;
   Call k(ctx);
   const uint8_t* d_c = k.in(commit, (t + 1) * 96);
   const uint64_t* d_idx = k.in(idx, M);
@@ -612,8 +628,9 @@ int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, cons
 }
 
 int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status) {
-  TC_REQUIRE(ctx && in48 && out96);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && in48 && out96);
   Call k(ctx);
   const uint8_t* d_in = k.in(in48, B * 48);
   uint8_t* d_out = k.out(out96, B * 96);
@@ -625,8 +642,9 @@ int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* 
 }
 
 int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out192, uint8_t* status) {
-  TC_REQUIRE(ctx && in96 && out192);
+  TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && in96 && out192);
   Call k(ctx);
   const uint8_t* d_in = k.in(in96, B * 96);
   uint8_t* d_out = k.out(out192, B * 192);
