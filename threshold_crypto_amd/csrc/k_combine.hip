@@ -5,7 +5,7 @@
 namespace tc {
 
 // one lane per (job, sample position): lambda_i of job j
-__global__ __launch_bounds__(kBlock) void k_lagrange(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t,
                                                      size_t B, uint32_t* __restrict__ lam,
                                                      uint8_t* __restrict__ status, int g2) {
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -27,12 +27,13 @@ TC_D bool combine_fast(const Fq2&, size_t t, const uint64_t* idx, const uint8_t*
 
 // one lane per job: sum_i lambda_i * share_i
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                     const uint8_t* __restrict__ shares,
                                                     const uint32_t* __restrict__ lam, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   constexpr int PB = PointIO<F>::BYTES;
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  constexpr int L = JobLanes<F>::N;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   if (j >= B) return;
   if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
     PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
@@ -41,20 +42,21 @@ __global__ __launch_bounds__(kBlock) void k_combine(size_t t, size_t n_per_job, 
   uint8_t st = TC_JOB_OK;
   if (!combine_fast(F::zero(), t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st))
     st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
-  if (status) status[j] = st;
+  if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
 // one lane per job: sum_i scalar_i * point_i with caller-supplied scalars (32 B LE each)
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   constexpr int PB = PointIO<F>::BYTES;
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  constexpr int L = JobLanes<F>::N;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   if (j >= B) return;
   uint8_t st = job_lincomb<F>((int)n, points + j * n * PB, reinterpret_cast<const uint32_t*>(scalars + j * n * 32),
                               out + j * PB);
-  if (status) status[j] = st;
+  if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
@@ -63,7 +65,7 @@ void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const u
 }
 void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, B, out, status);
+  if (B) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, scalars, points, B, out, status);
 }
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
@@ -77,7 +79,7 @@ void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_
 }
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status);
+  if (B) hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status);
 }
 
 }  // namespace tc

@@ -4,23 +4,23 @@
 
 namespace tc {
 
-__global__ __launch_bounds__(kBlock) void k_hash_g2(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g2(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
                                                     size_t B, uint8_t* __restrict__ out) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
   job_hash_g2(msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192);
 }
 
-__global__ __launch_bounds__(kBlock) void k_hash_g1_g2(const uint8_t* __restrict__ g1, const uint8_t* __restrict__ msgs,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g1_g2(const uint8_t* __restrict__ g1, const uint8_t* __restrict__ msgs,
                                                        const uint64_t* __restrict__ off, size_t B,
                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
   uint8_t st = job_hash_g1_g2(g1 + j * 96, msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192);
-  if (status) status[j] = st;
+  if (status && pair_leader()) status[j] = st;
 }
 
-__global__ __launch_bounds__(kBlock) void k_xor_with_hash(const uint8_t* __restrict__ g1,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_xor_with_hash(const uint8_t* __restrict__ g1,
                                                           const uint8_t* __restrict__ data,
                                                           const uint64_t* __restrict__ off, size_t B,
                                                           uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
@@ -31,19 +31,19 @@ __global__ __launch_bounds__(kBlock) void k_xor_with_hash(const uint8_t* __restr
   if (status) status[j] = st;
 }
 
-__global__ __launch_bounds__(kBlock) void k_encrypt(const uint8_t* __restrict__ pk, size_t pk_stride,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_encrypt(const uint8_t* __restrict__ pk, size_t pk_stride,
                                                     const uint8_t* __restrict__ r, const uint8_t* __restrict__ msgs,
                                                     const uint64_t* __restrict__ off, size_t B,
                                                     uint8_t* __restrict__ out_u, uint8_t* __restrict__ out_v,
                                                     uint8_t* __restrict__ out_w, uint8_t* __restrict__ status) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
   uint8_t st = job_encrypt(pk + j * pk_stride, r + j * 32, msgs + off[j], (size_t)(off[j + 1] - off[j]), out_u + j * 96,
                            out_v + off[j], out_w + j * 192);
-  if (status) status[j] = st;
+  if (status && pair_leader()) status[j] = st;
 }
 
-__global__ __launch_bounds__(kBlock) void k_commitment_evaluate(const uint8_t* __restrict__ commit, size_t t,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_commitment_evaluate(const uint8_t* __restrict__ commit, size_t t,
                                                                 const uint64_t* __restrict__ idx, size_t M,
                                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -54,18 +54,18 @@ __global__ __launch_bounds__(kBlock) void k_commitment_evaluate(const uint8_t* _
 
 void launch_encrypt(hipStream_t st, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_encrypt, dim3(grid_for(B)), dim3(kBlock), 0, st, pk, pk_stride, r, msgs, off, B, out_u, out_v, out_w, status);
+  if (B) hipLaunchKernelGGL(k_encrypt, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, pk, pk_stride, r, msgs, off, B, out_u, out_v, out_w, status);
 }
 void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                                 uint8_t* status) {
   if (M) hipLaunchKernelGGL(k_commitment_evaluate, dim3(grid_for(M)), dim3(kBlock), 0, st, commit, t, idx, M, out, status);
 }
 void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out) {
-  if (B) hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B)), dim3(kBlock), 0, st, msgs, off, B, out);
+  if (B) hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out);
 }
 void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
                        uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status);
+  if (B) hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status);
 }
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                           uint8_t* out, uint8_t* status) {

@@ -6,38 +6,38 @@ namespace tc {
 
 // One curve op per lane.  Lane order is signer-major (tid = s*B + j) so that the 64 lanes of
 // a wave share the signer's scalar: the bit-serial double-and-add stays wave-uniform.
-#ifndef TC_POINT_MUL_WAVES
-#define TC_POINT_MUL_WAVES 1  // min waves per SIMD the register allocator must leave room for
-#endif
 template <class F>
-__global__ __launch_bounds__(kBlock, TC_POINT_MUL_WAVES) void k_point_mul(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_point_mul(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts,
                                                       size_t S, size_t B, uint8_t* __restrict__ out,
                                                       uint8_t* __restrict__ status) {
   constexpr int PB = PointIO<F>::BYTES;
-  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  constexpr int L = JobLanes<F>::N;
+  const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   if (tid >= S * B) return;
   const size_t s = tid / B, j = tid % B;
   const size_t o = j * S + s;
   uint8_t st = job_point_mul<F>(fr + s * 32, pts + j * PB, out + o * PB);
-  if (status) status[o] = st;
+  if (status && (L == 1 || pair_leader())) status[o] = st;
 }
 
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_compress(const uint8_t* __restrict__ in, size_t B,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_compress(const uint8_t* __restrict__ in, size_t B,
                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  constexpr int L = JobLanes<F>::N;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   if (j >= B) return;
   uint8_t st = job_compress<F>(in + j * PointIO<F>::BYTES, out + j * PointIO<F>::CBYTES);
-  if (status) status[j] = st;
+  if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_decompress(const uint8_t* __restrict__ in, size_t B,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_decompress(const uint8_t* __restrict__ in, size_t B,
                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  constexpr int L = JobLanes<F>::N;
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   if (j >= B) return;
   uint8_t st = job_decompress<F>(in + j * PointIO<F>::CBYTES, out + j * PointIO<F>::BYTES);
-  if (status) status[j] = st;
+  if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
 __global__ void k_fill_g1_generator(uint8_t* out96) {
@@ -50,19 +50,19 @@ void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t
 }
 void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {
-  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
 }
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_compress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_compress<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
+  if (B) hipLaunchKernelGGL(k_compress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_decompress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
+  if (B) hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_fill_g1_generator(hipStream_t st, uint8_t* out96) {
   hipLaunchKernelGGL(k_fill_g1_generator, dim3(1), dim3(64), 0, st, out96);

@@ -45,6 +45,50 @@ TC_HD void fq_to_be48(const Fq& a, uint8_t* b) {
   TC_UNROLL for (int i = 0; i < 12; i++) store_be32(b + 44 - 4 * i, l[i]);
 }
 
+// 96 big-endian bytes c1 || c0 <-> Fq2.  In the lane-pair build each lane moves its own 48 bytes
+// (odd lane: c1, the first half) and the range check is reduced over the pair.
+TC_HD bool fq2_from_be96(const uint8_t* b, bool mask_top, Fq2& out) {
+#if TC_PAIR
+  const bool odd = Fq2::odd();
+  Fq m;
+  const bool ok = fq_from_be48(b + (odd ? 0 : 48), mask_top && odd, m);
+  out = Fq2{m};
+  return pair_all(ok);
+#else
+  Fq re, im;
+  bool ok = fq_from_be48(b, mask_top, im);
+  ok &= fq_from_be48(b + 48, false, re);
+  out = Fq2::make(re, im);
+  return ok;
+#endif
+}
+TC_HD void fq2_to_be96(const Fq2& a, uint8_t* b) {
+#if TC_PAIR
+  fq_to_be48(a.m, b + (Fq2::odd() ? 0 : 48));
+#else
+  fq_to_be48(a.c1, b);
+  fq_to_be48(a.c0, b + 48);
+#endif
+}
+// the lane that wrote byte 0 of a G2 encoding (and therefore ORs the flag bits into it)
+TC_HD bool g2_owns_byte0() {
+#if TC_PAIR
+  return Fq2::odd();
+#else
+  return true;
+#endif
+}
+// zero nchunks x 96 bytes, each lane of a pair its own halves
+TC_HD void g2_zero_bytes(uint8_t* b, int nchunks) {
+#if TC_PAIR
+  const int o = Fq2::odd() ? 0 : 48;
+  for (int c = 0; c < nchunks; c++)
+    for (int i = 0; i < 48; i++) b[96 * c + o + i] = 0;
+#else
+  for (int i = 0; i < 96 * nchunks; i++) b[i] = 0;
+#endif
+}
+
 // Fr <- 32 LE bytes; returns false if >= r
 TC_HD bool fr_from_le32(const uint8_t* b, uint32_t* limbs) {
   TC_UNROLL for (int i = 0; i < 8; i++)
@@ -81,10 +125,8 @@ TC_HD bool g2_decode_uncompressed(const uint8_t* b, G2Affine& p) {
     return o == 0;
   }
   if (f & 0x20) return false;
-  bool ok = fq_from_be48(b, true, p.x.c1);
-  ok &= fq_from_be48(b + 48, false, p.x.c0);
-  ok &= fq_from_be48(b + 96, false, p.y.c1);
-  ok &= fq_from_be48(b + 144, false, p.y.c0);
+  bool ok = fq2_from_be96(b, true, p.x);
+  ok &= fq2_from_be96(b + 96, false, p.y);
   p.inf = false;
   return ok && affine_on_curve(p, g2_b());
 }
@@ -101,14 +143,12 @@ TC_HD void g1_encode_uncompressed(const G1Affine& p, uint8_t* b) {
 
 TC_HD void g2_encode_uncompressed(const G2Affine& p, uint8_t* b) {
   if (p.inf) {
-    for (int i = 0; i < 192; i++) b[i] = 0;
-    b[0] = 0x40;
+    g2_zero_bytes(b, 2);
+    if (g2_owns_byte0()) b[0] = 0x40;
     return;
   }
-  fq_to_be48(p.x.c1, b);
-  fq_to_be48(p.x.c0, b + 48);
-  fq_to_be48(p.y.c1, b + 96);
-  fq_to_be48(p.y.c0, b + 144);
+  fq2_to_be96(p.x, b);
+  fq2_to_be96(p.y, b + 96);
 }
 
 // y lexicographically larger than -y ?   (Fq: y > (q-1)/2 ; Fq2: compare c1 first, then c0)
@@ -118,8 +158,9 @@ TC_HD bool fq_lex_largest(const Fq& y) {
   return fq_canonical_gt_half(l);
 }
 TC_HD bool fq2_lex_largest(const Fq2& y) {
-  if (!y.c1.is_zero()) return fq_lex_largest(y.c1);
-  return fq_lex_largest(y.c0);
+  const Fq im = y.im();
+  if (!im.is_zero()) return fq_lex_largest(im);
+  return fq_lex_largest(y.re());
 }
 
 TC_HD void g1_encode_compressed(const G1Affine& p, uint8_t* b) {
@@ -135,14 +176,13 @@ TC_HD void g1_encode_compressed(const G1Affine& p, uint8_t* b) {
 
 TC_HD void g2_encode_compressed(const G2Affine& p, uint8_t* b) {
   if (p.inf) {
-    for (int i = 0; i < 96; i++) b[i] = 0;
-    b[0] = 0xc0;
+    g2_zero_bytes(b, 1);
+    if (g2_owns_byte0()) b[0] = 0xc0;
     return;
   }
-  fq_to_be48(p.x.c1, b);
-  fq_to_be48(p.x.c0, b + 48);
-  b[0] |= 0x80;
-  if (fq2_lex_largest(p.y)) b[0] |= 0x20;
+  fq2_to_be96(p.x, b);
+  const bool largest = fq2_lex_largest(p.y);
+  if (g2_owns_byte0()) b[0] |= largest ? 0xa0 : 0x80;
 }
 
 }  // namespace tc

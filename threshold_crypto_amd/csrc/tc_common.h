@@ -53,6 +53,73 @@
 #define TC_MILLER_ATTR TC_HD_NOINLINE
 #endif
 
+// ---- Fq2 across a lane pair ------------------------------------------------------------------
+// In the hipcc build every job that touches Fq2 (all G2 arithmetic, the pairing, hash_g2) is
+// worked on by TWO adjacent lanes: the even lane holds the c0 coefficient of every Fq2 value,
+// the odd lane c1 (tc_tower.h).  Linear Fq2 operations are component-wise, so each lane does
+// half of them; a product costs each lane two 15x15 limb products and ONE Montgomery reduction
+// (tc_field.h fq2p_mul_call) with the partner's limbs fetched over DPP.  Per lane that halves
+// registers, scratch and latency; a batch of B jobs fills 2B lanes, so batch 65 536 gives the
+// MI355X two waves per SIMD instead of one.  Both lanes of a pair always take the same
+// branches (every predicate is reduced over the pair).  G1-only kernels keep one lane per job.
+// The g++ build of the same headers (tests/hostsim, a test harness) keeps both coefficients
+// in one object and runs the identical coefficient formulas one after the other.
+#if defined(__HIPCC__) && !defined(TC_NO_PAIR)
+#define TC_PAIR 1
+#else
+#define TC_PAIR 0
+#endif
+
+namespace tc {
+#if TC_PAIR
+constexpr int kG2Lanes = 2;  // lanes per job in kernels that work on Fq2 values
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int pair_odd() { return (int)(threadIdx.x & 1u); }
+// value held by the partner lane (quad_perm [1,0,3,2]: a full-rate VALU move)
+#if defined(TC_PAIR_SWIZZLE)
+__device__ __forceinline__ int32_t pair_swap(int32_t v) { return __builtin_amdgcn_ds_swizzle(v, 0x80B1); }
+#else
+__device__ __forceinline__ int32_t pair_swap(int32_t v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+#endif
+#else  // host pass of hipcc: never executed, only has to parse
+inline int pair_odd() { return 0; }
+inline int32_t pair_swap(int32_t v) { return v; }
+#endif
+// predicates reduced over the pair (the swap executes unconditionally on both lanes)
+TC_HD bool pair_all(bool c) {
+  const int32_t mine = c ? 1 : 0;
+  const int32_t theirs = pair_swap(mine);
+  return (mine & theirs) != 0;
+}
+TC_HD bool pair_any(bool c) {
+  const int32_t mine = c ? 1 : 0;
+  const int32_t theirs = pair_swap(mine);
+  return (mine | theirs) != 0;
+}
+#else
+constexpr int kG2Lanes = 1;
+TC_HD int pair_odd() { return 0; }
+TC_HD bool pair_all(bool c) { return c; }
+TC_HD bool pair_any(bool c) { return c; }
+#endif
+// the lane that writes per-job scalars (status bytes, booleans, G1 outputs) in a G2 kernel
+TC_HD bool pair_leader() { return pair_odd() == 0; }
+
+// Data-dependent loops are written wave-uniform:  while (wave_any(!done)) { if (!done) {...} }.
+// A loop whose lanes leave at different iterations costs the same on SIMD hardware (the wave
+// runs until its slowest lane is done), and it keeps every value that must survive the loop
+// out of the hands of the register allocator while its lane is masked off: measured on
+// gfx950 / ROCm 7.2, a lane-divergent retry loop inlined into the hash_g1_g2 kernel returned
+// corrupted live-out values for lanes that had left early (profiles/r01_d_pair_notes.md).
+TC_HD bool wave_any(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(c) != 0;
+#else
+  return c;
+#endif
+}
+}  // namespace tc
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TC_UNROLL _Pragma("unroll")
 #define TC_NOUNROLL _Pragma("nounroll")

@@ -142,7 +142,7 @@ TC_HD bool affine_on_curve(const Affine<F>& p, const F& b) {
 }
 
 TC_HD Fq g1_b() { return Fq::from_limbs(FQ26_B1); }
-TC_HD Fq2 g2_b() { return Fq2{g1_b(), g1_b()}; }
+TC_HD Fq2 g2_b() { return Fq2::make(g1_b(), g1_b()); }
 
 TC_HD Affine<Fq> g1_generator() {
   return Affine<Fq>{Fq::from_limbs(G1_GEN26_X), Fq::from_limbs(G1_GEN26_Y), false};

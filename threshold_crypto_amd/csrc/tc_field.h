@@ -241,7 +241,7 @@ constexpr int FQ_MAX_BOUND_PRODUCT = 128;  // B_a * B_b allowed at a multiplicat
 #if defined(TC_COUNT_OPS)
 // host-only (tests/hostsim): multiplications / squarings executed, for the "ours M/unit"
 // column of DESIGN.md and bench.py's executed-MAC roofline
-inline uint64_t g_tc_mul_count = 0, g_tc_sqr_count = 0;
+inline uint64_t g_tc_mul_count = 0, g_tc_sqr_count = 0, g_tc_mul2_count = 0;
 #endif
 
 struct Fq;
@@ -420,6 +420,40 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
   out[N - 1] = (int32_t)carry;
 }
 
+// Two products, one reduction:  out = (x*y + z*w + m*p) / 2^390.  This is what one lane of an
+// Fq2 lane pair computes for its own coefficient of a product (c0 = a0 b0 - a1 b1 or
+// c1 = a0 b1 + a1 b0): 675 multiply-adds instead of the 900 two separate Montgomery
+// multiplications would take, and three independent chains per column.
+// Column bound: 15 * 2^52 * (Bx By + Bz Bw + 1) < 2^63  <=>  Bx By + Bz Bw < 135.
+constexpr int FQ_MAX_BOUND_PRODUCT2 = 134;
+TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, const int32_t* w, int32_t* out) {
+  constexpr int N = FQ_LIMBS;
+  int32_t m[N];
+  int64_t carry = 0;
+  TC_UNROLL for (int k = 0; k < 2 * N - 1; k++) {
+    const int lo = (k < N) ? 0 : (k - N + 1);
+    const int hi = (k < N) ? k : (N - 1);
+    int64_t s1 = carry;
+    int64_t s2 = 0;
+    int64_t s3 = 0;
+    TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)x[i] * y[k - i];
+    TC_UNROLL for (int i = lo; i <= hi; i++) s3 += (int64_t)z[i] * w[k - i];
+    if (k < N) {
+      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      int64_t s = s1 + s2 + s3;
+      m[k] = (int32_t)(((uint32_t)s * FQ26_INV) & (uint32_t)FQ_MASK);
+      s += (int64_t)m[k] * FQ26_P[0];
+      carry = s >> FQ_RADIX;
+    } else {
+      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      int64_t s = s1 + s2 + s3;
+      out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
+      carry = s >> FQ_RADIX;
+    }
+  }
+  out[N - 1] = (int32_t)carry;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // On the device the multiplier is a REAL function, not inlined into every tower/curve routine
 // (that makes the pairing kernel's code object several MB and hipcc compile times unbounded).
@@ -449,6 +483,51 @@ __device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_
   fq_mul_body<true>(a, a, r.l);
   return r;
 }
+
+#if TC_PAIR
+// ---- Fq2 spread over a lane pair (tc_common.h) ---------------------------------------------
+// A product needs the partner's coefficients: they come over DPP inside the callee, so a call
+// still passes only its own 15 + 15 limbs (+ the lane parity) in VGPRs.
+//   even lane: c0 = a0 b0 - a1 b1 = mine*mine' + (-other)*other'
+//   odd  lane: c1 = a1 b0 + a0 b1 = mine*other' + other*mine'
+__device__ __attribute__((noinline)) inline FqRaw fq2p_mul_call(
+    int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8,
+    int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t a14, int32_t b0, int32_t b1, int32_t b2,
+    int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11,
+    int32_t b12, int32_t b13, int32_t b14, int32_t odd) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
+  const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14};
+  int32_t y[FQ_LIMBS], z[FQ_LIMBS], w[FQ_LIMBS];
+  const bool o = odd != 0;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int32_t ao = pair_swap(a[i]);
+    const int32_t bo = pair_swap(b[i]);
+    y[i] = o ? bo : b[i];
+    w[i] = o ? b[i] : bo;
+    z[i] = o ? ao : -ao;
+  }
+  FqRaw r;
+  fq_mul2_body(a, y, z, w, r.l);
+  return r;
+}
+//   even lane: c0 = (a0 + a1)(a0 - a1);   odd lane: c1 = (2 a1) a0
+__device__ __attribute__((noinline)) inline FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3,
+                                                                int32_t a4, int32_t a5, int32_t a6, int32_t a7,
+                                                                int32_t a8, int32_t a9, int32_t a10, int32_t a11,
+                                                                int32_t a12, int32_t a13, int32_t a14, int32_t odd) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
+  int32_t x[FQ_LIMBS], y[FQ_LIMBS];
+  const bool o = odd != 0;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int32_t ao = pair_swap(a[i]);
+    x[i] = a[i] + (o ? a[i] : ao);
+    y[i] = o ? ao : a[i] - ao;
+  }
+  FqRaw r;
+  fq_mul_body<false>(x, y, r.l);
+  return r;
+}
+#endif  // TC_PAIR
 #endif
 
 TC_HD Fq fq_mul(const Fq& a, const Fq& b) {
@@ -491,6 +570,25 @@ TC_HD Fq fq_sqr(const Fq& a) {
 #endif
   r.set_range(0.f, 1.f);
   r.set_val(1.f + a.val() * a.val() / 512.f);
+  return r;
+}
+
+// (x*y + z*w) / R with ONE reduction: the coefficient formula of an Fq2 product.  The hipcc build
+// reaches it through fq2p_mul_call (one coefficient per lane of a pair); this wrapper is the
+// g++ (test-harness) form, with the static bound bookkeeping.
+TC_HD Fq fq_mul2(const Fq& x, const Fq& y, const Fq& z, const Fq& w) {
+#if defined(TC_BOUND_CHECK)
+  if (x.bound() * y.bound() + z.bound() * w.bound() > (float)FQ_MAX_BOUND_PRODUCT2)
+    tc_bound_fail(x.bound() * y.bound(), z.bound() * w.bound());
+  if (x.val() > 300.f || y.val() > 300.f || z.val() > 300.f || w.val() > 300.f) tc_bound_fail(-x.val(), -y.val());
+#endif
+  Fq r;
+  fq_mul2_body(x.l, y.l, z.l, w.l, r.l);
+#if defined(TC_COUNT_OPS)
+  g_tc_mul2_count++;
+#endif
+  r.set_range(0.f, 1.f);
+  r.set_val(1.f + (x.val() * y.val() + z.val() * w.val()) / 512.f);
   return r;
 }
 

@@ -19,8 +19,8 @@
 
 namespace tc {
 
-TC_HD Fq2 psi_cx() { return Fq2{Fq::from_limbs(PSI_CX_C0), Fq::from_limbs(PSI_CX_C1)}; }
-TC_HD Fq2 psi_cy() { return Fq2{Fq::from_limbs(PSI_CY_C0), Fq::from_limbs(PSI_CY_C1)}; }
+TC_HD Fq2 psi_cx() { return Fq2::make(Fq::from_limbs(PSI_CX_C0), Fq::from_limbs(PSI_CX_C1)); }
+TC_HD Fq2 psi_cy() { return Fq2::make(Fq::from_limbs(PSI_CY_C0), Fq::from_limbs(PSI_CY_C1)); }
 
 TC_HD G2Affine g2_psi(const G2Affine& p) {
   if (p.inf) return p;
@@ -62,8 +62,7 @@ TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Jac* base, const uint64_t* d) {
   G2Jac tbl[16];
   tbl[0] = G2Jac::infinity();
   TC_NOUNROLL for (int m = 1; m < 16; m++) {
-    int low = 0;
-    while (!((m >> low) & 1)) low++;
+    const int low = __builtin_ctz((unsigned)m);
     const int rest = m & (m - 1);
     tbl[m] = rest ? jac_add(tbl[rest], base[low]) : base[low];
   }

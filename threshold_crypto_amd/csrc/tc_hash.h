@@ -52,7 +52,8 @@ TC_HD void sha3_256_words(const uint8_t* data, size_t len, uint32_t* out_words) 
   const size_t RATE = 136;
   size_t off = 0;
   bool final_done = false;
-  TC_NOUNROLL while (!final_done) {
+  TC_NOUNROLL while (wave_any(!final_done)) {
+    if (final_done) continue;
     size_t remaining = len - off;
     const bool last = remaining < RATE;
     TC_UNROLL for (int w = 0; w < 17; w++) {
@@ -127,10 +128,12 @@ struct ChaChaRng {
 TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
   uint32_t w[12];
   bool ok = false;
-  TC_NOUNROLL while (!ok) {
-    for (int i = 0; i < 12; i++) w[i] = rng.next_u32();
-    w[11] &= 0x1fffffffu;
-    ok = limbs_lt_p<FqParams>(w);
+  TC_NOUNROLL while (wave_any(!ok)) {
+    if (!ok) {
+      for (int i = 0; i < 12; i++) w[i] = rng.next_u32();
+      w[11] &= 0x1fffffffu;
+      ok = limbs_lt_p<FqParams>(w);
+    }
   }
   return Fq::from_mont384(w);
 }
@@ -142,22 +145,26 @@ TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
 // The retry loop only runs the squareness test (one Fq exponentiation per attempt); the root,
 // the sign selection and the cofactor clearing happen once per lane after every lane of the
 // wave has found its x, so the slowest lane's extra attempts cost the others little.
-TC_HD G2Jac g2_random_from_seed(const uint32_t* seed_words) {
+TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words) {
   ChaChaRng rng;
   rng.init(seed_words);
   G2Jac res = G2Jac::infinity();
   bool done = false;
-  TC_NOUNROLL while (!done) {
+  TC_NOUNROLL while (wave_any(!done)) {
+    if (done) continue;  // (a second round needs [h2] cand = 0: never in practice)
     Fq2 x, rhs;
     Fq n;
     bool greatest = false;
     bool have = false;
-    TC_NOUNROLL while (!have) {
-      x.c0 = fq_random(rng);
-      x.c1 = fq_random(rng);
-      greatest = (rng.next_u32() & 1u) != 0;
-      rhs = x.sqr() * x + g2_b();
-      have = fq2_sqrt_begin(rhs, n);
+    TC_NOUNROLL while (wave_any(!have)) {
+      if (!have) {
+        const Fq xre = fq_random(rng);  // c0 is drawn first
+        const Fq xim = fq_random(rng);
+        x = Fq2::make(xre, xim);
+        greatest = (rng.next_u32() & 1u) != 0;
+        rhs = x.sqr() * x + g2_b();
+        have = fq2_sqrt_begin(rhs, n);
+      }
     }
     const Fq2 y = fq2_sqrt_finish(rhs, n);
     const Fq2 negy = -y;

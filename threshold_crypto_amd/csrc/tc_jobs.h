@@ -13,6 +13,16 @@ namespace tc {
 template <class F>
 struct PointIO;
 
+// lanes that work on one job: Fq2 jobs are spread over a lane pair in the hipcc build (tc_common.h)
+template <class F>
+struct JobLanes {
+  static constexpr int N = 1;
+};
+template <>
+struct JobLanes<Fq2> {
+  static constexpr int N = kG2Lanes;
+};
+
 template <>
 struct PointIO<Fq> {
   static constexpr int BYTES = 96;
@@ -161,21 +171,18 @@ TC_HD uint8_t job_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_
   return pairing_check(pa, qb, pc, qd) ? 1 : 0;
 }
 
-// out = hash_g2(msg).into_affine()      (src/lib.rs:691-694)
-TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2) {
+// hash_g2(msg)      (src/lib.rs:691-694)
+TC_HD G2Jac hash_g2_point(const uint8_t* msg, size_t len) {
   uint32_t seed[8];
   sha3_256_words(msg, len, seed);
-  G2Jac h = g2_random_from_seed(seed);
-  g2_encode_uncompressed(jac_to_affine(h), out_g2);
+  return g2_random_from_seed(seed);
+}
+TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2) {
+  g2_encode_uncompressed(jac_to_affine(hash_g2_point(msg, len)), out_g2);
 }
 
-// out = hash_g1_g2(g1, msg).into_affine()   (src/lib.rs:697-707)
-TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2) {
-  G1Affine p;
-  if (!g1_decode_uncompressed(g1, p)) {
-    g2_encode_uncompressed(G2Affine::infinity(), out_g2);
-    return TC_JOB_INVALID_ENCODING;
-  }
+// hash_g1_g2(g1, msg)   (src/lib.rs:697-707)
+TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len) {
   uint8_t buf[64 + 48];
   size_t n;
   if (len > 64) {
@@ -189,11 +196,20 @@ TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, 
     }
     n = 32;
   } else {
-    for (size_t i = 0; i < len; i++) buf[i] = msg[i];
+    for (size_t i = 0; i < 64; i++)  // fixed trip count (tc_common.h wave_any)
+      if (i < len) buf[i] = msg[i];
     n = len;
   }
   g1_encode_compressed(p, buf + n);
-  job_hash_g2(buf, n + 48, out_g2);
+  return hash_g2_point(buf, n + 48);
+}
+TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2) {
+  G1Affine p;
+  if (!g1_decode_uncompressed(g1, p)) {
+    g2_encode_uncompressed(G2Affine::infinity(), out_g2);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  g2_encode_uncompressed(jac_to_affine(hash_g1_g2_point(p, msg, len)), out_g2);
   return TC_JOB_OK;
 }
 
@@ -207,7 +223,13 @@ TC_HD uint8_t job_xor_with_hash(const uint8_t* g1, const uint8_t* data, size_t l
   sha3_256_words(comp, 48, seed);
   ChaChaRng rng;
   rng.init(seed);
-  for (size_t i = 0; i < len; i++) out[i] = data[i] ^ (uint8_t)rng.next_u32();
+  size_t i = 0;
+  TC_NOUNROLL while (wave_any(i < len)) {
+    if (i < len) {
+      out[i] = data[i] ^ (uint8_t)rng.next_u32();
+      i++;
+    }
+  }
   return TC_JOB_OK;
 }
 
@@ -242,7 +264,10 @@ TC_HD uint8_t job_encrypt(const uint8_t* pk96, const uint8_t* r_le32, const uint
   if (!ok) {
     g1_encode_uncompressed(G1Affine::infinity(), out_u);
     g2_encode_uncompressed(G2Affine::infinity(), out_w);
-    for (size_t i = 0; i < len; i++) out_v[i] = 0;
+    size_t i = 0;
+    TC_NOUNROLL while (wave_any(i < len)) {
+      if (i < len) out_v[i++] = 0;
+    }
     return TC_JOB_INVALID_ENCODING;
   }
   const G1Affine u = jac_to_affine(g1_mul_glv(g1_generator(), k));
@@ -250,11 +275,9 @@ TC_HD uint8_t job_encrypt(const uint8_t* pk96, const uint8_t* r_le32, const uint
   uint8_t g[96];
   g1_encode_uncompressed(jac_to_affine(g1_mul_glv(pk, k)), g);
   job_xor_with_hash(g, msg, len, out_v);
-  uint8_t h[192];
-  job_hash_g1_g2(out_u, out_v, len, h);
-  G2Affine hp;
-  g2_decode_uncompressed(h, hp);
-  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(G2Jac::from_affine(hp), k)), out_w);
+  // (G2 values never round-trip through a per-lane byte buffer: in the lane-pair build each
+  // lane only holds half of an encoding)
+  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(hash_g1_g2_point(u, out_v, len), k)), out_w);
   return TC_JOB_OK;
 }
 

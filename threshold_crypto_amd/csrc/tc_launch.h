@@ -7,6 +7,15 @@
 
 namespace tc {
 
+// waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument).
+// Kernels on Fq2 values run two lanes per job (tc_common.h): batch 65 536 gives them two waves
+// per SIMD, so they are compiled for 256 registers; the G1 kernels keep the full 512.
+#ifndef TC_WAVES_G2
+#define TC_WAVES_G2 2
+#endif
+#ifndef TC_WAVES_G1
+#define TC_WAVES_G1 1
+#endif
 constexpr int kBlock = 64;  // one wavefront per workgroup: the jobs are register/scratch heavy
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }

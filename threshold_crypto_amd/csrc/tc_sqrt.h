@@ -34,26 +34,26 @@ TC_HD Fq fq_half(const Fq& a) { return a * Fq::from_limbs(FQ26_INV2); }
 //   begin : a is a square in Fq2  <=>  its norm a0^2 + a1^2 is a square in Fq; n = sqrt(norm)
 //   finish: x0 = sqrt((a0 +- n) / 2), x1 = a1 / (2 x0)
 TC_HD bool fq2_sqrt_begin(const Fq2& a, Fq& n) {
-  if (a.c1.is_zero()) {
+  if (a.im().is_zero()) {
     n = Fq::zero();
     return true;  // a = a0 in Fq: one of a0, -a0 is a square in Fq, so a is a square in Fq2
   }
-  return fq_sqrt(a.c0.sqr() + a.c1.sqr(), n);
+  return fq_sqrt(a.re().sqr() + a.im().sqr(), n);
 }
 
 TC_HD_NOINLINE Fq2 fq2_sqrt_finish(const Fq2& a, const Fq& n) {
-  if (a.c1.is_zero()) {
+  if (a.im().is_zero()) {
     Fq s;
-    if (fq_sqrt(a.c0, s)) return Fq2{s, Fq::zero()};
-    return Fq2{Fq::zero(), s};  // s^2 = -a0, (s u)^2 = a0
+    if (fq_sqrt(a.re(), s)) return Fq2::make(s, Fq::zero());
+    return Fq2::make(Fq::zero(), s);  // s^2 = -a0, (s u)^2 = a0
   }
-  Fq delta = fq_half(a.c0 + n);
+  Fq delta = fq_half(a.re() + n);
   Fq x0, x0inv;
   if (!fq_sqrt(delta, x0, &x0inv)) {
     delta = (delta - n).norm();  // (a0 - n) / 2: exactly one of the two is a square (a1 != 0)
     fq_sqrt(delta, x0, &x0inv);
   }
-  return Fq2{x0, fq_half(a.c1 * x0inv)};
+  return Fq2::make(x0, fq_half(a.im() * x0inv));
 }
 
 // root of a in Fq2; false if a is not a square
@@ -110,9 +110,7 @@ TC_HD bool g2_decode_compressed(const uint8_t* b, G2Affine& p) {
     return o == 0;
   }
   Fq2 x, y;
-  bool ok = fq_from_be48(b, true, x.c1);
-  ok &= fq_from_be48(b + 48, false, x.c0);
-  if (!ok) return false;
+  if (!fq2_from_be96(b, true, x)) return false;
   if (!fq2_sqrt(x.sqr() * x + g2_b(), y)) return false;
   const bool greatest = (f & 0x20) != 0;
   if (fq2_lex_largest(y) != greatest) y = -y;

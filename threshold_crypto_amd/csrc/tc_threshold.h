@@ -35,8 +35,7 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
   Jac<F> tbl[1 << K];
   tbl[0] = Jac<F>::infinity();
   TC_NOUNROLL for (int m = 1; m < (1 << K); m++) {
-    int low = 0;
-    while (!((m >> low) & 1)) low++;
+    const int low = __builtin_ctz((unsigned)m);
     const int rest = m & (m - 1);
     tbl[m] = jac_add_mixed(tbl[rest], pts[low]);
   }
@@ -121,14 +120,12 @@ TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   Jac<F> tbl[1 << K];
   tbl[0] = Jac<F>::infinity();
   TC_NOUNROLL for (int m = 1; m < (1 << K); m++) {
-    int low = 0;
-    while (!((m >> low) & 1)) low++;
+    const int low = __builtin_ctz((unsigned)m);
     tbl[m] = jac_add_mixed(tbl[m & (m - 1)], pts[low]);
   }
   uint64_t any = 0;
   TC_UNROLL for (int k = 0; k < K; k++) any |= c[k];
-  uint32_t bits = 0;
-  while (bits < 64 && (any >> bits)) bits++;
+  uint32_t bits = any ? 64u - (uint32_t)__builtin_clzll(any) : 0u;
   bits = wave_max_u32(bits);
   if (bits > 64) bits = 64;  // lanes that left for the general path contribute undefined values
   Jac<F> acc = Jac<F>::infinity();

@@ -5,8 +5,80 @@
 
 namespace tc {
 
+#if TC_PAIR
+// hipcc build: ONE coefficient per lane (tc_common.h).  Even lane: c0 (real part), odd lane: c1.
+struct Fq2 {
+  Fq m;
+  TC_HD static bool odd() { return pair_odd() != 0; }
+  // the partner lane's coefficient
+  TC_HD Fq other() const {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = pair_swap(m.l[i]);
+    return r;
+  }
+  // both coefficients, on both lanes (codecs, square roots)
+  TC_HD static Fq2 make(const Fq& re, const Fq& im) { return Fq2{Fq::select(odd(), im, re)}; }
+  TC_HD Fq re() const { return Fq::select(odd(), other(), m); }
+  TC_HD Fq im() const { return Fq::select(odd(), m, other()); }
+  TC_HD static Fq2 zero() { return Fq2{Fq::zero()}; }
+  TC_HD static Fq2 one() { return make(Fq::one(), Fq::zero()); }
+  TC_HD bool is_zero() const { return pair_all(m.is_zero()); }
+  TC_HD bool operator==(const Fq2& b) const { return (*this - b).is_zero(); }
+  TC_HD bool operator!=(const Fq2& b) const { return !(*this == b); }
+  TC_HD Fq2 operator+(const Fq2& b) const { return Fq2{m + b.m}; }
+  TC_HD Fq2 operator-(const Fq2& b) const { return Fq2{m - b.m}; }
+  TC_HD Fq2 operator-() const { return Fq2{-m}; }
+  TC_HD Fq2 dbl() const { return Fq2{m.dbl()}; }
+  TC_HD Fq2 conj() const { return Fq2{Fq::select(odd(), -m, m)}; }
+  TC_HD Fq2 norm() const { return Fq2{m.norm()}; }
+  TC_HD Fq2 reduce_value() const { return Fq2{m.reduce_value()}; }
+  // each lane: two limb products, one reduction (tc_field.h fq2p_mul_call)
+  TC_HD Fq2 operator*(const Fq2& b) const {
+    Fq2 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const Fq& a = m;
+    FqRaw t = fq2p_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
+                            a.l[11], a.l[12], a.l[13], a.l[14], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4],
+                            b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12],
+                            b.m.l[13], b.m.l[14], pair_odd());
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
+#else
+    r = b;
+#endif
+    return r;
+  }
+  TC_HD Fq2 sqr() const {
+    Fq2 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const Fq& a = m;
+    FqRaw t = fq2p_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
+                            a.l[11], a.l[12], a.l[13], a.l[14], pair_odd());
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
+#else
+    r = *this;
+#endif
+    return r;
+  }
+  TC_HD Fq2 scale(const Fq& k) const { return Fq2{m * k}; }
+  // times the non-residue (1 + u): (c0 - c1, c0 + c1)
+  TC_HD Fq2 mul_xi() const {
+    const Fq o = other();
+    return Fq2{m + Fq::select(odd(), o, -o)};
+  }
+  TC_HD_NOINLINE Fq2 inv() const {
+    const Fq sq = m.sqr();
+    const Fq t = (sq + Fq2{sq}.other()).inv();  // 1 / (c0^2 + c1^2), computed by both lanes
+    const Fq r = m * t;
+    return Fq2{Fq::select(odd(), -r, r)};
+  }
+  TC_HD static Fq2 select(bool c, const Fq2& a, const Fq2& b) { return Fq2{Fq::select(c, a.m, b.m)}; }
+};
+#else
 struct Fq2 {
   Fq c0, c1;
+  TC_HD static Fq2 make(const Fq& re, const Fq& im) { return Fq2{re, im}; }
+  TC_HD Fq re() const { return c0; }
+  TC_HD Fq im() const { return c1; }
   TC_HD static Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
   TC_HD static Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
   TC_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
@@ -19,19 +91,22 @@ struct Fq2 {
   TC_HD Fq2 conj() const { return Fq2{c0, -c1}; }
   TC_HD Fq2 norm() const { return Fq2{c0.norm(), c1.norm()}; }
   TC_HD Fq2 reduce_value() const { return Fq2{c0.reduce_value(), c1.reduce_value()}; }
-  // Karatsuba: 3 Fq mul
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one-lane-per-job device build (-DTC_NO_PAIR, kept for A/B measurements): Karatsuba, 3 Fq mul
   TC_HD Fq2 operator*(const Fq2& b) const {
     Fq aa = c0 * b.c0;
     Fq bb = c1 * b.c1;
     Fq o = (c0 + c1) * (b.c0 + b.c1);
     return Fq2{aa - bb, o - aa - bb};
   }
-  // complex squaring: 2 Fq mul
-  TC_HD Fq2 sqr() const {
-    Fq ab = c0 * c1;
-    Fq s = (c0 + c1) * (c0 - c1);
-    return Fq2{s, ab.dbl()};
+#else
+  // the two coefficient formulas of the lane-pair build, one after the other
+  TC_HD Fq2 operator*(const Fq2& b) const {
+    return Fq2{fq_mul2(c0, b.c0, -c1, b.c1), fq_mul2(c1, b.c0, c0, b.c1)};
   }
+#endif
+  // c0 = (c0 + c1)(c0 - c1), c1 = (2 c1) c0
+  TC_HD Fq2 sqr() const { return Fq2{(c0 + c1) * (c0 - c1), c1.dbl() * c0}; }
   TC_HD Fq2 scale(const Fq& k) const { return Fq2{c0 * k, c1 * k}; }
   // times the non-residue (1 + u)
   TC_HD Fq2 mul_xi() const { return Fq2{c0 - c1, c0 + c1}; }
@@ -43,6 +118,7 @@ struct Fq2 {
     return Fq2{Fq::select(c, a.c0, b.c0), Fq::select(c, a.c1, b.c1)};
   }
 };
+#endif
 
 struct Fq6 {
   Fq2 c0, c1, c2;
@@ -105,7 +181,7 @@ struct Fq6 {
 TC_HD Fq2 frob_coeff(int k, int i) {  // gamma_k[i], i = 1..5
   const int32_t* a0 = (k == 1) ? FROB26_1_C0[i - 1] : (k == 2) ? FROB26_2_C0[i - 1] : FROB26_3_C0[i - 1];
   const int32_t* a1 = (k == 1) ? FROB26_1_C1[i - 1] : (k == 2) ? FROB26_2_C1[i - 1] : FROB26_3_C1[i - 1];
-  return Fq2{Fq::from_limbs(a0), Fq::from_limbs(a1)};
+  return Fq2::make(Fq::from_limbs(a0), Fq::from_limbs(a1));
 }
 
 struct Fq12 {
