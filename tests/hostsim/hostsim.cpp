@@ -33,6 +33,20 @@ int hs_fq_addsub(const uint8_t* a, const uint8_t* b, uint8_t* sum, uint8_t* diff
   fq_to_be48(-x, neg);
   return 0;
 }
+// zero test on k*p + delta built as a LAZY value: x - y with x = a + (k+1) p-ish pieces.  Returns
+// bit0 = maybe_zero(), bit1 = is_zero_full(), for value  a - b + k*p  (a, b canonical inputs).
+int hs_fq_zero_probe(const uint8_t* a, const uint8_t* b, int k) {
+  Fq x, y;
+  fq_from_be48(a, false, x);
+  fq_from_be48(b, false, y);
+  Fq v = x - y;
+  const Fq p = Fq::from_limbs(FQ26_P);
+  for (int i = 0; i < (k < 0 ? -k : k); i++) {
+    v = (k < 0) ? v - p : v + p;
+    if ((i & 7) == 7) v = v.norm();
+  }
+  return (v.maybe_zero() ? 1 : 0) | (v.is_zero_full() ? 2 : 0) | (v.is_zero() ? 4 : 0);
+}
 int hs_fq2_sqrt(const uint8_t* a /*c0||c1 be48*/, uint8_t* out) {
   Fq2 x, y;
   fq_from_be48(a, false, x.c0);

@@ -54,6 +54,21 @@ def test_field_ops(L, rnd):
     assert L.hs_fq_mul(be(o.Q), be(1), buf(48)) == -1  # non-canonical input rejected
 
 
+def test_zero_filter_never_misses_a_zero(L, rnd):
+    # every representation k*p, |k| <= 300 (the value bound of the lazy arithmetic), must pass the
+    # 4-instruction filter in front of the full zero test; non-zero values must never be reported zero
+    a = rnd.randrange(o.Q)
+    for k in list(range(-300, 301, 7)) + [-300, -1, 0, 1, 300]:
+        assert L.hs_fq_zero_probe(be(a), be(a), k) == 7, k
+    rejected = 0
+    for _ in range(300):
+        a, b = rnd.randrange(o.Q), rnd.randrange(o.Q)
+        r = L.hs_fq_zero_probe(be(a), be(b), rnd.randrange(-50, 50))
+        assert a != b and not (r & 2) and not (r & 4)
+        rejected += not (r & 1)
+    assert rejected >= 295  # the filter does its job
+
+
 def test_fq2_sqrt(L, rnd):
     for _ in range(8):
         a = (rnd.randrange(o.Q), rnd.randrange(o.Q))

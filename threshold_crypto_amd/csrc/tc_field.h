@@ -366,7 +366,20 @@ struct Fq {
     return r;
   }
 
-  TC_HD_NOINLINE bool is_zero() const;
+  // Zero test in two steps.  value = k p with |k| <= 300 (the value bound every operand
+  // obeys) forces the low 26 bits of the value -- l[0] & mask, whatever the lazy upper limbs
+  // hold -- to be k p mod 2^26, i.e. (l[0] * p^-1) mod 2^26 must land within 300 of zero.
+  // Four VALU instructions reject all but ~2^-16 of the non-zero inputs; only survivors pay for
+  // the full reduction.  (Point additions test three coordinates per call.)
+  TC_HD bool maybe_zero() const {
+#if defined(TC_BOUND_CHECK)
+    if (val() > 300.f) tc_bound_fail(val(), -2.f);
+#endif
+    const uint32_t t = ((uint32_t)l[0] * FQ26_INV) & (uint32_t)FQ_MASK;  // = -k mod 2^26
+    return ((t + 300u) & (uint32_t)FQ_MASK) <= 600u;
+  }
+  TC_HD_NOINLINE bool is_zero_full() const;
+  TC_HD bool is_zero() const { return maybe_zero() && is_zero_full(); }
   TC_HD bool operator==(const Fq& b) const { return (*this - b).is_zero(); }
   TC_HD bool operator!=(const Fq& b) const { return !(*this == b); }
   TC_HD_NOINLINE Fq inv() const;  // Fermat a^(p-2); 0 -> 0
@@ -602,7 +615,7 @@ TC_HD void fq_redc_full(const Fq& a, int32_t* out) {
   fq_mul_body<false>(an.l, one, out);
 }
 
-TC_HD_NOINLINE bool Fq::is_zero() const {
+TC_HD_NOINLINE bool Fq::is_zero_full() const {
   int32_t t[FQ_LIMBS];
   fq_redc_full(*this, t);
   int32_t z = 0, e = 0;
