@@ -69,12 +69,18 @@ void hs_force_general_combine(int on) { g_force_general = on; }
 static int combine(int g2, int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) {
   uint32_t lam[8 * 256];
   if (t + 1 > 256) return -1;
-  if (g2 && !g_force_general) {  // same dispatch as k_combine<Fq2>
+  if (!g_force_general) {  // same dispatch as k_combine
     uint8_t st = 0;
     bool done = false;
-    if (t == 1) done = job_combine_g2_small<2>(idx, shares, out, &st);
-    if (t == 2) done = job_combine_g2_small<3>(idx, shares, out, &st);
-    if (t == 3) done = job_combine_g2_small<4>(idx, shares, out, &st);
+    if (g2) {
+      if (t == 1) done = job_combine_small<Fq2, 2>(idx, shares, out, &st);
+      if (t == 2) done = job_combine_small<Fq2, 3>(idx, shares, out, &st);
+      if (t == 3) done = job_combine_small<Fq2, 4>(idx, shares, out, &st);
+    } else {
+      if (t == 1) done = job_combine_small<Fq, 2>(idx, shares, out, &st);
+      if (t == 2) done = job_combine_small<Fq, 3>(idx, shares, out, &st);
+      if (t == 3) done = job_combine_small<Fq, 4>(idx, shares, out, &st);
+    }
     if (done) return st;
   }
   for (int i = 0; i <= t; i++) {

@@ -198,6 +198,16 @@ def test_combine_fast_path_equals_general_path(L, rnd):
         assert L.hs_combine_g2(t, idx, blob, gen) == 0
         L.hs_force_general_combine(0)
         assert fast.raw == gen.raw == o.g2_uncompressed(o.interpolate(o.E2, t, list(zip(ids, sh)))), (t, ids)
+        # the same in G1 (threshold decryption): [D^-1] through the 2-dimensional GLV ladder
+        U = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        sh1 = [o.E1.mul(U, o.poly_evaluate(poly, (i + 1) % o.R)) for i in ids]
+        blob1 = b"".join(o.g1_uncompressed(s) for s in sh1)
+        fast1, gen1 = buf(96), buf(96)
+        assert L.hs_combine_g1(t, idx, blob1, fast1) == 0
+        L.hs_force_general_combine(1)
+        assert L.hs_combine_g1(t, idx, blob1, gen1) == 0
+        L.hs_force_general_combine(0)
+        assert fast1.raw == gen1.raw == o.g1_uncompressed(o.interpolate(o.E1, t, list(zip(ids, sh1)))), (t, ids)
 
 
 def test_gls_and_cofactor_probe(L, rnd):

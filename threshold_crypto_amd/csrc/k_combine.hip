@@ -12,16 +12,17 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t
   const size_t k = t + 1;
   if (tid >= B * k) return;
   const size_t j = tid / k, i = tid % k;
-  if (g2 && combine_g2_small_applies(idx + j * n_per_job, (int)t)) return;  // the fast path owns the job
+  (void)g2;
+  if (combine_small_applies(idx + j * n_per_job, (int)t)) return;  // the fast path owns the job
   uint8_t st = job_lagrange(idx + j * n_per_job, (int)t, (int)i, lam + tid * 8);
   if (st && status) status[j] = st;
 }
 
-TC_D bool combine_fast(const Fq&, size_t, const uint64_t*, const uint8_t*, uint8_t*, uint8_t*) { return false; }
-TC_D bool combine_fast(const Fq2&, size_t t, const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* st) {
-  if (t == 1) return job_combine_g2_small<2>(idx, shares, out, st);
-  if (t == 2) return job_combine_g2_small<3>(idx, shares, out, st);
-  if (t == 3) return job_combine_g2_small<4>(idx, shares, out, st);
+template <class F>
+TC_D bool combine_fast(size_t t, const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* st) {
+  if (t == 1) return job_combine_small<F, 2>(idx, shares, out, st);
+  if (t == 2) return job_combine_small<F, 3>(idx, shares, out, st);
+  if (t == 3) return job_combine_small<F, 4>(idx, shares, out, st);
   return false;
 }
 
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
     return;
   }
   uint8_t st = TC_JOB_OK;
-  if (!combine_fast(F::zero(), t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st))
+  if (!combine_fast<F>(t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st))
     st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }

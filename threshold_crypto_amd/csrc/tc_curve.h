@@ -7,7 +7,7 @@
 namespace tc {
 
 // Output conditioning of point coordinates (tc_field.h): one carry pass is enough over Fq;
-// over Fq2 the Karatsuba sums also need the value pulled back towards p.
+// over Fq2 the value must also be pulled back towards p (the bound checker rejects norm() here).
 TC_HD Fq coord_out(const Fq& a) { return a.norm(); }
 TC_HD Fq2 coord_out(const Fq2& a) { return a.reduce_value(); }
 

@@ -167,6 +167,24 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   return acc;
 }
 
+// [k] P for a Jacobian P in G1 (the share combiner's final [D^-1] step): same decomposition, full additions
+TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) {
+  tc_u128 k1, k2;
+  glv_decompose(k, &k1, &k2);
+  G1Jac tbl[4];
+  tbl[0] = G1Jac::infinity();
+  tbl[1] = p;
+  tbl[2] = G1Jac{(p.x * Fq::from_limbs(G1_BETA)).norm(), -p.y, p.z};  // -phi(P) = [x^2] P
+  tbl[3] = jac_add(tbl[1], tbl[2]);
+  G1Jac acc = G1Jac::infinity();
+  TC_NOUNROLL for (int bit = 127; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
+    if (m) acc = jac_add(acc, tbl[m]);
+  }
+  return acc;
+}
+
 // [|x|] P on G1 by the 64-bit ladder
 TC_HD_NOINLINE G1Jac g1_mul_by_x_abs(const G1Jac& p) {
   G1Jac acc = p;

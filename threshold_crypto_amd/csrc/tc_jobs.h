@@ -42,6 +42,8 @@ struct PointIO<Fq2> {
 // (64 doublings) -- tc_gls.h -- instead of the reference's 255-bit ladder.  Operands must lie in
 // the prime-order subgroup, as every G1/G2 value the reference holds does.
 TC_HD Jac<Fq> point_mul_scalar(const Affine<Fq>& p, const uint32_t* k) { return g1_mul_glv(p, k); }
+TC_HD Jac<Fq> point_mul_scalar(const Jac<Fq>& p, const uint32_t* k) { return g1_mul_glv(p, k); }
+TC_HD Jac<Fq2> point_mul_scalar(const Jac<Fq2>& p, const uint32_t* k) { return g2_mul_gls(p, k); }
 TC_HD Jac<Fq2> point_mul_scalar(const Affine<Fq2>& p, const uint32_t* k) {
   return g2_mul_gls(G2Jac::from_affine(p), k);
 }
@@ -107,33 +109,34 @@ TC_HD uint8_t job_lincomb(int n, const uint8_t* points, const uint32_t* scalars,
   return TC_JOB_OK;
 }
 
-// G2 combination through the small-index fast path (tc_threshold.h); false => not applicable
-template <int K>
-TC_HD bool job_combine_g2_small(const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* status) {
+// combination through the small-index fast path (tc_threshold.h); false => not applicable
+template <class F, int K>
+TC_HD bool job_combine_small(const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* status) {
+  constexpr int PB = PointIO<F>::BYTES;
   uint64_t c_abs[K], d_abs;
   bool c_neg[K], d_neg;
   if (!lagrange_small_coeffs<K>(idx, c_abs, c_neg, &d_abs, &d_neg)) return false;
-  G2Affine pts[K];
+  Affine<F> pts[K];
   bool ok = true;
   TC_NOUNROLL for (int k = 0; k < K; k++) {
-    ok &= g2_decode_uncompressed(shares + (size_t)k * 192, pts[k]);
+    ok &= PointIO<F>::decode(shares + (size_t)k * PB, pts[k]);
     if (c_neg[k]) pts[k].y = -pts[k].y;
   }
   if (!ok) {
-    g2_encode_uncompressed(G2Affine::infinity(), out);
+    PointIO<F>::encode(Affine<F>::infinity(), out);
     *status = TC_JOB_INVALID_ENCODING;
     return true;
   }
-  G2Jac a = straus_small<Fq2, K>(pts, c_abs);
+  Jac<F> a = straus_small<F, K>(pts, c_abs);
   uint32_t dinv[8];
   fr_inverse_of_small(d_abs, d_neg, dinv);
-  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(a, dinv)), out);
+  PointIO<F>::encode(jac_to_affine(point_mul_scalar(a, dinv)), out);
   *status = TC_JOB_OK;
   return true;
 }
 
-// true when job_combine_g2_small will handle the job (so the Lagrange kernel can skip it)
-TC_HD bool combine_g2_small_applies(const uint64_t* idx, int t) {
+// true when job_combine_small will handle the job (so the Lagrange kernel can skip it)
+TC_HD bool combine_small_applies(const uint64_t* idx, int t) {
   uint64_t c_abs[4], d_abs;
   bool c_neg[4], d_neg;
   if (t == 1) return lagrange_small_coeffs<2>(idx, c_abs, c_neg, &d_abs, &d_neg);
