@@ -112,7 +112,7 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
 }
 
 // f^|x| followed by conjugation (x < 0), for f in the cyclotomic subgroup
-TC_HD_NOINLINE Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
+TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
   Fq12 r = f;
   bool started = false;
   TC_NOUNROLL for (int i = 63; i >= 0; i--) {

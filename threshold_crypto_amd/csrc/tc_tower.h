@@ -188,7 +188,7 @@ struct Fq12 {
   Fq6 c0, c1;
   TC_HD static Fq12 one() { return Fq12{Fq6::one(), Fq6::zero()}; }
   TC_HD bool operator==(const Fq12& b) const { return c0 == b.c0 && c1 == b.c1; }
-  TC_HD_NOINLINE Fq12 operator*(const Fq12& b) const {
+  TC_FQ12MUL_ATTR Fq12 operator*(const Fq12& b) const {
     Fq6 t0 = c0 * b.c0;
     Fq6 t1 = c1 * b.c1;
     Fq12 r;
@@ -233,7 +233,7 @@ struct Fq12 {
   }
   // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part
   // of the final exponentiation): 9 Fq2 squarings' worth instead of 2 Fq6 mul.
-  TC_HD_NOINLINE Fq12 cyclotomic_sqr() const {
+  TC_CYCLO_ATTR Fq12 cyclotomic_sqr() const {
     // view as three Fq4 = Fq2[s]/(s^2 - xi) pairs: (c0.c0, c1.c1), (c1.c0, c0.c2), (c0.c1, c1.c2)
     Fq2 z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2;
     Fq2 t0, t1, t2, t3;
