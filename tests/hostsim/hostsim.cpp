@@ -47,6 +47,11 @@ int hs_fq_zero_probe(const uint8_t* a, const uint8_t* b, int k) {
   }
   return (v.maybe_zero() ? 1 : 0) | (v.is_zero_full() ? 2 : 0) | (v.is_zero() ? 4 : 0);
 }
+int hs_fq_legendre(const uint8_t* a) {
+  Fq x;
+  fq_from_be48(a, false, x);
+  return fq_legendre(x);
+}
 int hs_fq2_sqrt(const uint8_t* a /*c0||c1 be48*/, uint8_t* out) {
   Fq2 x, y;
   fq_from_be48(a, false, x.c0);
@@ -186,6 +191,9 @@ void hs_chacha_words(const uint8_t* seed32, int n, uint32_t* out) {
   for (int i = 0; i < n; i++) out[i] = rng.next_u32();
 }
 void hs_hash_g2(const uint8_t* msg, size_t len, uint8_t* out192) { job_hash_g2(msg, len, out192); }
+#if defined(TC_TEST_HOOKS)
+void hs_force_extra_hash_rounds(int n) { g_tc_force_extra_rounds = n; }
+#endif
 int hs_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out192) {
   return job_hash_g1_g2(g1, msg, len, out192);
 }

@@ -22,7 +22,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "threshold_crypto_amd", "csrc")
 def L():
     newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(newest, os.path.getmtime(SRC)):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", LIB], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-DTC_TEST_HOOKS", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", LIB], check=True)
     return ctypes.CDLL(LIB)
 
 
@@ -67,6 +67,34 @@ def test_zero_filter_never_misses_a_zero(L, rnd):
         assert a != b and not (r & 2) and not (r & 4)
         rejected += not (r & 1)
     assert rejected >= 295  # the filter does its job
+
+
+def test_hash_g2_stream_position_after_a_rejected_point(L, rnd):
+    # G2::random keeps drawing from the SAME stream if a cofactor-cleared point is the identity
+    # (never in practice).  Force that round and compare with the oracle doing the same.
+    for j in range(6):
+        msg = b"retry/%d" % j
+        for extra in (1, 2):
+            rng = o.ChaChaRng(o.sha3_256(msg))
+            good = []
+            while len(good) <= extra:
+                c0 = o.fq_random(rng); c1 = o.fq_random(rng); gr = (rng.next_u32() % 2) != 0
+                P = o.g2_get_point_from_x((c0, c1), gr)
+                if P is not None:
+                    good.append(o.E2.mul(P, o.H2))
+            out = buf(192)
+            L.hs_force_extra_hash_rounds(extra)
+            L.hs_hash_g2(msg, len(msg), out)
+            L.hs_force_extra_hash_rounds(0)
+            assert out.raw == o.g2_uncompressed(good[extra]), (j, extra)
+
+
+def test_legendre_symbol_by_binary_jacobi(L, rnd):
+    # the squareness test inside hash_g2's retry loop (tc_sqrt.h fq_legendre) against Euler's criterion
+    vals = [0, 1, 2, 3, 4, o.Q - 1, o.Q - 2, (o.Q - 1) // 2, 1 << 380, (1 << 380) + 1] + [rnd.randrange(o.Q) for _ in range(300)]
+    for a in vals:
+        e = pow(a, (o.Q - 1) // 2, o.Q)
+        assert L.hs_fq_legendre(be(a)) == (0 if a == 0 else (1 if e == 1 else -1)), hex(a)
 
 
 def test_fq2_sqrt(L, rnd):

@@ -142,37 +142,88 @@ TC_HD_NOINLINE Fq fq_random(ChaChaRng& rng) {
 //   loop { x = Fq2::random; greatest = next_u32() % 2 != 0;
 //          if let Some(p) = get_point_from_x(x, greatest) { p = p.scale_by_cofactor(); if !p.is_zero() return p } }
 // with get_point_from_x = { y = sqrt(x^3 + b)?; pick y or -y: the lexicographically larger iff greatest }.
-// The retry loop only runs the squareness test (one Fq exponentiation per attempt); the root,
-// the sign selection and the cofactor clearing happen once per lane after every lane of the
-// wave has found its x, so the slowest lane's extra attempts cost the others little.
+// The retry loop takes the candidates of the stream two at a time and only decides WHICH is the
+// first with a square right-hand side (Jacobi symbol of the norm, no exponentiation; the
+// lane-pair build tests the two candidates on its two lanes at once).  The root, the sign
+// selection and the cofactor clearing happen once, after every job of the wave has its x.
+struct G2Candidate {
+  Fq2 x, rhs;
+  Fq norm;
+  bool greatest, rhs_in_fq;
+};
+TC_HD G2Candidate g2_draw_candidate(ChaChaRng& rng) {
+  G2Candidate c;
+  const Fq xre = fq_random(rng);  // c0 is drawn first
+  const Fq xim = fq_random(rng);
+  c.x = Fq2::make(xre, xim);
+  c.greatest = (rng.next_u32() & 1u) != 0;
+  c.rhs = c.x.sqr() * c.x + g2_b();
+  c.norm = c.rhs.norm_fq();
+  c.rhs_in_fq = c.rhs.im().is_zero();
+  return c;
+}
+
+#if defined(TC_TEST_HOOKS)
+// host-only (tests/hostsim): pretend the first N candidates' cofactor-cleared points were the
+// identity, to walk the otherwise unreachable second round of the outer loop
+inline int g_tc_force_extra_rounds = 0;
+#endif
 TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words) {
   ChaChaRng rng;
-  rng.init(seed_words);
+#if defined(TC_TEST_HOOKS)
+  int forced = g_tc_force_extra_rounds;
+#endif
   G2Jac res = G2Jac::infinity();
+  uint32_t consumed = 0;  // candidates of the stream used up so far
   bool done = false;
   TC_NOUNROLL while (wave_any(!done)) {
-    if (done) continue;  // (a second round needs [h2] cand = 0: never in practice)
-    Fq2 x, rhs;
-    Fq n;
-    bool greatest = false;
-    bool have = false;
-    TC_NOUNROLL while (wave_any(!have)) {
-      if (!have) {
-        const Fq xre = fq_random(rng);  // c0 is drawn first
-        const Fq xim = fq_random(rng);
-        x = Fq2::make(xre, xim);
-        greatest = (rng.next_u32() & 1u) != 0;
-        rhs = x.sqr() * x + g2_b();
-        have = fq2_sqrt_begin(rhs, n);
+    if (done) continue;
+    // (re)position the stream after the candidates already consumed.  A second round needs
+    // [h2] cand = 0, which does not happen in practice; it is here for exactness.
+    rng.init(seed_words);
+    {
+      uint32_t skip = consumed;
+      TC_NOUNROLL while (wave_any(skip != 0)) {
+        if (skip != 0) {
+          fq_random(rng);
+          fq_random(rng);
+          rng.next_u32();
+          skip--;
+        }
       }
     }
-    const Fq2 y = fq2_sqrt_finish(rhs, n);
+    G2Candidate pick;
+    bool have = false;
+    TC_NOUNROLL while (wave_any(!have)) {
+      if (have) continue;
+      const G2Candidate a = g2_draw_candidate(rng);
+      const G2Candidate b = g2_draw_candidate(rng);
+      bool sa, sb;
+      fq_is_square_2(a.norm, b.norm, sa, sb);
+      const bool ok_a = a.rhs_in_fq || sa;
+      const bool ok_b = b.rhs_in_fq || sb;
+      if (ok_a) {
+        pick = a;
+        consumed += 1;
+      } else {
+        pick = b;
+        consumed += 2;
+      }
+      have = ok_a || ok_b;
+    }
+    const Fq2 y = fq2_sqrt_of_square(pick.rhs, pick.norm);
     const Fq2 negy = -y;
     // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
     const bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
-    G2Affine cand{x, (y_lt_negy ^ greatest) ? y : negy.norm(), false};
+    G2Affine cand{pick.x, (y_lt_negy ^ pick.greatest) ? y : negy.norm(), false};
     res = g2_clear_cofactor(cand);  // = [h2] cand, the value scale_by_cofactor returns
     done = !res.is_inf();
+#if defined(TC_TEST_HOOKS)
+    if (forced > 0) {
+      forced--;
+      done = false;
+    }
+#endif
   }
   return res;
 }

@@ -5,8 +5,8 @@
 //     48 / 96-byte compressed forms: on-curve AND in the order-r subgroup.
 // The reference's Fq2::sqrt is Algorithm 9 of eprint 2012/685 (two Fq2 exponentiations).  Which
 // root comes out is not observable -- callers re-select by lexicographic order -- so the device
-// takes roots through the norm instead: three Fq exponentiations at most, and a non-square is
-// rejected after ONE of them (that is the common case inside hash_g2's retry loop).
+// takes roots through the norm instead: two Fq exponentiations, and a non-square is rejected
+// without any (binary Jacobi symbol of the norm: the common case inside hash_g2's retry loop).
 #pragma once
 #include "tc_codec.h"
 #include "tc_gls.h"
@@ -28,39 +28,113 @@ TC_HD bool fq_sqrt(const Fq& a, Fq& root, Fq* inv_root = nullptr) {
 
 TC_HD Fq fq_half(const Fq& a) { return a * Fq::from_limbs(FQ26_INV2); }
 
-// Square root in Fq2 in two steps, so that rejection sampling (hash_g2) can run only the cheap
-// squareness test inside its retry loop and finish the root once, after the loop, for all lanes
-// of the wave together:
-//   begin : a is a square in Fq2  <=>  its norm a0^2 + a1^2 is a square in Fq; n = sqrt(norm)
-//   finish: x0 = sqrt((a0 +- n) / 2), x1 = a1 / (2 x0)
-TC_HD bool fq2_sqrt_begin(const Fq2& a, Fq& n) {
-  if (a.im().is_zero()) {
-    n = Fq::zero();
-    return true;  // a = a0 in Fq: one of a0, -a0 is a square in Fq, so a is a square in Fq2
+// Legendre symbol (a / q) by the binary Jacobi algorithm on the canonical integer: compares,
+// subtractions and shifts on 6 x u64, ~4x cheaper than the exponentiation a^((q-1)/2).
+// The Montgomery factor R = 2^390 is a square, so the symbol of the representative is the
+// symbol of the value.  Wave-uniform loop (tc_common.h wave_any), branch-free body.
+// Returns +1, -1, or 0 for a = 0.
+TC_HD_NOINLINE int fq_legendre(const Fq& a) {
+  uint32_t w[12];
+  a.to_canonical(w);
+  uint64_t x[6], n[6];
+  TC_UNROLL for (int i = 0; i < 6; i++) {
+    x[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    n[i] = (uint64_t)FQ_P[2 * i] | ((uint64_t)FQ_P[2 * i + 1] << 32);
   }
-  return fq_sqrt(a.re().sqr() + a.im().sqr(), n);
+  uint32_t s = 0;  // sign bit of the running symbol
+  bool nz = (x[0] | x[1] | x[2] | x[3] | x[4] | x[5]) != 0;
+  TC_NOUNROLL while (wave_any(nz)) {
+    if (!nz) continue;
+    // x odd: (x / n) = (x - n / n), after reciprocity if x < n
+    const bool odd = (x[0] & 1ull) != 0;
+    uint64_t d1[6], d2[6];  // x - n, n - x
+    uint64_t b1 = 0, b2 = 0;
+    TC_UNROLL for (int i = 0; i < 6; i++) {
+      const uint64_t t1 = x[i] - n[i];
+      const uint64_t c1 = (uint64_t)(x[i] < n[i]) | ((uint64_t)(t1 < b1));
+      d1[i] = t1 - b1;
+      b1 = c1;
+      const uint64_t t2 = n[i] - x[i];
+      const uint64_t c2 = (uint64_t)(n[i] < x[i]) | ((uint64_t)(t2 < b2));
+      d2[i] = t2 - b2;
+      b2 = c2;
+    }
+    const bool lt = b1 != 0;  // x < n
+    if (odd && lt && (x[0] & 3ull) == 3 && (n[0] & 3ull) == 3) s ^= 1u;
+    TC_UNROLL for (int i = 0; i < 6; i++) {
+      const uint64_t xi = x[i];
+      x[i] = odd ? (lt ? d2[i] : d1[i]) : xi;
+      n[i] = (odd && lt) ? xi : n[i];
+    }
+    // x is even now (or zero): strip the factors of two, (2 / n) = -1 iff n = 3, 5 mod 8
+    const bool zero_lo = x[0] == 0;
+    const int k = zero_lo ? 63 : __builtin_ctzll(x[0]);
+    const uint32_t n8 = (uint32_t)n[0] & 7u;
+    if ((k & 1) && (n8 == 3u || n8 == 5u)) s ^= 1u;
+    if (k) {
+      TC_UNROLL for (int i = 0; i < 5; i++) x[i] = (x[i] >> k) | (x[i + 1] << (64 - k));
+      x[5] >>= k;
+    }
+    nz = (x[0] | x[1] | x[2] | x[3] | x[4] | x[5]) != 0;
+  }
+  const bool n_is_one = n[0] == 1 && (n[1] | n[2] | n[3] | n[4] | n[5]) == 0;
+  return n_is_one ? (s ? -1 : 1) : 0;
 }
 
-TC_HD_NOINLINE Fq2 fq2_sqrt_finish(const Fq2& a, const Fq& n) {
-  if (a.im().is_zero()) {
+// "is a square" for two Fq values at once: the lane-pair build evaluates one per lane
+TC_HD void fq_is_square_2(const Fq& a, const Fq& b, bool& sa, bool& sb) {
+#if TC_PAIR
+  const bool odd = pair_odd() != 0;
+  const int mine = fq_legendre(Fq::select(odd, b, a));
+  const int theirs = pair_swap(mine);
+  sa = (odd ? theirs : mine) >= 0;
+  sb = (odd ? mine : theirs) >= 0;
+#else
+  sa = fq_legendre(a) >= 0;
+  sb = fq_legendre(b) >= 0;
+#endif
+}
+
+// a in Fq2 is a square  <=>  its norm a0^2 + a1^2 is a square in Fq  (a1 = 0: always, one of
+// a0, -a0 is a square in Fq).  norm = a.norm_fq().
+TC_HD bool fq2_is_square(const Fq2& a, const Fq& norm) {
+  if (a.im().is_zero()) return true;
+  return fq_legendre(norm) >= 0;
+}
+
+// Square root of a SQUARE a of Fq2 through the norm:
+//   n = sqrt(a0^2 + a1^2),  x0 = sqrt((a0 + n) / 2) or sqrt((a0 - n) / 2) -- exactly one of the two
+//   is a square when a1 != 0 --,  x1 = a1 / (2 x0).
+// Two Fq exponentiations; in the lane-pair build the two candidates for x0 are tried by the two
+// lanes at the same time.
+TC_HD_NOINLINE Fq2 fq2_sqrt_of_square(const Fq2& a, const Fq& norm) {
+  const Fq re = a.re(), im = a.im();
+  if (im.is_zero()) {
     Fq s;
-    if (fq_sqrt(a.re(), s)) return Fq2::make(s, Fq::zero());
+    if (fq_sqrt(re, s)) return Fq2::make(s, Fq::zero());
     return Fq2::make(Fq::zero(), s);  // s^2 = -a0, (s u)^2 = a0
   }
-  Fq delta = fq_half(a.re() + n);
+  Fq n;
+  fq_sqrt(norm, n);
+  const Fq dp = fq_half(re + n), dm = fq_half(re - n);
   Fq x0, x0inv;
-  if (!fq_sqrt(delta, x0, &x0inv)) {
-    delta = (delta - n).norm();  // (a0 - n) / 2: exactly one of the two is a square (a1 != 0)
-    fq_sqrt(delta, x0, &x0inv);
-  }
-  return Fq2::make(x0, fq_half(a.im() * x0inv));
+#if TC_PAIR
+  const bool odd = pair_odd() != 0;
+  const bool mine_ok = fq_sqrt(Fq::select(odd, dm, dp).norm(), x0, &x0inv);
+  x0 = Fq::select(mine_ok, x0, Fq2{x0}.other());
+  x0inv = Fq::select(mine_ok, x0inv, Fq2{x0inv}.other());
+  // (exactly one lane succeeds: dp * dm = -a1^2 / 4 is a non-square)
+#else
+  if (!fq_sqrt(dp, x0, &x0inv)) fq_sqrt(dm.norm(), x0, &x0inv);
+#endif
+  return Fq2::make(x0, fq_half(im * x0inv));
 }
 
 // root of a in Fq2; false if a is not a square
 TC_HD bool fq2_sqrt(const Fq2& a, Fq2& out) {
-  Fq n;
-  if (!fq2_sqrt_begin(a, n)) return false;
-  out = fq2_sqrt_finish(a, n);
+  const Fq norm = a.norm_fq();
+  if (!fq2_is_square(a, norm)) return false;
+  out = fq2_sqrt_of_square(a, norm);
   return true;
 }
 

@@ -65,6 +65,11 @@ struct Fq2 {
     const Fq o = other();
     return Fq2{m + Fq::select(odd(), o, -o)};
   }
+  // c0^2 + c1^2 (the Fq2 norm), on both lanes
+  TC_HD Fq norm_fq() const {
+    const Fq sq = m.sqr();
+    return sq + Fq2{sq}.other();
+  }
   TC_HD_NOINLINE Fq2 inv() const {
     const Fq sq = m.sqr();
     const Fq t = (sq + Fq2{sq}.other()).inv();  // 1 / (c0^2 + c1^2), computed by both lanes
@@ -110,6 +115,7 @@ struct Fq2 {
   TC_HD Fq2 scale(const Fq& k) const { return Fq2{c0 * k, c1 * k}; }
   // times the non-residue (1 + u)
   TC_HD Fq2 mul_xi() const { return Fq2{c0 - c1, c0 + c1}; }
+  TC_HD Fq norm_fq() const { return c0.sqr() + c1.sqr(); }
   TC_HD_NOINLINE Fq2 inv() const {
     Fq t = (c0.sqr() + c1.sqr()).inv();
     return Fq2{c0 * t, -(c1 * t)};
