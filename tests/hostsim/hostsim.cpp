@@ -12,6 +12,15 @@ void hs_op_counts(uint64_t* mul, uint64_t* sqr, int reset) {
   *sqr = g_tc_sqr_count;
   if (reset) g_tc_mul_count = g_tc_sqr_count = 0;
 }
+// out[0..4] = mul2 (Fq2 products' coefficient formulas), split mul, split sqr, all mul, all sqr
+void hs_op_counts5(uint64_t* out, int reset) {
+  out[0] = g_tc_mul2_count;
+  out[1] = g_tc_split_mul_count;
+  out[2] = g_tc_split_sqr_count;
+  out[3] = g_tc_mul_count;
+  out[4] = g_tc_sqr_count;
+  if (reset) g_tc_mul2_count = g_tc_split_mul_count = g_tc_split_sqr_count = g_tc_mul_count = g_tc_sqr_count = 0;
+}
 #endif
 int hs_fq_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   Fq x, y;
@@ -68,6 +77,11 @@ int hs_lagrange(const uint64_t* idx, int t, int i, uint8_t* out32le) {
   int st = job_lagrange(idx, t, i, w);
   memcpy(out32le, w, 32);
   return st;
+}
+void hs_fr_inverse_of_small(uint64_t d_abs, int d_neg, uint8_t* out32le) {
+  uint32_t w[8];
+  fr_inverse_of_small(d_abs, d_neg != 0, w);
+  memcpy(out32le, w, 32);
 }
 static int g_force_general = 0;
 void hs_force_general_combine(int on) { g_force_general = on; }

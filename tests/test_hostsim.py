@@ -208,6 +208,18 @@ def test_hash_and_kdf(L, rnd):
     assert out.raw == o.g2_compressed(Qp)
 
 
+def test_inverse_of_small_denominator(L, rnd):
+    # D^-1 mod r by 64-bit Euclid + exact division (tc_threshold.h), the fast path's only inversion
+    L.hs_fr_inverse_of_small.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p]
+    ds = [1, 2, 3, 4, 6, 255, 2 ** 32 - 1, 2 ** 32, 2 ** 62, 2 ** 63 - 1, 2 ** 63 - 25] + [rnd.randrange(1, 2 ** 63) for _ in range(200)] + [rnd.randrange(1, 2 ** 20) for _ in range(100)]
+    for d in ds:
+        for neg in (0, 1):
+            out = buf(32)
+            L.hs_fr_inverse_of_small(d, neg, out)
+            want = pow(-d if neg else d, -1, o.R)
+            assert int.from_bytes(out.raw, "little") == want, (d, neg)
+
+
 def test_combine_fast_path_equals_general_path(L, rnd):
     """The small-index fast path ([D^-1](sum c_i S_i), tc_threshold.h) and the general Lagrange
     path give the same bytes; large / repeated indices fall back to the general path."""

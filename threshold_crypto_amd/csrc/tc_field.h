@@ -240,8 +240,20 @@ constexpr int FQ_MAX_BOUND_PRODUCT = 128;  // B_a * B_b allowed at a multiplicat
 
 #if defined(TC_COUNT_OPS)
 // host-only (tests/hostsim): multiplications / squarings executed, for the "ours M/unit"
-// column of DESIGN.md and bench.py's executed-MAC roofline
+// column of DESIGN.md and bench.py's executed-MAC roofline.  In the lane-pair build an Fq
+// operation INSIDE an Fq2 method is one lane's half of that method (counted once: "split"); an
+// Fq operation outside (inversions, square-root exponentiations, G1 work in a G2 kernel) is
+// executed by both lanes ("local", counted twice for a G2 kernel by tools/count_ops.py).
 inline uint64_t g_tc_mul_count = 0, g_tc_sqr_count = 0, g_tc_mul2_count = 0;
+inline uint64_t g_tc_split_mul_count = 0, g_tc_split_sqr_count = 0;
+inline int g_tc_split_depth = 0;
+struct TcSplitScope {
+  TcSplitScope() { g_tc_split_depth++; }
+  ~TcSplitScope() { g_tc_split_depth--; }
+};
+#define TC_SPLIT_SCOPE TcSplitScope tc_split_scope_
+#else
+#define TC_SPLIT_SCOPE
 #endif
 
 struct Fq;
@@ -558,6 +570,7 @@ TC_HD Fq fq_mul(const Fq& a, const Fq& b) {
   fq_mul_body<false>(a.l, b.l, r.l);
 #if defined(TC_COUNT_OPS)
   g_tc_mul_count++;
+  if (g_tc_split_depth) g_tc_split_mul_count++;
 #endif
 #endif
   r.set_range(0.f, 1.f);
@@ -579,6 +592,7 @@ TC_HD Fq fq_sqr(const Fq& a) {
   fq_mul_body<true>(a.l, a.l, r.l);
 #if defined(TC_COUNT_OPS)
   g_tc_sqr_count++;
+  if (g_tc_split_depth) g_tc_split_sqr_count++;
 #endif
 #endif
   r.set_range(0.f, 1.f);

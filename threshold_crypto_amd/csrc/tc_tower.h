@@ -111,14 +111,23 @@ struct Fq2 {
   }
 #endif
   // c0 = (c0 + c1)(c0 - c1), c1 = (2 c1) c0
-  TC_HD Fq2 sqr() const { return Fq2{(c0 + c1) * (c0 - c1), c1.dbl() * c0}; }
-  TC_HD Fq2 scale(const Fq& k) const { return Fq2{c0 * k, c1 * k}; }
+  TC_HD Fq2 sqr() const {
+    TC_SPLIT_SCOPE;
+    return Fq2{(c0 + c1) * (c0 - c1), c1.dbl() * c0};
+  }
+  TC_HD Fq2 scale(const Fq& k) const {
+    TC_SPLIT_SCOPE;
+    return Fq2{c0 * k, c1 * k};
+  }
   // times the non-residue (1 + u)
   TC_HD Fq2 mul_xi() const { return Fq2{c0 - c1, c0 + c1}; }
-  TC_HD Fq norm_fq() const { return c0.sqr() + c1.sqr(); }
+  TC_HD Fq norm_fq() const {
+    TC_SPLIT_SCOPE;
+    return c0.sqr() + c1.sqr();
+  }
   TC_HD_NOINLINE Fq2 inv() const {
-    Fq t = (c0.sqr() + c1.sqr()).inv();
-    return Fq2{c0 * t, -(c1 * t)};
+    const Fq t = norm_fq().inv();
+    return scale(t).conj();
   }
   TC_HD static Fq2 select(bool c, const Fq2& a, const Fq2& b) {
     return Fq2{Fq::select(c, a.c0, b.c0), Fq::select(c, a.c1, b.c1)};

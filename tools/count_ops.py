@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""Counts the Fq products / squarings each per-lane job body executes (host build of the device
-source with -DTC_COUNT_OPS).  Source of the EXECUTED table in bench.py and DESIGN.md 4.2."""
+"""Counts the limb multiply-adds each per-lane job body executes (host build of the device source
+with -DTC_COUNT_OPS).  Source of the EXECUTED table in bench.py and DESIGN.md.
+
+One 15x15 limb product or one Montgomery reduction is 225 v_mad:
+    Fq product 450, Fq squaring 345, one coefficient of an Fq2 product (two products, one
+    reduction, tc_field.h fq_mul2) 675.
+In a G2 kernel two lanes work on a job: operations inside Fq2 methods are split between them
+(counted once), Fq operations outside (inversions, square-root exponentiations) run on both lanes
+(counted twice).  G1 kernels run one lane per job."""
 import ctypes
 import os
 import random
@@ -18,9 +25,15 @@ L = ctypes.CDLL(lib)
 
 
 def cnt():
-    a, b = ctypes.c_uint64(), ctypes.c_uint64()
-    L.hs_op_counts(ctypes.byref(a), ctypes.byref(b), 1)
-    return a.value, b.value
+    a = (ctypes.c_uint64 * 5)()
+    L.hs_op_counts5(a, 1)
+    return tuple(a)
+
+
+def macs(c, lanes):
+    mul2, smul, ssqr, mul, sqr = c
+    local_mul, local_sqr = mul - smul, sqr - ssqr
+    return mul2 * 675 + smul * 450 + ssqr * 345 + lanes * (local_mul * 450 + local_sqr * 345)
 
 
 rnd = random.Random(1)
@@ -29,28 +42,34 @@ P2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
 P1 = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
 res = {}
 cnt()
-L.hs_g2_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g2_uncompressed(P2), buf(192)); res["g2_mul"] = cnt()
-L.hs_g1_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g1_uncompressed(P1), buf(96)); res["g1_mul"] = cnt()
+L.hs_g2_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g2_uncompressed(P2), buf(192)); res["g2_mul"] = (cnt(), 2)
+L.hs_g1_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g1_uncompressed(P1), buf(96)); res["g1_mul"] = (cnt(), 1)
 poly = [rnd.randrange(o.R) for _ in range(4)]
 ids = [1, 4, 6, 9]
 idx = (ctypes.c_uint64 * 4)(*ids)
 sh = b"".join(o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in ids)
 cnt()
-L.hs_combine_g2(3, idx, sh, buf(192)); res["combine_g2_t3_fast"] = cnt()
+L.hs_combine_g2(3, idx, sh, buf(192)); res["combine_g2_t3_fast"] = (cnt(), 2)
 L.hs_force_general_combine(1)
-L.hs_combine_g2(3, idx, sh, buf(192)); res["combine_g2_t3_general"] = cnt()
+L.hs_combine_g2(3, idx, sh, buf(192)); res["combine_g2_t3_general"] = (cnt(), 2)
 L.hs_force_general_combine(0)
 sh1 = b"".join(o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in ids)
-L.hs_combine_g1(3, idx, sh1, buf(96)); res["combine_g1_t3"] = cnt()
+L.hs_combine_g1(3, idx, sh1, buf(96)); res["combine_g1_t3_fast"] = (cnt(), 1)
+L.hs_force_general_combine(1)
+L.hs_combine_g1(3, idx, sh1, buf(96)); res["combine_g1_t3_general"] = (cnt(), 1)
+L.hs_force_general_combine(0)
 a = rnd.randrange(o.R)
 L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
-                   o.g2_uncompressed(o.E2.mul(P2, a))); res["pairing_check"] = cnt()
-hs = []
-for j in range(40):
+                   o.g2_uncompressed(o.E2.mul(P2, a))); res["pairing_check"] = (cnt(), 2)
+tot = [0] * 5
+N = 64
+for j in range(N):
     m = b"tc/msg" + j.to_bytes(8, "little")
-    L.hs_hash_g2(m, len(m), buf(192)); hs.append(cnt())
-res["hash_g2_avg40"] = (sum(h[0] for h in hs) // 40, sum(h[1] for h in hs) // 40)
-L.hs_decompress_g2(o.g2_compressed(P2), buf(192)); res["g2_decompress"] = cnt()
-L.hs_decompress_g1(o.g1_compressed(P1), buf(96)); res["g1_decompress"] = cnt()
-for k, (m, s) in res.items():
-    print("%-24s products %6d  squarings %5d  total %6d  v_mad %9d" % (k, m, s, m + s, m * 450 + s * 345))
+    L.hs_hash_g2(m, len(m), buf(192))
+    tot = [x + y for x, y in zip(tot, cnt())]
+res["hash_g2_avg%d" % N] = (tuple(x // N for x in tot), 2)
+L.hs_decompress_g2(o.g2_compressed(P2), buf(192)); res["g2_decompress"] = (cnt(), 2)
+L.hs_decompress_g1(o.g1_compressed(P1), buf(96)); res["g1_decompress"] = (cnt(), 1)
+print("%-26s %8s %8s %8s %8s %8s %12s" % ("job", "mul2", "split_m", "split_s", "all_mul", "all_sqr", "device v_mad"))
+for k, (c, lanes) in res.items():
+    print("%-26s %8d %8d %8d %8d %8d %12d" % ((k,) + tuple(c) + (macs(c, lanes),)))
