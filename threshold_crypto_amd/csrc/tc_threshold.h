@@ -53,12 +53,23 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
 // Share indices are node numbers, so the abscissae x_i = idx_i + 1 are small integers and the
 // Lagrange coefficients are ratios of SMALL integers:
 //     lambda_i = num_i / den_i,  num_i = prod_{j != i} x_j,  den_i = prod_{j != i} (x_j - x_i).
-// With D = prod_j den_j and the integers c_i = num_i * prod_{j != i} den_j (a few tens of bits),
+// With D = lcm_i |den_i| and the integers c_i = num_i * (D / den_i) (a few tens of bits),
 //     sum_i lambda_i S_i = [D^-1 mod r] ( sum_i c_i S_i ),
-// i.e. one short joint ladder over |c_i| followed by ONE full-size (GLS) multiplication,
+// i.e. one short joint ladder over |c_i| followed by ONE full-size (GLS / GLV) multiplication,
 // instead of t+1 full-size ones.  Same group element, same bytes.  Returns false -- caller
 // uses the general path -- when indices repeat (the reference's by-value filtering then
 // applies, src/lib.rs:758), are large, or a product leaves 63 bits.
+TC_HD uint64_t gcd_u64(uint64_t a, uint64_t b) {
+  TC_NOUNROLL while (wave_any(b != 0)) {
+    if (b != 0) {
+      const uint64_t t = a % b;
+      a = b;
+      b = t;
+    }
+  }
+  return a;
+}
+
 template <int K>
 TC_HD bool lagrange_small_coeffs(const uint64_t* idx, uint64_t* c_abs, bool* c_neg, uint64_t* d_abs, bool* d_neg) {
   int64_t x[K];
@@ -66,7 +77,8 @@ TC_HD bool lagrange_small_coeffs(const uint64_t* idx, uint64_t* c_abs, bool* c_n
     if (idx[i] >= 65535) return false;
     x[i] = (int64_t)idx[i] + 1;
   }
-  int64_t den[K];
+  uint64_t den[K];
+  bool den_neg[K];
   TC_UNROLL for (int i = 0; i < K; i++) {
     int64_t d = 1;
     TC_UNROLL for (int j = 0; j < K; j++) {
@@ -75,23 +87,27 @@ TC_HD bool lagrange_small_coeffs(const uint64_t* idx, uint64_t* c_abs, bool* c_n
       if (diff == 0) return false;
       if (__builtin_mul_overflow(d, diff, &d)) return false;
     }
-    den[i] = d;
+    den_neg[i] = d < 0;
+    den[i] = (uint64_t)(d < 0 ? -d : d);
   }
-  int64_t D = 1;
-  TC_UNROLL for (int i = 0; i < K; i++)
-    if (__builtin_mul_overflow(D, den[i], &D)) return false;
+  uint64_t D = 1;  // lcm of the denominators
   TC_UNROLL for (int i = 0; i < K; i++) {
-    int64_t c = 1;
+    const uint64_t g = gcd_u64(D, den[i]);
+    if (__builtin_mul_overflow(D / g, den[i], &D)) return false;
+    if (D >> 62) return false;
+  }
+  TC_UNROLL for (int i = 0; i < K; i++) {
+    uint64_t c = D / den[i];
     TC_UNROLL for (int j = 0; j < K; j++) {
       if (j == i) continue;
-      if (__builtin_mul_overflow(c, x[j], &c)) return false;
-      if (__builtin_mul_overflow(c, den[j], &c)) return false;
+      if (__builtin_mul_overflow(c, (uint64_t)x[j], &c)) return false;
     }
-    c_neg[i] = c < 0;
-    c_abs[i] = (uint64_t)(c < 0 ? -c : c);
+    if (c >> 63) return false;
+    c_neg[i] = den_neg[i];
+    c_abs[i] = c;
   }
-  *d_neg = D < 0;
-  *d_abs = (uint64_t)(D < 0 ? -D : D);
+  *d_neg = false;
+  *d_abs = D;
   return true;
 }
 
