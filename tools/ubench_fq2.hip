@@ -13,10 +13,23 @@ using namespace tc;
 #define ITERS 2000
 #endif
 
+// one lane per Fq2 value: Karatsuba over three fq_mul_call (the r01_c build's Fq2)
+struct S2 {
+  Fq c0, c1;
+  __device__ __forceinline__ S2 operator*(const S2& b) const {
+    Fq aa = c0 * b.c0;
+    Fq bb = c1 * b.c1;
+    Fq o = (c0 + c1) * (b.c0 + b.c1);
+    return S2{aa - bb, o - aa - bb};
+  }
+  __device__ __forceinline__ S2 sqr() const { return S2{(c0 + c1) * (c0 - c1), (c0 * c1).dbl()}; }
+  __device__ __forceinline__ S2 operator+(const S2& b) const { return S2{c0 + b.c0, c1 + b.c1}; }
+};
+
 __global__ __launch_bounds__(256) void k_single(const int32_t* in, int32_t* out, int jobs) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= jobs) return;
-  Fq2 x, y;
+  S2 x, y;
   for (int i = 0; i < 15; i++) {
     x.c0.l[i] = in[(j * 4 + 0) * 15 + i];
     x.c1.l[i] = in[(j * 4 + 1) * 15 + i];
