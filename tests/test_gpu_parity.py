@@ -373,3 +373,97 @@ def test_not_enough_shares_in_device_mode(engine, rnd):
     out, st = engine.combine_g2(3, idx, sh)
     engine.sync()
     assert st.cpu().tolist() == [1] * 5
+
+
+def test_heterogeneous_waves_every_job_checked(engine, rnd):
+    """Waves whose lanes take different paths (message lengths across the SHA3 rate and the 64-byte
+    switch, rejection-sampling attempts, valid / invalid / infinity operands, fast and general
+    combine paths side by side) -- EVERY job compared with the C oracle.  Guards the lane-pair
+    kernels against divergence-dependent corruption (profiles/r01_d_pair_notes.md)."""
+    import c_oracle
+    c_oracle.load()
+    # hash_g2: 130 messages, lengths 0..289
+    msgs = [bytes(rnd.randrange(256) for _ in range((j * 37) % 290)) for j in range(130)]
+    flat, off = pack_messages(msgs)
+    out = engine.hash_g2(flat, off)
+    for j, m in enumerate(msgs):
+        assert bytes(out[j]) == c_oracle.hash_g2(m), j
+    # hash_g1_g2: valid, off-curve and infinity G1 operands, lengths 0..130
+    B = 70
+    g1 = np.zeros((B, 96), np.uint8)
+    msgs = []
+    for j in range(B):
+        P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        enc = bytearray(o.g1_uncompressed(None if j % 11 == 5 else P))
+        if j % 7 == 3:
+            enc[95] ^= 1  # leaves the curve
+        g1[j] = u8(enc)
+        msgs.append(bytes(rnd.randrange(256) for _ in range((j * 13) % 131)))
+    flat, off = pack_messages(msgs)
+    out, st = engine.hash_g1_g2(g1, flat, off)
+    for j in range(B):
+        rc, want = c_oracle.hash_g1_g2(bytes(g1[j]), msgs[j])
+        assert (st[j] != 0) == (rc != 0), j
+        if rc == 0:
+            assert bytes(out[j]) == want, j
+    x, stx = engine.xor_with_hash(g1, flat, off)
+    for j in range(B):
+        rc, want = c_oracle.xor_with_hash(bytes(g1[j]), msgs[j])
+        assert (stx[j] != 0) == (rc != 0), j
+        if rc == 0:
+            assert bytes(x[int(off[j]): int(off[j + 1])]) == want, j
+    # combine_g2, t = 3: fast path, large indices, duplicate indices and an invalid share in one wave
+    t, N = 3, 12
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    H = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    idx = np.zeros((B, t + 1), np.uint64)
+    shares = np.zeros((B, t + 1, 192), np.uint8)
+    cache = {}
+    for j in range(B):
+        ids = sorted(rnd.sample(range(N), t + 1))
+        if j % 5 == 0:
+            ids = [i + (1 << 20) for i in ids]
+        elif j % 5 == 1:
+            ids = [ids[0], ids[0], ids[2], ids[3]]
+        idx[j] = ids
+        for k, i in enumerate(ids):
+            if i not in cache:
+                cache[i] = u8(o.g2_uncompressed(o.E2.mul(H, o.poly_evaluate(poly, (i + 1) % o.R))))
+            shares[j, k] = cache[i]
+        if j % 9 == 4:
+            shares[j, 2, 191] ^= 1
+    got, st = engine.combine_g2(t, idx, shares)
+    for j in range(B):
+        rc, want = c_oracle.combine_g2(t, [int(i) for i in idx[j]], [bytes(shares[j, k]) for k in range(t + 1)])
+        assert (st[j] != 0) == (rc != 0), (j, st[j], rc)
+        if rc == 0:
+            assert bytes(got[j]) == want, j
+    # the same mix in G1 (threshold decryption's combiner)
+    U = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    sh1 = np.zeros((B, t + 1, 96), np.uint8)
+    cache = {}
+    for j in range(B):
+        for k, i in enumerate(int(i) for i in idx[j]):
+            if i not in cache:
+                cache[i] = u8(o.g1_uncompressed(o.E1.mul(U, o.poly_evaluate(poly, (i + 1) % o.R))))
+            sh1[j, k] = cache[i]
+    got1, st1 = engine.combine_g1(t, idx, sh1)
+    for j in range(B):
+        rc, want = c_oracle.combine_g1(t, [int(i) for i in idx[j]], [bytes(sh1[j, k]) for k in range(t + 1)])
+        assert (st1[j] != 0) == (rc != 0), j
+        if rc == 0:
+            assert bytes(got1[j]) == want, j
+    # pairing checks: true / false / infinity / invalid encodings interleaved
+    a_ = np.zeros((B, 96), np.uint8); b_ = np.zeros((B, 192), np.uint8)
+    c_ = np.zeros((B, 96), np.uint8); d_ = np.zeros((B, 192), np.uint8)
+    for j in range(B):
+        xs, ys = rnd.randrange(1, o.R), rnd.randrange(1, o.R)
+        a_[j] = u8(o.g1_uncompressed(None if j % 13 == 6 else o.E1.mul(o.G1_GEN, xs)))
+        b_[j] = u8(o.g2_uncompressed(o.E2.mul(o.G2_GEN, ys)))
+        c_[j] = u8(o.g1_uncompressed(o.G1_GEN))
+        d_[j] = u8(o.g2_uncompressed(None if j % 17 == 8 else o.E2.mul(o.G2_GEN, (xs * ys + (j % 3 == 1)) % o.R)))
+        if j % 19 == 9:
+            d_[j, 100] ^= 4
+    ok = engine.pairing_check(a_, b_, c_, d_)
+    for j in range(B):
+        assert int(ok[j]) == int(c_oracle.pairing_check(bytes(a_[j]), bytes(b_[j]), bytes(c_[j]), bytes(d_[j])) == 1), j

@@ -86,11 +86,12 @@ def build(force=False, jobs=None, timeout=1500, verbose=True):
     os.replace(LIB + ".tmp", LIB)
     with open(stamp, "w") as f:
         f.write(want)
-    # drop stale objects (default build only; experiment builds share the directory)
+    # drop stale objects (default build only; experiment builds share the directory and simply
+    # recompile): the directory travels to the GPU box with every gpurun snapshot
     if not SUFFIX:
         keep = {os.path.basename(o) for o in objs.values()}
         for name in os.listdir(BUILD):
-            if name.endswith(".o") and name not in keep and os.path.getmtime(os.path.join(BUILD, name)) < time.time() - 86400:
+            if name.endswith(".o") and name not in keep:
                 os.remove(os.path.join(BUILD, name))
     if verbose:
         print("[tc build] linked", LIB, flush=True)
