@@ -34,6 +34,13 @@ int hs_fq_inv(const uint8_t* a, uint8_t* out) {
   fq_to_be48(x.inv(), out);
   return 0;
 }
+int hs_fq_inv_both(const uint8_t* a, uint8_t* out_gcd, uint8_t* out_fermat) {
+  Fq x;
+  if (!fq_from_be48(a, false, x)) return -1;
+  fq_to_be48(x.inv(), out_gcd);
+  fq_to_be48(fq_inv_fermat(x), out_fermat);
+  return 0;
+}
 int hs_fq_addsub(const uint8_t* a, const uint8_t* b, uint8_t* sum, uint8_t* diff, uint8_t* neg) {
   Fq x, y;
   if (!fq_from_be48(a, false, x) || !fq_from_be48(b, false, y)) return -1;

@@ -97,6 +97,18 @@ def test_legendre_symbol_by_binary_jacobi(L, rnd):
         assert L.hs_fq_legendre(be(a)) == (0 if a == 0 else (1 if e == 1 else -1)), hex(a)
 
 
+def test_inverse_by_binary_gcd(L, rnd):
+    # Fq::inv (binary extended GCD + two Montgomery products for the power of two) against Fermat
+    # and Python; edge values exercise long runs of trailing zeros and both ends of the k range
+    vals = [0, 1, 2, 3, 4, o.Q - 1, o.Q - 2, (o.Q - 1) // 2, (o.Q + 1) // 2, 1 << 380, 1 << 64, (1 << 64) + 1, 1 << 128, (1 << 320) - 1,
+            pow(2, -1, o.Q), pow(1 << 200, -1, o.Q), 3 << 370] + [rnd.randrange(o.Q) for _ in range(500)] + [rnd.randrange(1 << 70) for _ in range(50)]
+    for a in vals:
+        g, f = buf(48), buf(48)
+        assert L.hs_fq_inv_both(be(a), g, f) == 0
+        want = pow(a, o.Q - 2, o.Q)
+        assert int.from_bytes(g.raw, "big") == want == int.from_bytes(f.raw, "big"), hex(a)
+
+
 def test_fq2_sqrt(L, rnd):
     for _ in range(8):
         a = (rnd.randrange(o.Q), rnd.randrange(o.Q))

@@ -394,7 +394,7 @@ struct Fq {
   TC_HD bool is_zero() const { return maybe_zero() && is_zero_full(); }
   TC_HD bool operator==(const Fq& b) const { return (*this - b).is_zero(); }
   TC_HD bool operator!=(const Fq& b) const { return !(*this == b); }
-  TC_HD_NOINLINE Fq inv() const;  // Fermat a^(p-2); 0 -> 0
+  TC_HD_NOINLINE Fq inv() const;  // 0 -> 0
   TC_HD static Fq from_canonical(const uint32_t* words12);
   TC_HD void to_canonical(uint32_t* words12) const;
   TC_HD static Fq from_mont384(const uint32_t* words12);
@@ -640,8 +640,109 @@ TC_HD_NOINLINE bool Fq::is_zero_full() const {
   return z == 0 || e == 0;
 }
 
+// Fermat inverse a^(p-2): ~381 squarings + ~110 products.  Kept for the cross-check in
+// tests/hostsim; the library inverts with Fq::inv() below.
+TC_HD_NOINLINE Fq fq_inv_fermat(const Fq& a) {
+  return field_pow_fixed(a.norm(), [](int i) { return FQ_P_MINUS_2[i]; }, 381);
+}
+
+TC_HD void words12_to_limbs26(const uint32_t* w, int32_t* l);
+
+// Inverse by the binary extended GCD with Kaliski's bookkeeping ("almost Montgomery inverse"),
+// on the canonical integer a as 6 x u64:
+//     invariants   a r = -u 2^k,   a s = v 2^k  (mod p),   u s + v r = p   (so r, s <= p)
+//     u > v (both odd):  u = (u - v) >> j,  r = r + s,  s <<= j      (j = trailing zeros, k += j)
+//     v > u           :  v = (v - u) >> j,  s = s + r,  r <<= j
+//     u = v = 1       :  s = a^-1 2^k
+// ~380 subtract-and-shift rounds of ~280 VALU instructions against 381 + 110 field
+// multiplications: 2.3x cheaper, and every job ends with one inversion (both lanes of a pair).
+// Wave-uniform loop (tc_common.h wave_any), branch-free body.  0 -> 0.
 TC_HD_NOINLINE Fq Fq::inv() const {
-  return field_pow_fixed(this->norm(), [](int i) { return FQ_P_MINUS_2[i]; }, 381);
+  uint32_t w[12];
+  this->to_canonical(w);
+  uint64_t u[6], v[6], r[6], s[6];
+  uint64_t any = 0;
+  TC_UNROLL for (int i = 0; i < 6; i++) {
+    u[i] = (uint64_t)FQ_P[2 * i] | ((uint64_t)FQ_P[2 * i + 1] << 32);
+    v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    r[i] = 0;
+    s[i] = (i == 0) ? 1 : 0;
+    any |= v[i];
+  }
+  const bool nonzero = any != 0;
+  uint32_t k = 0;
+  bool busy = nonzero;
+  TC_NOUNROLL while (wave_any(busy)) {
+    if (!busy) continue;
+    const bool ue = (u[0] & 1ull) == 0, ve = (v[0] & 1ull) == 0;
+    const bool odd2 = !ue && !ve;
+    uint64_t d1[6], d2[6], rs[6];  // u - v, v - u, r + s
+    uint64_t b1 = 0, b2 = 0, c = 0, nz = 0;
+    TC_UNROLL for (int i = 0; i < 6; i++) {
+      const uint64_t t1 = u[i] - v[i];
+      const uint64_t n1 = (uint64_t)(u[i] < v[i]) | (uint64_t)(t1 < b1);
+      d1[i] = t1 - b1;
+      b1 = n1;
+      const uint64_t t2 = v[i] - u[i];
+      const uint64_t n2 = (uint64_t)(v[i] < u[i]) | (uint64_t)(t2 < b2);
+      d2[i] = t2 - b2;
+      b2 = n2;
+      const uint64_t t3 = r[i] + s[i];
+      const uint64_t n3 = (uint64_t)(t3 < r[i]);
+      rs[i] = t3 + c;
+      c = n3 | (uint64_t)(rs[i] < t3);
+      nz |= d1[i];
+    }
+    const bool finished = odd2 && nz == 0;       // u == v (== 1)
+    const bool upd_u = ue || (odd2 && b1 == 0);  // otherwise v is the one that changes
+    // the value that gets its trailing zeros stripped, and the coefficient that is shifted left
+    uint64_t x[6], y[6];
+    TC_UNROLL for (int i = 0; i < 6; i++) {
+      x[i] = upd_u ? (ue ? u[i] : d1[i]) : (ve ? v[i] : d2[i]);
+      y[i] = upd_u ? s[i] : r[i];
+    }
+    const int j = x[0] ? __builtin_ctzll(x[0]) : 63;  // >= 1; a longer run of zeros takes another round
+    TC_UNROLL for (int i = 0; i < 5; i++) x[i] = (x[i] >> j) | (x[i + 1] << (64 - j));
+    x[5] >>= j;
+    TC_UNROLL for (int i = 5; i > 0; i--) y[i] = (y[i] << j) | (y[i - 1] >> (64 - j));
+    y[0] <<= j;
+    if (!finished) {
+      TC_UNROLL for (int i = 0; i < 6; i++) {
+        const uint64_t ri = r[i], si = s[i];
+        u[i] = upd_u ? x[i] : u[i];
+        v[i] = upd_u ? v[i] : x[i];
+        r[i] = upd_u ? (odd2 ? rs[i] : ri) : y[i];
+        s[i] = upd_u ? y[i] : (odd2 ? rs[i] : si);
+      }
+      k += (uint32_t)j;
+    }
+    busy = !finished;
+  }
+  // s = a^-1 2^k, s <= p.  Plain limbs of s, then the two products.
+  uint32_t sw[12];
+  TC_UNROLL for (int i = 0; i < 6; i++) {
+    sw[2 * i] = (uint32_t)s[i];
+    sw[2 * i + 1] = (uint32_t)(s[i] >> 32);
+  }
+  Fq sp, pw;
+  words12_to_limbs26(sw, sp.l);
+  sp.set_range(0.f, 1.f);
+  sp.set_val(1.f);
+  // three Montgomery products take out 2^k and put in R:  s 2^e1 2^e2 2^790 / R^3 = s 2^(390-k)
+  // with e1 + e2 = 770 - k  (0 <= k <= 762), each a single-bit limb vector below 2^390
+  const uint32_t e = 770u - k;
+  const uint32_t e1 = e > 388u ? 388u : e, e2 = e - e1;  // 2^388 < 160 p: inside the multiplier's value bound
+  Fq pw2;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    pw.l[i] = ((uint32_t)i == e1 / 26u) ? (int32_t)(1u << (e1 % 26u)) : 0;
+    pw2.l[i] = ((uint32_t)i == e2 / 26u) ? (int32_t)(1u << (e2 % 26u)) : 0;
+  }
+  pw.set_range(0.f, 0.5f);
+  pw.set_val(160.f);
+  pw2.set_range(0.f, 0.5f);
+  pw2.set_val(160.f);
+  const Fq out = fq_mul(fq_mul(fq_mul(sp, pw), pw2), Fq::from_limbs(FQ26_POW2_790));
+  return Fq::select(nonzero, out, Fq::zero());
 }
 
 // 12 canonical u32 words (an integer < 2^384) -> 15 plain 26-bit limbs
