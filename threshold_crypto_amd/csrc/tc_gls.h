@@ -24,11 +24,11 @@ TC_HD Fq2 psi_cy() { return Fq2::make(Fq::from_limbs(PSI_CY_C0), Fq::from_limbs(
 
 TC_HD G2Affine g2_psi(const G2Affine& p) {
   if (p.inf) return p;
-  return G2Affine{(p.x.conj() * psi_cx()).reduce_value(), (p.y.conj() * psi_cy()).reduce_value(), false};
+  return G2Affine{(p.x.conj() * psi_cx()).norm(), (p.y.conj() * psi_cy()).norm(), false};
 }
 
 TC_HD_NOINLINE G2Jac g2_psi(const G2Jac& p) {
-  return G2Jac{(p.x.conj() * psi_cx()).reduce_value(), (p.y.conj() * psi_cy()).reduce_value(), p.z.conj().norm()};
+  return G2Jac{(p.x.conj() * psi_cx()).norm(), (p.y.conj() * psi_cy()).norm(), p.z.conj().norm()};
 }
 
 // k (8 little-endian u32 words, < r < |x|^4) -> four base-|x| digits.  Binary long division on

@@ -21,18 +21,18 @@ TC_MILLER_ATTR LineCoeffs miller_doubling_step(G2Jac& r) {
   Fq2 tmp0 = r.x.sqr();
   Fq2 tmp1 = r.y.sqr();
   Fq2 tmp2 = tmp1.sqr();
-  Fq2 tmp3 = ((tmp1 + r.x).sqr() - tmp0 - tmp2).dbl().reduce_value();
+  Fq2 tmp3 = ((tmp1 + r.x).sqr() - tmp0 - tmp2).dbl().norm();
   Fq2 tmp4 = tmp0.dbl() + tmp0;
   Fq2 tmp6 = r.x + tmp4;
   Fq2 tmp5 = tmp4.sqr();
   Fq2 zsq = r.z.sqr();
   Fq2 nx = (tmp5 - tmp3.dbl()).reduce_value();
-  Fq2 nz = ((r.z + r.y).sqr() - tmp1 - zsq).reduce_value();
-  Fq2 ny = ((tmp3 - nx) * tmp4 - tmp2.dbl().dbl().dbl()).reduce_value();
+  Fq2 nz = ((r.z + r.y).sqr() - tmp1 - zsq).norm();
+  Fq2 ny = ((tmp3 - nx) * tmp4 - tmp2.dbl().dbl().dbl()).norm();
   LineCoeffs l;
-  l.c1 = (-((tmp4 * zsq).dbl())).reduce_value();
-  l.c2 = (tmp6.sqr() - tmp0 - tmp5 - tmp1.dbl().dbl()).reduce_value();
-  l.c0 = (nz * zsq).dbl().reduce_value();
+  l.c1 = (-((tmp4 * zsq).dbl())).norm();
+  l.c2 = (tmp6.sqr() - tmp0 - tmp5 - tmp1.dbl().dbl()).norm();
+  l.c0 = (nz * zsq).dbl().norm();
   r.x = nx;
   r.y = ny;
   r.z = nz;
@@ -47,21 +47,21 @@ TC_MILLER_ATTR LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
   Fq2 t1 = ((q.y + r.z).sqr() - ysq - zsq) * zsq;
   Fq2 t2 = t0 - r.x;
   Fq2 t3 = t2.sqr();
-  Fq2 t4 = t3.dbl().dbl().reduce_value();
+  Fq2 t4 = t3.dbl().dbl().norm();
   Fq2 t5 = t4 * t2;
-  Fq2 t6 = (t1 - r.y.dbl()).reduce_value();
+  Fq2 t6 = (t1 - r.y.dbl()).norm();
   Fq2 t9 = t6 * q.x;
   Fq2 t7 = t4 * r.x;
-  Fq2 nx = (t6.sqr() - t5 - t7.dbl()).reduce_value();
-  Fq2 nz = ((r.z + t2).sqr() - zsq - t3).reduce_value();
+  Fq2 nx = (t6.sqr() - t5 - t7.dbl()).norm();
+  Fq2 nz = ((r.z + t2).sqr() - zsq - t3).norm();
   Fq2 t10 = q.y + nz;
   Fq2 t8 = (t7 - nx) * t6;
-  Fq2 ny = (t8 - (r.y * t5).dbl()).reduce_value();
+  Fq2 ny = (t8 - (r.y * t5).dbl()).norm();
   t10 = t10.sqr() - ysq - nz.sqr();
-  t9 = (t9.dbl() - t10).reduce_value();
+  t9 = (t9.dbl() - t10).norm();
   LineCoeffs l;
   l.c0 = nz.dbl();
-  l.c1 = (-t6).dbl().reduce_value();
+  l.c1 = (-t6).dbl().norm();
   l.c2 = t9;
   r.x = nx;
   r.y = ny;

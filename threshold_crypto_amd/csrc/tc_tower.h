@@ -189,7 +189,7 @@ struct Fq6 {
     Fq2 t2 = c1.sqr() - c0 * c2;
     Fq2 d = c0 * t0 + (c2 * t1 + c1 * t2).mul_xi();
     Fq2 di = d.inv();
-    return Fq6{t0 * di, t1 * di, t2 * di}.reduce_value();
+    return Fq6{t0 * di, t1 * di, t2 * di}.norm();
   }
 };
 
@@ -215,14 +215,14 @@ struct Fq12 {
   TC_FQ12_ATTR Fq12 sqr() const {
     Fq6 ab = c0 * c1;
     Fq6 t = (c0 + c1) * (c0 + c1.mul_by_v()) - ab - ab.mul_by_v();
-    return Fq12{t, ab + ab}.reduce_value();
+    return Fq12{t, ab + ab}.norm();
   }
   TC_HD Fq12 conj() const { return Fq12{c0, -c1}; }
   TC_HD Fq12 norm() const { return Fq12{c0.norm(), c1.norm()}; }
   TC_HD Fq12 reduce_value() const { return Fq12{c0.reduce_value(), c1.reduce_value()}; }
   TC_HD_NOINLINE Fq12 inv() const {
     Fq6 t = (c0.sqr() - c1.sqr().mul_by_v()).inv();
-    return Fq12{c0 * t, -(c1 * t)}.reduce_value();
+    return Fq12{c0 * t, -(c1 * t)}.norm();
   }
   // sparse multiplication by (d0 + d1 v) + (d4 v) w -- the Miller-loop line shape
   TC_FQ12_ATTR Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
@@ -232,7 +232,7 @@ struct Fq12 {
     Fq12 r;
     r.c1 = (c1 + c0).mul_by_01(d0, o) - aa - bb;
     r.c0 = bb.mul_by_v() + aa;
-    return r.reduce_value();
+    return r.norm();
   }
   // a^(q^k), k in {1,2,3}
   TC_HD_NOINLINE Fq12 frobenius(int k) const {
@@ -244,7 +244,7 @@ struct Fq12 {
     r.c1.c0 = (cj ? c1.c0.conj() : c1.c0) * frob_coeff(k, 1);
     r.c1.c1 = (cj ? c1.c1.conj() : c1.c1) * frob_coeff(k, 3);
     r.c1.c2 = (cj ? c1.c2.conj() : c1.c2) * frob_coeff(k, 5);
-    return r.reduce_value();
+    return r.norm();
   }
   // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part
   // of the final exponentiation): 9 Fq2 squarings' worth instead of 2 Fq6 mul.
