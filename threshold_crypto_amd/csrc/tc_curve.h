@@ -120,6 +120,27 @@ TC_HD_NOINLINE Affine<F> jac_to_affine(const Jac<F>& p) {
   return Affine<F>{p.x * zi2, p.y * zi2 * zi, false};
 }
 
+// Affine coordinates of n <= 16 Jacobian points with ONE field inversion (Montgomery's trick).
+// Points at infinity stay flagged and do not poison the product.
+template <class F>
+TC_HD void jac_batch_to_affine(const Jac<F>* in, Affine<F>* out, int n) {
+  F pre[16];
+  bool inf[16];
+  F acc = F::one();
+  TC_NOUNROLL for (int i = 0; i < n; i++) {
+    inf[i] = in[i].is_inf();
+    pre[i] = acc;
+    acc = acc * F::select(inf[i], F::one(), in[i].z);
+  }
+  F inv = acc.inv();
+  TC_NOUNROLL for (int i = n - 1; i >= 0; i--) {
+    const F zi = inv * pre[i];
+    inv = inv * F::select(inf[i], F::one(), in[i].z);
+    const F zi2 = zi.sqr();
+    out[i] = Affine<F>{coord_out(in[i].x * zi2), coord_out(in[i].y * zi2 * zi), inf[i]};
+  }
+}
+
 // k * P for a scalar given as nwords little-endian u32 words (bits above nbits are zero).
 // MSB-first double-and-add with mixed additions (the CurveAffine::mul shape of group 0.6).
 // Control flow depends on the scalar: use when the scalar is wave-uniform (shared secret

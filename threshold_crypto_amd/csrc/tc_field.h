@@ -472,6 +472,20 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
       s1 += (int64_t)z[i] * w[k - i];
     }
 #endif
+#if defined(TC_MUL2_ONE_CHAIN)
+    if (k < N) {
+      TC_UNROLL for (int i = 0; i < k; i++) s1 += (int64_t)m[i] * FQ26_P[k - i];
+      int64_t s = s1;
+      m[k] = (int32_t)(((uint32_t)s * FQ26_INV) & (uint32_t)FQ_MASK);
+      s += (int64_t)m[k] * FQ26_P[0];
+      carry = s >> FQ_RADIX;
+    } else {
+      TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)m[i] * FQ26_P[k - i];
+      out[k - N] = (int32_t)((uint32_t)s1 & (uint32_t)FQ_MASK);
+      carry = s1 >> FQ_RADIX;
+    }
+    (void)s2;
+#else
     if (k < N) {
       TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
       int64_t s = s1 + s2;
@@ -484,6 +498,7 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
+#endif
   }
   out[N - 1] = (int32_t)carry;
 }

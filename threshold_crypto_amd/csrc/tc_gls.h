@@ -56,38 +56,64 @@ TC_HD void gls_decompose(const uint32_t* k, uint64_t* d) {
   d[3] = n[0];  // k < r < |x|^4  =>  the last quotient fits one word
 }
 
-// sum_i d_i * B_i for four Jacobian base points and 64-bit scalars: joint double-and-add over
-// a 15-entry subset-sum table (per-lane scratch).
-TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Jac* base, const uint64_t* d) {
-  G2Jac tbl[16];
-  tbl[0] = G2Jac::infinity();
-  TC_NOUNROLL for (int m = 1; m < 16; m++) {
-    const int low = __builtin_ctz((unsigned)m);
-    const int rest = m & (m - 1);
-    tbl[m] = rest ? jac_add(tbl[rest], base[low]) : base[low];
+// sum_i d_i * B_i for four AFFINE base points and 64-bit scalars: joint double-and-add over a
+// 15-entry subset-sum table.  The 11 proper sums are brought back to affine with one shared
+// inversion (jac_batch_to_affine), so every addition of the 64-step ladder is a mixed one
+// (7M + 4S instead of 11M + 5S in Fq2): about a fifth fewer multiply-adds for the whole
+// multiplication, and a table of two coordinates per entry instead of three.
+TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Affine* base, const uint64_t* d) {
+  G2Affine tbl[16];
+  {
+    G2Jac sums[11];
+    G2Affine sums_aff[11];
+    int slot[16];
+    int ns = 0;
+    TC_NOUNROLL for (int m = 1; m < 16; m++) {
+      const int low = __builtin_ctz((unsigned)m);
+      const int rest = m & (m - 1);
+      if (!rest) {
+        tbl[m] = base[low];
+        slot[m] = -1;
+      } else {
+        const int rs = slot[rest];
+        const G2Jac prev = (rs < 0) ? G2Jac::from_affine(tbl[rest]) : sums[rs];
+        sums[ns] = jac_add_mixed(prev, base[low]);
+        slot[m] = ns++;
+      }
+    }
+    jac_batch_to_affine(sums, sums_aff, 11);
+    TC_NOUNROLL for (int m = 3; m < 16; m++)
+      if (slot[m] >= 0) tbl[m] = sums_aff[slot[m]];
   }
   G2Jac acc = G2Jac::infinity();
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((d[0] >> bit) & 1) | ((uint32_t)((d[1] >> bit) & 1) << 1) |
                        ((uint32_t)((d[2] >> bit) & 1) << 2) | ((uint32_t)((d[3] >> bit) & 1) << 3);
-    if (m) acc = jac_add(acc, tbl[m]);
+    if (m) acc = jac_add_mixed(acc, tbl[m]);
   }
   return acc;
 }
 
-// [k] P for P in G2 (the order-r subgroup), k < r given as 8 LE u32 words
-TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) {
-  uint64_t d[4];
-  gls_decompose(k, d);
-  G2Jac base[4];
+// the four psi-images the digits multiply:  P, -psi(P), psi^2(P), -psi^3(P)
+TC_HD void g2_gls_bases(const G2Affine& p, G2Affine* base) {
   base[0] = p;
   base[1] = g2_psi(p);
   base[2] = g2_psi(base[1]);
-  base[3] = jac_neg(g2_psi(base[2]));
-  base[1] = jac_neg(base[1]);
+  base[3] = g2_psi(base[2]);
+  base[1].y = -base[1].y;
+  base[3].y = -base[3].y;
+}
+
+// [k] P for P in G2 (the order-r subgroup), k < r given as 8 LE u32 words
+TC_HD G2Jac g2_mul_gls(const G2Affine& p, const uint32_t* k) {
+  uint64_t d[4];
+  gls_decompose(k, d);
+  G2Affine base[4];
+  g2_gls_bases(p, base);
   return g2_joint_mul4(base, d);
 }
+TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) { return g2_mul_gls(jac_to_affine(p), k); }
 
 // [|x|] P by the 64-bit ladder (|x| has Hamming weight 6: 63 doublings, 5 additions)
 TC_HD_NOINLINE G2Jac g2_mul_by_x_abs(const G2Jac& p) {
@@ -111,12 +137,8 @@ TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa) {
   t3 = jac_add(t3, t2);
   t3 = jac_add(t3, jac_neg(t1));
   t3 = jac_add(t3, jac_neg(p));                      // = [3(x^2-1) h2] P, in G2
-  G2Jac base[4];
-  base[0] = t3;
-  base[1] = g2_psi(t3);
-  base[2] = g2_psi(base[1]);
-  base[3] = jac_neg(g2_psi(base[2]));
-  base[1] = jac_neg(base[1]);
+  G2Affine base[4];
+  g2_gls_bases(jac_to_affine(t3), base);
   return g2_joint_mul4(base, G2_COFACTOR_FIX_DIGITS);
 }
 

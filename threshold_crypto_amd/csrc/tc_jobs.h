@@ -45,7 +45,7 @@ TC_HD Jac<Fq> point_mul_scalar(const Affine<Fq>& p, const uint32_t* k) { return 
 TC_HD Jac<Fq> point_mul_scalar(const Jac<Fq>& p, const uint32_t* k) { return g1_mul_glv(p, k); }
 TC_HD Jac<Fq2> point_mul_scalar(const Jac<Fq2>& p, const uint32_t* k) { return g2_mul_gls(p, k); }
 TC_HD Jac<Fq2> point_mul_scalar(const Affine<Fq2>& p, const uint32_t* k) {
-  return g2_mul_gls(G2Jac::from_affine(p), k);
+  return g2_mul_gls(p, k);
 }
 
 // out = fr * pt           (CurveAffine::mul: sign_g2 src/lib.rs:373, decrypt_share :461)
