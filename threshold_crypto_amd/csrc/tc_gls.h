@@ -170,42 +170,26 @@ TC_HD void glv_decompose(const uint32_t* k, tc_u128* k1, tc_u128* k2) {
   *k2 = q;
 }
 
-// [k] P for P in G1, k < r
+// [k] P for P in G1, k < r: joint 128-step ladder over the affine table {P, -phi(P), P - phi(P)}
 TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   if (p.inf) return G1Jac::infinity();
   tc_u128 k1, k2;
   glv_decompose(k, &k1, &k2);
-  G1Affine q = g1_phi(p);
-  q.y = -q.y;  // -phi(P) = [x^2] P
-  const G1Jac pq = jac_add_mixed(G1Jac::from_affine(p), q);
-  G1Jac acc = G1Jac::infinity();
-  TC_NOUNROLL for (int bit = 127; bit >= 0; bit--) {
-    acc = jac_dbl(acc);
-    const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
-    if (m == 1) acc = jac_add_mixed(acc, p);
-    else if (m == 2) acc = jac_add_mixed(acc, q);
-    else if (m == 3) acc = jac_add(acc, pq);
-  }
-  return acc;
-}
-
-// [k] P for a Jacobian P in G1 (the share combiner's final [D^-1] step): same decomposition, full additions
-TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) {
-  tc_u128 k1, k2;
-  glv_decompose(k, &k1, &k2);
-  G1Jac tbl[4];
-  tbl[0] = G1Jac::infinity();
+  G1Affine tbl[4];
   tbl[1] = p;
-  tbl[2] = G1Jac{(p.x * Fq::from_limbs(G1_BETA)).norm(), -p.y, p.z};  // -phi(P) = [x^2] P
-  tbl[3] = jac_add(tbl[1], tbl[2]);
+  tbl[2] = g1_phi(p);
+  tbl[2].y = -tbl[2].y;  // -phi(P) = [x^2] P
+  tbl[3] = jac_to_affine(jac_add_mixed(G1Jac::from_affine(p), tbl[2]));
   G1Jac acc = G1Jac::infinity();
   TC_NOUNROLL for (int bit = 127; bit >= 0; bit--) {
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
-    if (m) acc = jac_add(acc, tbl[m]);
+    if (m) acc = jac_add_mixed(acc, tbl[m]);
   }
   return acc;
 }
+// the same for a Jacobian P (the share combiner's final [D^-1] step)
+TC_HD G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) { return g1_mul_glv(jac_to_affine(p), k); }
 
 // [|x|] P on G1 by the 64-bit ladder
 TC_HD_NOINLINE G1Jac g1_mul_by_x_abs(const G1Jac& p) {
