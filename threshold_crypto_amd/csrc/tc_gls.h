@@ -113,7 +113,25 @@ TC_HD G2Jac g2_mul_gls(const G2Affine& p, const uint32_t* k) {
   g2_gls_bases(p, base);
   return g2_joint_mul4(base, d);
 }
-TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) { return g2_mul_gls(jac_to_affine(p), k); }
+// Jacobian input without an inversion: scale (X, Y, Z) by conj(Z) so that the third coordinate
+// becomes the norm N = Z conj(Z), an element of Fq.  psi keeps a real Z, so all four psi-images
+// share it and are AFFINE points of the isomorphic curve y^2 = x^3 + b N^6 -- the a = 0 group
+// law never reads b -- and the result only needs its Z multiplied by N to come back.
+TC_HD G2Jac g2_gls_digits_mul(const G2Jac& p, const uint64_t* d) {
+  const Fq2 l = p.z.conj();
+  const Fq2 l2 = l.sqr();
+  const G2Affine q{coord_out(p.x * l2), coord_out(p.y * (l2 * l)), p.is_inf()};
+  G2Affine base[4];
+  g2_gls_bases(q, base);
+  G2Jac r = g2_joint_mul4(base, d);
+  r.z = coord_out(r.z.scale(p.z.norm_fq()));
+  return r;
+}
+TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) {
+  uint64_t d[4];
+  gls_decompose(k, d);
+  return g2_gls_digits_mul(p, d);
+}
 
 // [|x|] P by the 64-bit ladder (|x| has Hamming weight 6: 63 doublings, 5 additions)
 TC_HD_NOINLINE G2Jac g2_mul_by_x_abs(const G2Jac& p) {
@@ -137,9 +155,7 @@ TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa) {
   t3 = jac_add(t3, t2);
   t3 = jac_add(t3, jac_neg(t1));
   t3 = jac_add(t3, jac_neg(p));                      // = [3(x^2-1) h2] P, in G2
-  G2Affine base[4];
-  g2_gls_bases(jac_to_affine(t3), base);
-  return g2_joint_mul4(base, G2_COFACTOR_FIX_DIGITS);
+  return g2_gls_digits_mul(t3, G2_COFACTOR_FIX_DIGITS);
 }
 
 // ---- G1: 2-dimensional GLV through phi(x, y) = (beta x, y) --------------------------------------
@@ -189,7 +205,13 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   return acc;
 }
 // the same for a Jacobian P (the share combiner's final [D^-1] step)
-TC_HD G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) { return g1_mul_glv(jac_to_affine(p), k); }
+// (no inversion: (X, Y) is an affine point of the isomorphic curve y^2 = x^3 + b Z^6, phi acts on
+// it the same way, and the a = 0 group law never reads b; the result's Z is multiplied by Z)
+TC_HD G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) {
+  G1Jac r = g1_mul_glv(G1Affine{p.x, p.y, p.is_inf()}, k);
+  r.z = coord_out(r.z * p.z);
+  return r;
+}
 
 // [|x|] P on G1 by the 64-bit ladder
 TC_HD_NOINLINE G1Jac g1_mul_by_x_abs(const G1Jac& p) {
