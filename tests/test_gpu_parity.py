@@ -467,3 +467,45 @@ def test_heterogeneous_waves_every_job_checked(engine, rnd):
     ok = engine.pairing_check(a_, b_, c_, d_)
     for j in range(B):
         assert int(ok[j]) == int(c_oracle.pairing_check(bytes(a_[j]), bytes(b_[j]), bytes(c_[j]), bytes(d_[j])) == 1), j
+
+
+def test_lincomb_with_infinity_points_zero_scalars_and_ragged_chunks(engine, rnd):
+    """sum_i s_i P_i (Commitment::evaluate's shape, src/poly.rs:497-508) for n = 1..6 points, with the
+    identity among the points, zero scalars and repeated points: the affine window tables of the
+    Straus ladder (one shared inversion) must cope with entries at infinity."""
+    for grp, E, gen, enc, fn, nb in (("g2", o.E2, o.G2_GEN, o.g2_uncompressed, engine.lincomb_g2, 192),
+                                     ("g1", o.E1, o.G1_GEN, o.g1_uncompressed, engine.lincomb_g1, 96)):
+        for n in (1, 2, 3, 4, 5, 6):
+            B = 9
+            pts, scs, want = np.zeros((B, n, nb), np.uint8), np.zeros((B, n, 32), np.uint8), []
+            for j in range(B):
+                P = [E.mul(gen, rnd.randrange(1, o.R)) for _ in range(n)]
+                s = [rnd.randrange(o.R) for _ in range(n)]
+                if j % 3 == 1:
+                    P[rnd.randrange(n)] = None
+                if j % 3 == 2:
+                    s[rnd.randrange(n)] = 0
+                if j == 4 and n >= 2:
+                    P[1] = P[0]
+                if j == 5 and n >= 2:
+                    P[1] = E.neg(P[0]) if hasattr(E, "neg") else E.mul(P[0], o.R - 1)
+                    s[1] = s[0]
+                if j == 6:
+                    P = [None] * n
+                acc = None
+                for Pi, si in zip(P, s):
+                    acc = E.add(acc, E.mul(Pi, si))
+                want.append(enc(acc))
+                for i in range(n):
+                    pts[j, i] = u8(enc(P[i]))
+                    scs[j, i] = u8(o.fr_to_bytes(s[i]))
+            out, st = fn(scs, pts)
+            assert not st.any()
+            for j in range(B):
+                assert bytes(out[j]) == want[j], (grp, n, j)
+    # scalar multiplication of the identity and by 0 / 1 / r - 1 through the GLS / GLV tables
+    Q = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    out, st = engine.g2_mul(frs([0, 1, o.R - 1, 5]), g2s([Q, None]))
+    assert not st.any()
+    for si, s in enumerate([0, 1, o.R - 1, 5]):
+        assert bytes(out[0, si]) == o.g2_uncompressed(o.E2.mul(Q, s)) and bytes(out[1, si]) == o.g2_uncompressed(None)

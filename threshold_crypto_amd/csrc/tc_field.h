@@ -458,34 +458,14 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
   TC_UNROLL for (int k = 0; k < 2 * N - 1; k++) {
     const int lo = (k < N) ? 0 : (k - N + 1);
     const int hi = (k < N) ? k : (N - 1);
+    // the two products share one accumulator chain, the reduction runs in a second one
+    // (three chains or a single one measure the same on MI355X: the multiplier pipe is the limit)
     int64_t s1 = carry;
     int64_t s2 = 0;
-#if defined(TC_MUL2_THREE_CHAINS)
-    int64_t s3 = 0;
-    TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)x[i] * y[k - i];
-    TC_UNROLL for (int i = lo; i <= hi; i++) s3 += (int64_t)z[i] * w[k - i];
-    s1 += s3;
-#else
-    // the two products share one accumulator chain; the reduction runs in a second one
     TC_UNROLL for (int i = lo; i <= hi; i++) {
       s1 += (int64_t)x[i] * y[k - i];
       s1 += (int64_t)z[i] * w[k - i];
     }
-#endif
-#if defined(TC_MUL2_ONE_CHAIN)
-    if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s1 += (int64_t)m[i] * FQ26_P[k - i];
-      int64_t s = s1;
-      m[k] = (int32_t)(((uint32_t)s * FQ26_INV) & (uint32_t)FQ_MASK);
-      s += (int64_t)m[k] * FQ26_P[0];
-      carry = s >> FQ_RADIX;
-    } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)m[i] * FQ26_P[k - i];
-      out[k - N] = (int32_t)((uint32_t)s1 & (uint32_t)FQ_MASK);
-      carry = s1 >> FQ_RADIX;
-    }
-    (void)s2;
-#else
     if (k < N) {
       TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
       int64_t s = s1 + s2;
@@ -498,7 +478,6 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
-#endif
   }
   out[N - 1] = (int32_t)carry;
 }

@@ -45,19 +45,32 @@ cnt()
 L.hs_g2_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g2_uncompressed(P2), buf(192)); res["g2_mul"] = (cnt(), 2)
 L.hs_g1_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g1_uncompressed(P1), buf(96)); res["g1_mul"] = (cnt(), 1)
 poly = [rnd.randrange(o.R) for _ in range(4)]
-ids = [1, 4, 6, 9]
-idx = (ctypes.c_uint64 * 4)(*ids)
-sh = b"".join(o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in ids)
+shares_g2 = {i: o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in range(10)}
+shares_g1 = {i: o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in range(10)}
+
+
+def avg_combine(g2, general, n=48):
+    """average over random 4-subsets of 10 signers (the bench's distribution); a wave additionally
+    pads the short ladder of the fast path to its longest job (not counted here)"""
+    tot = [0] * 5
+    L.hs_force_general_combine(1 if general else 0)
+    for _ in range(n):
+        ids = sorted(rnd.sample(range(10), 4))
+        idx = (ctypes.c_uint64 * 4)(*ids)
+        if g2:
+            L.hs_combine_g2(3, idx, b"".join(shares_g2[i] for i in ids), buf(192))
+        else:
+            L.hs_combine_g1(3, idx, b"".join(shares_g1[i] for i in ids), buf(96))
+        tot = [x + y for x, y in zip(tot, cnt())]
+    L.hs_force_general_combine(0)
+    return tuple(x // n for x in tot)
+
+
 cnt()
-L.hs_combine_g2(3, idx, sh, buf(192)); res["combine_g2_t3_fast"] = (cnt(), 2)
-L.hs_force_general_combine(1)
-L.hs_combine_g2(3, idx, sh, buf(192)); res["combine_g2_t3_general"] = (cnt(), 2)
-L.hs_force_general_combine(0)
-sh1 = b"".join(o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in ids)
-L.hs_combine_g1(3, idx, sh1, buf(96)); res["combine_g1_t3_fast"] = (cnt(), 1)
-L.hs_force_general_combine(1)
-L.hs_combine_g1(3, idx, sh1, buf(96)); res["combine_g1_t3_general"] = (cnt(), 1)
-L.hs_force_general_combine(0)
+res["combine_g2_t3_fast"] = (avg_combine(True, False), 2)
+res["combine_g2_t3_general"] = (avg_combine(True, True, 8), 2)
+res["combine_g1_t3_fast"] = (avg_combine(False, False), 1)
+res["combine_g1_t3_general"] = (avg_combine(False, True, 8), 1)
 a = rnd.randrange(o.R)
 L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
                    o.g2_uncompressed(o.E2.mul(P2, a))); res["pairing_check"] = (cnt(), 2)
