@@ -71,7 +71,8 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
 // Share indices are node numbers, so the abscissae x_i = idx_i + 1 are small integers and the
 // Lagrange coefficients are ratios of SMALL integers:
 //     lambda_i = num_i / den_i,  num_i = prod_{j != i} x_j,  den_i = prod_{j != i} (x_j - x_i).
-// With D = lcm_i |den_i| and the integers c_i = num_i * (D / den_i) (a few tens of bits),
+// With D = lcm_i |den_i| and the integers c_i = num_i * (D / den_i), all divided by their common
+// factor (a few bits to a few tens of bits),
 //     sum_i lambda_i S_i = [D^-1 mod r] ( sum_i c_i S_i ),
 // i.e. one short joint ladder over |c_i| followed by ONE full-size (GLS / GLV) multiplication,
 // instead of t+1 full-size ones.  Same group element, same bytes.  Returns false -- caller
@@ -124,8 +125,13 @@ TC_HD bool lagrange_small_coeffs(const uint64_t* idx, uint64_t* c_abs, bool* c_n
     c_neg[i] = den_neg[i];
     c_abs[i] = c;
   }
+  // common factor of all numerators and the denominator: for 4 of 10 signers it shortens the
+  // longest c_i from 14 to 9 bits (the ladder over the c_i runs to the longest one in the wave)
+  uint64_t g = D;
+  TC_UNROLL for (int i = 0; i < K; i++) g = gcd_u64(g, c_abs[i]);
+  TC_UNROLL for (int i = 0; i < K; i++) c_abs[i] /= g;
   *d_neg = false;
-  *d_abs = D;
+  *d_abs = D / g;
   return true;
 }
 
