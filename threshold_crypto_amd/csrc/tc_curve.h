@@ -120,10 +120,14 @@ TC_HD_NOINLINE Affine<F> jac_to_affine(const Jac<F>& p) {
   return Affine<F>{p.x * zi2, p.y * zi2 * zi, false};
 }
 
-// Affine coordinates of n <= 16 Jacobian points with ONE field inversion (Montgomery's trick).
-// Points at infinity stay flagged and do not poison the product.
+// Brings n <= 16 Jacobian points to ONE common Z without an inversion:
+//     out[i] = (X_i F_i^2, Y_i F_i^3),   F_i = prod_{k != i} Z_k,   Zc = prod_k Z_k  (returned)
+// (X_i, Y_i, Z_i) ~ (X_i F_i^2, Y_i F_i^3, Zc), so every out[i] is an AFFINE point of the
+// isomorphic curve y^2 = x^3 + b Zc^6.  The a = 0 group law never reads b: a ladder can run on
+// those affine points with mixed additions, and its result (X, Y, Z) is (X, Y, Z Zc) on the
+// original curve.  Points at infinity stay flagged and count as Z = 1.
 template <class F>
-TC_HD void jac_batch_to_affine(const Jac<F>* in, Affine<F>* out, int n) {
+TC_HD F jac_batch_to_common_z(const Jac<F>* in, Affine<F>* out, int n) {
   F pre[16];
   bool inf[16];
   F acc = F::one();
@@ -132,13 +136,20 @@ TC_HD void jac_batch_to_affine(const Jac<F>* in, Affine<F>* out, int n) {
     pre[i] = acc;
     acc = acc * F::select(inf[i], F::one(), in[i].z);
   }
-  F inv = acc.inv();
+  const F zc = acc;
+  F suf = F::one();
   TC_NOUNROLL for (int i = n - 1; i >= 0; i--) {
-    const F zi = inv * pre[i];
-    inv = inv * F::select(inf[i], F::one(), in[i].z);
-    const F zi2 = zi.sqr();
-    out[i] = Affine<F>{coord_out(in[i].x * zi2), coord_out(in[i].y * zi2 * zi), inf[i]};
+    const F f = pre[i] * suf;
+    suf = suf * F::select(inf[i], F::one(), in[i].z);
+    const F f2 = f.sqr();
+    out[i] = Affine<F>{coord_out(in[i].x * f2), coord_out(in[i].y * (f2 * f)), inf[i]};
   }
+  return zc;
+}
+// an affine point of the original curve on the curve scaled by zc (zc2 = zc^2, zc3 = zc^3)
+template <class F>
+TC_HD Affine<F> affine_scale_z(const Affine<F>& p, const F& zc2, const F& zc3) {
+  return Affine<F>{coord_out(p.x * zc2), coord_out(p.y * zc3), p.inf};
 }
 
 // k * P for a scalar given as nwords little-endian u32 words (bits above nbits are zero).

@@ -32,9 +32,10 @@ TC_HD bool lagrange_coeff_at_zero(const uint64_t* idx, int t, int i, Fr& out) {
 // "all K bits are zero" skip.  sc[k] points at 8 little-endian u32 words (canonical, < r).
 template <class F, int K>
 TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
-  // subset sums by mixed additions, then back to affine with one shared inversion so that the
-  // 255-step ladder below also runs on mixed additions
+  // subset sums by mixed additions, then one common Z for the whole table (tc_curve.h
+  // jac_batch_to_common_z, no inversion) so that the 255-step ladder also runs on mixed additions
   Affine<F> tbl[1 << K];
+  F zc;
   {
     Jac<F> sums[(1 << K) - 1];
     Affine<F> sums_aff[(1 << K) - 1];
@@ -44,18 +45,19 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
       const int low = __builtin_ctz((unsigned)m);
       const int rest = m & (m - 1);
       if (!rest) {
-        tbl[m] = pts[low];
         slot[m] = -1;
       } else {
         const int rs = slot[rest];
-        const Jac<F> prev = (rs < 0) ? Jac<F>::from_affine(tbl[rest]) : sums[rs];
+        const Jac<F> prev = (rs < 0) ? Jac<F>::from_affine(pts[__builtin_ctz((unsigned)rest)]) : sums[rs];
         sums[ns] = jac_add_mixed(prev, pts[low]);
         slot[m] = ns++;
       }
     }
-    jac_batch_to_affine(sums, sums_aff, ns);
-    TC_NOUNROLL for (int m = 3; m < (1 << K); m++)
-      if (slot[m] >= 0) tbl[m] = sums_aff[slot[m]];
+    zc = jac_batch_to_common_z(sums, sums_aff, ns);
+    const F zc2 = zc.sqr();
+    const F zc3 = zc2 * zc;
+    TC_NOUNROLL for (int m = 1; m < (1 << K); m++)
+      tbl[m] = (slot[m] >= 0) ? sums_aff[slot[m]] : affine_scale_z(pts[__builtin_ctz((unsigned)m)], zc2, zc3);
   }
   Jac<F> acc = Jac<F>::infinity();
   TC_NOUNROLL for (int bit = 254; bit >= 0; bit--) {
@@ -64,6 +66,7 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
     TC_UNROLL for (int k = 0; k < K; k++) m |= ((sc[k][bit >> 5] >> (bit & 31)) & 1u) << k;
     if (m) acc = jac_add_mixed(acc, tbl[m]);
   }
+  acc.z = coord_out(acc.z * zc);
   return acc;
 }
 
