@@ -262,6 +262,21 @@ def test_combine_fast_path_equals_general_path(L, rnd):
         assert fast1.raw == gen1.raw == o.g1_uncompressed(o.interpolate(o.E1, t, list(zip(ids, sh1)))), (t, ids)
 
 
+def test_fast_combine_for_every_signer_subset_of_ten(L, rnd):
+    """All C(10,2) + C(10,3) + C(10,4) signer subsets through the small-coefficient path (lcm of the
+    denominators, common factor removed, D^-1 by Euclid) in G1, against the oracle's interpolation."""
+    import itertools
+    U = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    for t in (1, 2, 3):
+        poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+        want = o.g1_uncompressed(o.E1.mul(U, poly[0]))
+        sh = {i: o.g1_uncompressed(o.E1.mul(U, o.poly_evaluate(poly, i + 1))) for i in range(10)}
+        for ids in itertools.combinations(range(10), t + 1):
+            out = buf(96)
+            assert L.hs_combine_g1(t, (ctypes.c_uint64 * (t + 1))(*ids), b"".join(sh[i] for i in ids), out) == 0
+            assert out.raw == want, (t, ids)
+
+
 def test_gls_and_cofactor_probe(L, rnd):
     """GLS scalar multiplication edge scalars; cofactor clearing is covered by test_hash_and_kdf."""
     Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
