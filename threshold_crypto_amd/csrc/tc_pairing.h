@@ -74,6 +74,22 @@ TC_HD void miller_ell(Fq12& f, const LineCoeffs& l, const G1Affine& p) {
   f = f.mul_by_014(l.c2, l.c1.scale(p.x), l.c0.scale(p.y));
 }
 
+// f *= product of the lines of all pairs.  Two lines are multiplied with each other first (6 Fq2
+// products) and f by the result (17) -- 23 instead of the 2 x 13 of two sparse multiplications.
+template <int NP>
+TC_HD void miller_apply_lines(Fq12& f, const LineCoeffs* l, const G1Affine* ps, const bool* skip) {
+  if (NP == 2) {
+    if (!skip[0] && !skip[1]) {
+      const Fq12 lp = Fq12::line_product(l[0].c2, l[0].c1.scale(ps[0].x), l[0].c0.scale(ps[0].y), l[1].c2,
+                                         l[1].c1.scale(ps[1].x), l[1].c0.scale(ps[1].y));
+      f = f.mul_by_line_product(lp);
+      return;
+    }
+  }
+  TC_UNROLL for (int k = 0; k < NP; k++)
+    if (!skip[k]) miller_ell(f, l[k], ps[k]);
+}
+
 // Product Miller loop over NP pairs (NP = 2 for every check on the path).
 template <int NP>
 TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
@@ -85,29 +101,21 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
     r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one()};
   }
   const uint64_t xs = BLS_X_ABS >> 1;
+  LineCoeffs l[NP];
   TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
-    TC_UNROLL for (int k = 0; k < NP; k++) {
-      if (!skip[k]) {
-        LineCoeffs l = miller_doubling_step(r[k]);
-        miller_ell(f, l, ps[k]);
-      }
-    }
+    TC_UNROLL for (int k = 0; k < NP; k++)
+      if (!skip[k]) l[k] = miller_doubling_step(r[k]);
+    miller_apply_lines<NP>(f, l, ps, skip);
     if ((xs >> i) & 1ull) {
-      TC_UNROLL for (int k = 0; k < NP; k++) {
-        if (!skip[k]) {
-          LineCoeffs l = miller_addition_step(r[k], qs[k]);
-          miller_ell(f, l, ps[k]);
-        }
-      }
+      TC_UNROLL for (int k = 0; k < NP; k++)
+        if (!skip[k]) l[k] = miller_addition_step(r[k], qs[k]);
+      miller_apply_lines<NP>(f, l, ps, skip);
     }
     f = f.sqr();
   }
-  TC_UNROLL for (int k = 0; k < NP; k++) {
-    if (!skip[k]) {
-      LineCoeffs l = miller_doubling_step(r[k]);
-      miller_ell(f, l, ps[k]);
-    }
-  }
+  TC_UNROLL for (int k = 0; k < NP; k++)
+    if (!skip[k]) l[k] = miller_doubling_step(r[k]);
+  miller_apply_lines<NP>(f, l, ps, skip);
   return f.conj();  // x < 0
 }
 

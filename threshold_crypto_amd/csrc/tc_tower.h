@@ -181,6 +181,16 @@ struct Fq6 {
     r.c2 = (c0 + c2) * b0 - aa + bb;
     return TC_FQ6_OUT(r);
   }
+  // sparse: times (b1 v + b2 v^2)
+  TC_FQ6_ATTR Fq6 mul_by_12(const Fq2& b1, const Fq2& b2) const {
+    Fq2 bb = c1 * b1;
+    Fq2 cc = c2 * b2;
+    Fq6 r;
+    r.c0 = ((c1 + c2) * (b1 + b2) - bb - cc).mul_xi();
+    r.c1 = (c0 + c1) * b1 - bb + cc.mul_xi();
+    r.c2 = (c0 + c2) * b2 - cc + bb;
+    return TC_FQ6_OUT(r);
+  }
   // sparse: times (b1 v)
   TC_FQ6_ATTR Fq6 mul_by_1(const Fq2& b1) const { return TC_FQ6_OUT((Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1})); }
   TC_HD_NOINLINE Fq6 inv() const {
@@ -233,6 +243,30 @@ struct Fq12 {
     r.c1 = (c1 + c0).mul_by_01(d0, o) - aa - bb;
     r.c0 = bb.mul_by_v() + aa;
     return r.norm();
+  }
+  // (d0 + d1 v + d4 v w) * (e0 + e1 v + e4 v w): the product of two Miller-loop lines, 6 Fq2
+  // products; the result has no w coefficient of degree 0 in v:  c1 = (0, *, *)
+  TC_HD static Fq12 line_product(const Fq2& d0, const Fq2& d1, const Fq2& d4, const Fq2& e0, const Fq2& e1,
+                                 const Fq2& e4) {
+    Fq2 t0 = d0 * e0;
+    Fq2 t1 = d1 * e1;
+    Fq2 t3 = d4 * e4;
+    Fq2 t2 = (d0 + d1) * (e0 + e1) - t0 - t1;
+    Fq2 u = (d0 + d4) * (e0 + e4) - t0 - t3;
+    Fq2 w = (d1 + d4) * (e1 + e4) - t1 - t3;
+    Fq12 r;
+    r.c0 = Fq6{(t0 + t3.mul_xi()).norm(), t2.norm(), t1};
+    r.c1 = Fq6{Fq2::zero(), u.norm(), w.norm()};
+    return r;
+  }
+  // times an element whose c1 is (0, *, *) (a line product): 6 + 5 + 6 Fq2 products
+  TC_FQ12_ATTR Fq12 mul_by_line_product(const Fq12& l) const {
+    Fq6 t0 = c0 * l.c0;
+    Fq6 t1 = c1.mul_by_12(l.c1.c1, l.c1.c2);
+    Fq12 r;
+    r.c1 = (c0 + c1) * (l.c0 + l.c1) - t0 - t1;
+    r.c0 = t0 + t1.mul_by_v();
+    return r.reduce_value();
   }
   // a^(q^k), k in {1,2,3}
   TC_HD_NOINLINE Fq12 frobenius(int k) const {
