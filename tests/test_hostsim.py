@@ -304,7 +304,7 @@ P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)); Q2 = o.E2.mul(o.G2_GEN, rnd.randr
 k = rnd.randrange(o.R)
 out = buf(96); assert L.hs_g1_mul(o.fr_to_bytes(k), o.g1_uncompressed(P), out) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(P, k))
 out = buf(192); assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0 and out.raw == o.g2_uncompressed(o.E2.mul(Q2, k))
-for t, ids in [(3, [1, 4, 6, 9]), (5, [0, 2, 3, 6, 9, 11]), (3, [2**40, 1, 2, 3])]:
+for t, ids in [(3, [1, 4, 6, 9]), (5, [0, 2, 3, 6, 9, 11]), (3, [2**40, 1, 2, 3]), (21, list(range(0, 66, 3)))]:
     poly = [rnd.randrange(o.R) for _ in range(t + 1)]
     sh = [o.E2.mul(Q2, o.poly_evaluate(poly, (i + 1) %% o.R)) for i in ids]
     out = buf(192); assert L.hs_combine_g2(t, (ctypes.c_uint64 * (t + 1))(*ids), b"".join(o.g2_uncompressed(s) for s in sh), out) == 0

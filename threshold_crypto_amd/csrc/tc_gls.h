@@ -94,7 +94,7 @@ TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Affine* base, const uint64_t* d) {
                        ((uint32_t)((d[2] >> bit) & 1) << 2) | ((uint32_t)((d[3] >> bit) & 1) << 3);
     if (m) acc = jac_add_mixed(acc, tbl[m]);
   }
-  acc.z = coord_out(acc.z * zc);
+  acc.z = coord_norm(acc.z * zc);
   return acc;
 }
 
@@ -123,11 +123,11 @@ TC_HD G2Jac g2_mul_gls(const G2Affine& p, const uint32_t* k) {
 TC_HD G2Jac g2_gls_digits_mul(const G2Jac& p, const uint64_t* d) {
   const Fq2 l = p.z.conj();
   const Fq2 l2 = l.sqr();
-  const G2Affine q{coord_out(p.x * l2), coord_out(p.y * (l2 * l)), p.is_inf()};
+  const G2Affine q{coord_norm(p.x * l2), coord_norm(p.y * (l2 * l)), p.is_inf()};
   G2Affine base[4];
   g2_gls_bases(q, base);
   G2Jac r = g2_joint_mul4(base, d);
-  r.z = coord_out(r.z.scale(p.z.norm_fq()));
+  r.z = coord_norm(r.z.scale(p.z.norm_fq()));
   return r;
 }
 TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) {
@@ -214,7 +214,7 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
     const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
     if (m) acc = jac_add_mixed(acc, tbl[m]);
   }
-  acc.z = coord_out(acc.z * zc);
+  acc.z = coord_norm(acc.z * zc);
   return acc;
 }
 // the same for a Jacobian P (the share combiner's final [D^-1] step)
@@ -222,7 +222,7 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
 // it the same way, and the a = 0 group law never reads b; the result's Z is multiplied by Z)
 TC_HD G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) {
   G1Jac r = g1_mul_glv(G1Affine{p.x, p.y, p.is_inf()}, k);
-  r.z = coord_out(r.z * p.z);
+  r.z = coord_norm(r.z * p.z);
   return r;
 }
 

@@ -66,7 +66,7 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
     TC_UNROLL for (int k = 0; k < K; k++) m |= ((sc[k][bit >> 5] >> (bit & 31)) & 1u) << k;
     if (m) acc = jac_add_mixed(acc, tbl[m]);
   }
-  acc.z = coord_out(acc.z * zc);
+  acc.z = coord_norm(acc.z * zc);
   return acc;
 }
 
