@@ -34,12 +34,12 @@ MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient d
 # operations is split between them, Fq work outside (inversions, root exponentiations) is done
 # by both and counted twice.
 EXECUTED_MACS = {"combine_g2_t3_fast": 1610805, "combine_g2_t3_general": 5084790, "g2_mul": 1511790,
-                 "verify_g2": 8716800, "hash_g2": 3535200, "combine_g1_t3_fast": 755655}
+                 "verify_g2": 8441400, "hash_g2": 3535200, "combine_g1_t3_fast": 755655}
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
 # profiles/r01_d_pair_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
 # (register-spill / window-table) traffic, several hundred times the algorithmic bytes.
-PROFILED_TRAFFIC_BYTES = {65536: int((2 * 4962655.4 + 6795272.1) * 1024)}
+PROFILED_TRAFFIC_BYTES = {65536: int((2 * 5015639.5 + 7272686.7) * 1024)}
 P_INT_TMACS = 27.2             # measured v_mad_u64_u32 issue rate, tools/ubench_valu (profiles/)
 HBM_PEAK_GBPS = 8000.0
 
