@@ -509,3 +509,14 @@ def test_lincomb_with_infinity_points_zero_scalars_and_ragged_chunks(engine, rnd
     assert not st.any()
     for si, s in enumerate([0, 1, o.R - 1, 5]):
         assert bytes(out[0, si]) == o.g2_uncompressed(o.E2.mul(Q, s)) and bytes(out[1, si]) == o.g2_uncompressed(None)
+
+
+def test_randomised_soak_short():
+    """tools/soak.py for a few seconds: random shapes, index patterns, message lengths and
+    operand validity, every job against the C oracle (the long run is `python tools/soak.py 600`)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "10", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SOAK-OK" in r.stdout, (r.stdout[-500:], r.stderr[-500:])

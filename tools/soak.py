@@ -1,0 +1,158 @@
+"""Randomised differential soak test on the GPU: random batch shapes, signer subsets, message lengths,
+valid / invalid / identity operands -- EVERY job compared with the C oracle (oracle/c, test
+infrastructure).  Usage on an MI355X:  python tools/soak.py [seconds] [seed]
+Exits non-zero on the first mismatch and prints the reproducer (seed, round, entry point, job)."""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+import c_oracle  # noqa: E402
+import tc_oracle as o  # noqa: E402
+from threshold_crypto_amd.engine import Engine, pack_messages  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rnd = random.Random(SEED)
+c_oracle.load()
+e = Engine(0)
+
+
+def u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def rbytes(n):
+    return bytes(rnd.randrange(256) for _ in range(n))
+
+
+def fr(k):
+    return o.fr_to_bytes(k)
+
+
+# pools of valid points made with the C oracle (fast), so that batches are cheap to assemble
+G1U, G2U = o.g1_uncompressed(o.G1_GEN), o.g2_uncompressed(o.G2_GEN)
+pool1 = [c_oracle.g1_mul(fr(rnd.randrange(1, o.R)), G1U)[1] for _ in range(24)] + [o.g1_uncompressed(None)]
+pool2 = [c_oracle.g2_mul(fr(rnd.randrange(1, o.R)), G2U)[1] for _ in range(24)] + [o.g2_uncompressed(None)]
+
+
+def maybe_corrupt(enc):
+    if rnd.random() < 0.06:
+        b = bytearray(enc)
+        b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        return bytes(b)
+    return enc
+
+
+def fail(what, rnd_no, j, extra=""):
+    print("MISMATCH seed=%d round=%d %s job=%d %s" % (SEED, rnd_no, what, j, extra), flush=True)
+    sys.exit(1)
+
+
+checked = 0
+rounds = 0
+t_end = time.time() + SECONDS
+while time.time() < t_end:
+    rounds += 1
+    B = rnd.choice([1, 2, 31, 32, 33, 63, 64, 65, 97, 130])
+    # ---- scalar multiplication (S signers x B points) -------------------------------------------
+    S = rnd.choice([1, 2, 3])
+    ks = [rnd.choice([0, 1, o.R - 1, rnd.randrange(o.R), rnd.randrange(1 << 64)]) for _ in range(S)]
+    pts2 = [maybe_corrupt(rnd.choice(pool2)) for _ in range(B)]
+    out, st = e.g2_mul(np.stack([u8(fr(k)) for k in ks]), np.stack([u8(p) for p in pts2]))
+    for j in range(B):
+        for s in range(S):
+            rc, want = c_oracle.g2_mul(fr(ks[s]), pts2[j])
+            if (st[j, s] != 0) != (rc != 0) or (rc == 0 and bytes(out[j, s]) != want):
+                fail("g2_mul", rounds, j)
+    pts1 = [maybe_corrupt(rnd.choice(pool1)) for _ in range(B)]
+    out, st = e.g1_mul(np.stack([u8(fr(k)) for k in ks]), np.stack([u8(p) for p in pts1]))
+    for j in range(B):
+        for s in range(S):
+            rc, want = c_oracle.g1_mul(fr(ks[s]), pts1[j])
+            if (st[j, s] != 0) != (rc != 0) or (rc == 0 and bytes(out[j, s]) != want):
+                fail("g1_mul", rounds, j)
+    checked += 2 * B * S
+    # ---- combine (G2 and G1), mixed index patterns --------------------------------------------------
+    t = rnd.choice([1, 2, 3, 3, 3, 5])
+    n = t + 1 + rnd.choice([0, 0, 1])
+    N = rnd.choice([t + 2, 10, 40, 200])
+    idx = np.zeros((B, n), np.uint64)
+    sh2 = np.zeros((B, n, 192), np.uint8)
+    sh1 = np.zeros((B, n, 96), np.uint8)
+    for j in range(B):
+        ids = sorted(rnd.sample(range(max(N, n)), n))
+        mode = rnd.random()
+        if mode < 0.1:
+            ids = [i + (1 << rnd.choice([16, 20, 40, 63])) for i in ids]
+        elif mode < 0.2:
+            ids[1] = ids[0]
+        idx[j] = ids
+        for k_ in range(n):
+            sh2[j, k_] = u8(maybe_corrupt(rnd.choice(pool2)))
+            sh1[j, k_] = u8(maybe_corrupt(rnd.choice(pool1)))
+        if mode >= 0.1 and mode < 0.2:
+            sh2[j, 1] = sh2[j, 0]
+            sh1[j, 1] = sh1[j, 0]
+    got2, st2 = e.combine_g2(t, idx, sh2)
+    got1, st1 = e.combine_g1(t, idx, sh1)
+    for j in range(B):
+        ids = [int(i) for i in idx[j]]
+        rc, want = c_oracle.combine_g2(t, ids, [bytes(sh2[j, k_]) for k_ in range(n)])
+        if (st2[j] != 0) != (rc != 0) or (rc == 0 and bytes(got2[j]) != want):
+            fail("combine_g2", rounds, j, "t=%d ids=%s st=%d rc=%d" % (t, ids, st2[j], rc))
+        rc, want = c_oracle.combine_g1(t, ids, [bytes(sh1[j, k_]) for k_ in range(n)])
+        if (st1[j] != 0) != (rc != 0) or (rc == 0 and bytes(got1[j]) != want):
+            fail("combine_g1", rounds, j, "t=%d ids=%s st=%d rc=%d" % (t, ids, st1[j], rc))
+    checked += 2 * B
+    # ---- hashing ---------------------------------------------------------------------------------
+    msgs = [rbytes(rnd.choice([0, 1, 14, 63, 64, 65, 135, 136, 137, rnd.randrange(300)])) for _ in range(B)]
+    flat, off = pack_messages(msgs)
+    h = e.hash_g2(flat, off)
+    for j in range(B):
+        if bytes(h[j]) != c_oracle.hash_g2(msgs[j]):
+            fail("hash_g2", rounds, j, "len=%d" % len(msgs[j]))
+    g1 = np.stack([u8(maybe_corrupt(rnd.choice(pool1))) for _ in range(B)])
+    hg, st = e.hash_g1_g2(g1, flat, off)
+    x, stx = e.xor_with_hash(g1, flat, off)
+    for j in range(B):
+        rc, want = c_oracle.hash_g1_g2(bytes(g1[j]), msgs[j])
+        if (st[j] != 0) != (rc != 0) or (rc == 0 and bytes(hg[j]) != want):
+            fail("hash_g1_g2", rounds, j)
+        rc, want = c_oracle.xor_with_hash(bytes(g1[j]), msgs[j])
+        if (stx[j] != 0) != (rc != 0) or (rc == 0 and bytes(x[int(off[j]): int(off[j + 1])]) != want):
+            fail("xor_with_hash", rounds, j)
+    checked += 3 * B
+    # ---- pairing checks: true / false / identity / invalid ------------------------------------------
+    Bp = min(B, 48)
+    a_ = np.zeros((Bp, 96), np.uint8); b_ = np.zeros((Bp, 192), np.uint8)
+    c_ = np.zeros((Bp, 96), np.uint8); d_ = np.zeros((Bp, 192), np.uint8)
+    for j in range(Bp):
+        xs, ys = rnd.randrange(1, o.R), rnd.randrange(1, o.R)
+        a_[j] = u8(maybe_corrupt(c_oracle.g1_mul(fr(xs), G1U)[1] if rnd.random() > 0.05 else o.g1_uncompressed(None)))
+        b_[j] = u8(maybe_corrupt(c_oracle.g2_mul(fr(ys), G2U)[1]))
+        c_[j] = u8(G1U)
+        good = rnd.random() < 0.6
+        d_[j] = u8(maybe_corrupt(c_oracle.g2_mul(fr((xs * ys + (0 if good else 1)) % o.R), G2U)[1] if rnd.random() > 0.05 else o.g2_uncompressed(None)))
+    ok = e.pairing_check(a_, b_, c_, d_)
+    for j in range(Bp):
+        if int(ok[j]) != int(c_oracle.pairing_check(bytes(a_[j]), bytes(b_[j]), bytes(c_[j]), bytes(d_[j])) == 1):
+            fail("pairing_check", rounds, j)
+    checked += Bp
+    # ---- compressed round trip ------------------------------------------------------------------------
+    c2, stc = e.g2_compress(np.stack([u8(p) for p in pts2]))
+    d2, std = e.g2_decompress(c2)
+    for j in range(B):
+        rc, want = c_oracle.g2_compress(pts2[j])
+        if (stc[j] != 0) != (rc != 0) or (rc == 0 and bytes(c2[j]) != want):
+            fail("g2_compress", rounds, j)
+        if rc == 0:
+            rc2, want2 = c_oracle.g2_decompress(bytes(c2[j]))
+            if (std[j] != 0) != (rc2 != 0) or (rc2 == 0 and bytes(d2[j]) != want2):
+                fail("g2_decompress", rounds, j)
+    checked += 2 * B
+print("SOAK-OK seed=%d rounds=%d jobs_checked=%d seconds=%.0f" % (SEED, rounds, checked, SECONDS), flush=True)
