@@ -28,13 +28,13 @@ sys.path.insert(0, ROOT)
 # with Oracle B's counter (oracle/c/tc_oracle.c or_fq_mul_count; see DESIGN.md "Work constants")
 W_FQMUL = {"combine_g2_t3": 31148, "g2_mul": 7771, "verify_g2": 41226, "hash_g2": 19604}
 MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient digits (CIOS)
-# what the kernels actually execute per unit, in v_mad (one 15x15 limb product or one Montgomery
-# reduction = 225): counted by running the same per-lane job bodies in the host build
+# what the kernels actually execute per unit, in v_mad (one 14x14 limb product or one Montgomery
+# reduction = 196): counted by running the same per-lane job bodies in the host build
 # (tools/count_ops.py, tests/hostsim -DTC_COUNT_OPS).  Two lanes work on a G2 job; work inside Fq2
 # operations is split between them, Fq work outside (inversions, root exponentiations) is done
 # by both and counted twice.
-EXECUTED_MACS = {"combine_g2_t3_fast": 1610805, "combine_g2_t3_general": 5084790, "g2_mul": 1511790,
-                 "verify_g2": 8441400, "hash_g2": 3535200, "combine_g1_t3_fast": 755655}
+EXECUTED_MACS = {"combine_g2_t3_fast": 1403192, "combine_g2_t3_general": 4429418, "g2_mul": 1316938,
+                 "verify_g2": 7353402, "hash_g2": 3080441, "combine_g1_t3_fast": 658735}
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
 # profiles/r01_d_pair_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
@@ -216,7 +216,7 @@ def main():
         result = {
             "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 limbs (Fq = 15 x 26-bit signed, Montgomery R=2^390; 64-bit column accumulators; one Fq2 coefficient per lane of a lane pair)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 limbs (Fq = 14 x 28-bit signed, Montgomery R=2^392; 64-bit column accumulators; one Fq2 coefficient per lane of a lane pair)",
             "data": "synthetic",
             "config": {"workload": "t=%d,N=%d,batch=%d threshold signatures (combine_signatures, G2), per GPU" % (t, N, B),
                        "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world},

@@ -56,10 +56,10 @@ int hs_fq_zero_probe(const uint8_t* a, const uint8_t* b, int k) {
   fq_from_be48(a, false, x);
   fq_from_be48(b, false, y);
   Fq v = x - y;
-  const Fq p = Fq::from_limbs(FQ26_P);
+  const Fq p = Fq::from_limbs(FQL_P);
   for (int i = 0; i < (k < 0 ? -k : k); i++) {
     v = (k < 0) ? v - p : v + p;
-    if ((i & 7) == 7) v = v.norm();
+    if ((i & 3) == 3) v = v.norm();  // keep the lazy limbs inside int32
   }
   return (v.maybe_zero() ? 1 : 0) | (v.is_zero_full() ? 2 : 0) | (v.is_zero() ? 4 : 0);
 }

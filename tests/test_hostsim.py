@@ -21,6 +21,12 @@ CSRC = os.path.join(os.path.dirname(HERE), "threshold_crypto_amd", "csrc")
 @pytest.fixture(scope="module")
 def L():
     newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    if os.environ.get("TC_HOSTSIM_BOUND_CHECK"):
+        # the WHOLE suite under the interval analysis (aborts the process on a violation):
+        #   TC_HOSTSIM_BOUND_CHECK=1 python -m pytest tests/test_hostsim.py -x -q
+        lib = LIB.replace(".so", "_bcall.so")
+        subprocess.run(["g++", "-O1", "-std=c++17", "-DTC_TEST_HOOKS", "-DTC_BOUND_CHECK", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", lib], check=True)
+        return ctypes.CDLL(lib)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(newest, os.path.getmtime(SRC)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-DTC_TEST_HOOKS", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", LIB], check=True)
     return ctypes.CDLL(LIB)
@@ -58,7 +64,7 @@ def test_zero_filter_never_misses_a_zero(L, rnd):
     # every representation k*p, |k| <= 300 (the value bound of the lazy arithmetic), must pass the
     # 4-instruction filter in front of the full zero test; non-zero values must never be reported zero
     a = rnd.randrange(o.Q)
-    for k in list(range(-300, 301, 7)) + [-300, -1, 0, 1, 300]:
+    for k in list(range(-297, 298, 7)) + [-297, -1, 0, 1, 297]:  # (x - y carries a value bound of 2 itself)
         assert L.hs_fq_zero_probe(be(a), be(a), k) == 7, k
     rejected = 0
     for _ in range(300):

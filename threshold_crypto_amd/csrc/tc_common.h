@@ -76,7 +76,7 @@
 // In the hipcc build every job that touches Fq2 (all G2 arithmetic, the pairing, hash_g2) is
 // worked on by TWO adjacent lanes: the even lane holds the c0 coefficient of every Fq2 value,
 // the odd lane c1 (tc_tower.h).  Linear Fq2 operations are component-wise, so each lane does
-// half of them; a product costs each lane two 15x15 limb products and ONE Montgomery reduction
+// half of them; a product costs each lane two 14x14 limb products and ONE Montgomery reduction
 // (tc_field.h fq2p_mul_call) with the partner's limbs fetched over DPP.  Per lane that halves
 // registers, scratch and latency; a batch of B jobs fills 2B lanes, so batch 65 536 gives the
 // MI355X two waves per SIMD instead of one.  Both lanes of a pair always take the same

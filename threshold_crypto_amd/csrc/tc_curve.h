@@ -36,24 +36,30 @@ struct Jac {
   }
 };
 
+// The 28-bit limbs leave three bits of headroom in an int32 (|limb| < 8 * 2^28) and a
+// multiplication wants B_a * B_b <= 8 (tc_field.h), so the formulas below keep small multiples
+// AFTER the products they scale and pass sums through norm() (one carry pass) where the interval
+// analysis of tests/hostsim -DTC_BOUND_CHECK asks for it.
+
 // dbl-2009-l (a = 0): 2M + 5S.  Doubling the identity (z = 0) yields z3 = 0 again.
 template <class F>
 TC_JAC_ATTR Jac<F> jac_dbl(const Jac<F>& p) {
   F a = p.x.sqr();
   F b = p.y.sqr();
   F c = b.sqr();
-  F d = ((p.x + b).sqr() - a - c).dbl();
-  F e = a.dbl() + a;
+  F t = ((p.x + b).sqr() - a - c).norm();  // d = 2 t
+  F e = (a.dbl() + a).norm();
   F f = e.sqr();
   Jac<F> r;
-  // coordinates are kept carry-normalised between point operations (lazy limbs, tc_field.h)
   r.z = coord_norm((p.y * p.z).dbl());
-  r.x = coord_out(f - d.dbl());
-  r.y = coord_norm(e * (d - r.x) - c.dbl().dbl().dbl());
+  r.x = coord_out(f - t.dbl().dbl());
+  r.y = coord_norm(e * (t.dbl() - r.x) - c.dbl().dbl().norm().dbl());
   return r;
 }
 
 // madd-2007-bl with the exceptional cases handled (p = inf, q = inf, p = +-q).
+//   h = u2 - x1, r = s2 - y1 (the formulas' r is 2 r), hh = h^2, j = h hh (theirs: 4 j), v = x1 hh (4 v)
+//   x3 = 4 (r^2 - j - 2 v),  y3 = 2 (r (4 v - x3) - 4 y1 j),  z3 = (z1 + h)^2 - z1^2 - hh
 template <class F>
 TC_JAC_ATTR Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
   if (q.inf) return p;
@@ -61,7 +67,7 @@ TC_JAC_ATTR Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
   F u2 = q.x * z1z1;
   F s2 = q.y * p.z * z1z1;
   F h = u2 - p.x;
-  F rr = (s2 - p.y).dbl();
+  F rr = s2 - p.y;
   const bool p_inf = p.is_inf();
   const bool same_x = h.is_zero();
   if (!p_inf && same_x) {
@@ -70,18 +76,18 @@ TC_JAC_ATTR Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
     return Jac<F>::infinity();
   }
   F hh = h.sqr();
-  F i = hh.dbl().dbl();
-  F j = h * i;
-  F v = p.x * i;
+  F j = h * hh;
+  F v = p.x * hh;
   Jac<F> r;
-  r.x = coord_norm(rr.sqr() - j - v.dbl());
-  r.y = coord_norm(rr * (v - r.x) - (p.y * j).dbl());
-  r.z = coord_norm((p.z + h).sqr() - z1z1 - hh);
+  r.x = coord_norm((rr.sqr() - j - v.dbl()).norm().dbl().dbl());
+  r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (p.y * j).dbl().dbl()).norm().dbl());
+  r.z = coord_norm((p.z + h).norm().sqr() - z1z1 - hh);
   if (p_inf) r = Jac<F>{q.x, q.y, F::one()};
   return r;
 }
 
-// add-2007-bl with the exceptional cases handled.
+// add-2007-bl with the exceptional cases handled (same rescaling as above: r is half the
+// formulas' r, i = hh is a quarter of theirs).
 template <class F>
 TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   const bool p_inf = p.is_inf();
@@ -93,18 +99,18 @@ TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   F s1 = p.y * q.z * z2z2;
   F s2 = q.y * p.z * z1z1;
   F h = u2 - u1;
-  F rr = (s2 - s1).dbl();
+  F rr = s2 - s1;
   if (!p_inf && !q_inf && h.is_zero()) {
     if (rr.is_zero()) return jac_dbl(p);
     return Jac<F>::infinity();
   }
-  F i = h.dbl().sqr();
-  F j = h * i;
-  F v = u1 * i;
+  F hh = h.sqr();
+  F j = h * hh;
+  F v = u1 * hh;
   Jac<F> r;
-  r.x = coord_norm(rr.sqr() - j - v.dbl());
-  r.y = coord_norm(rr * (v - r.x) - (s1 * j).dbl());
-  r.z = coord_norm(((p.z + q.z).sqr() - z1z1 - z2z2) * h);
+  r.x = coord_norm((rr.sqr() - j - v.dbl()).norm().dbl().dbl());
+  r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (s1 * j).dbl().dbl()).norm().dbl());
+  r.z = coord_norm(((p.z + q.z).norm().sqr() - z1z1 - z2z2).norm() * h);
   if (q_inf) r = p;
   if (p_inf) r = q;
   return r;
@@ -112,7 +118,7 @@ TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
 
 template <class F>
 TC_HD Jac<F> jac_neg(const Jac<F>& p) {
-  return Jac<F>{p.x, -p.y, p.z};
+  return Jac<F>{p.x, (-p.y).norm(), p.z};
 }
 
 template <class F>
@@ -176,11 +182,11 @@ TC_HD bool affine_on_curve(const Affine<F>& p, const F& b) {
   return p.y.sqr() == p.x.sqr() * p.x + b;
 }
 
-TC_HD Fq g1_b() { return Fq::from_limbs(FQ26_B1); }
+TC_HD Fq g1_b() { return Fq::from_limbs(FQL_B1); }
 TC_HD Fq2 g2_b() { return Fq2::make(g1_b(), g1_b()); }
 
 TC_HD Affine<Fq> g1_generator() {
-  return Affine<Fq>{Fq::from_limbs(G1_GEN26_X), Fq::from_limbs(G1_GEN26_Y), false};
+  return Affine<Fq>{Fq::from_limbs(G1_GENL_X), Fq::from_limbs(G1_GENL_Y), false};
 }
 
 using G1Affine = Affine<Fq>;

@@ -1,17 +1,22 @@
 // Prime-field arithmetic for gfx950.
 //
-//   Fq (BLS12-381 base field, 381 bit) -- the hot field: REDUCED RADIX, 15 signed limbs of
-//      26 bits in 32-bit VGPRs, Montgomery form with R = 2^390.  On gfx950 a VALU carry-out
+//   Fq (BLS12-381 base field, 381 bit) -- the hot field: REDUCED RADIX, 14 signed limbs of
+//      28 bits in 32-bit VGPRs, Montgomery form with R = 2^392.  On gfx950 a VALU carry-out
 //      feeding a VALU carry-in costs two wait states (the compiler pads every v_add_co ->
 //      v_addc pair), so saturated 32-bit limbs make every add/sub/multiply-accumulate a serial,
-//      padded carry chain.  With 26-bit limbs nothing carries:
-//        * a + b, a - b, -a, 2a are 15 independent v_add/v_sub (lazy, no reduction);
+//      padded carry chain.  With 28-bit limbs nothing carries:
+//        * a + b, a - b, -a, 2a are 14 independent v_add/v_sub (lazy, no reduction);
 //        * a product column is a chain of v_mad_i64_i32 into one 64-bit accumulator
-//          (15 * 2^52 * 129 < 2^63), the carry into the next column is one 64-bit shift;
+//          (14 * 2^56 * 9.14 = 2^63), the carry into the next column is one 64-bit shift;
 //        * reduction is interleaved per column (product scanning), quotient digit
-//          m_k = column * (-p^-1) mod 2^26.
-//      Limbs may grow to |l_i| < 2^26 * B through lazy additions; a multiplication needs
-//      B_a * B_b <= 128.  `norm()` (one parallel carry pass) brings B back to ~1.
+//          m_k = column * (-p^-1) mod 2^28.
+//      14 limbs are the fewest that hold 381 bits with any headroom: a limb product is 196
+//      multiply-adds (15 x 26-bit limbs, the previous layout: 225; measured -9..11 % kernel time).
+//      The price is a tight budget: lazy limbs must stay below 8 * 2^28 (int32) and a
+//      multiplication needs B_a * B_b <= 8 (sum of the two products of an Fq2 coefficient <= 8),
+//      so formulas apply small multiples AFTER products and pass sums through `norm()` (one
+//      parallel carry pass) where needed.  Every such decision is checked, not trusted: the
+//      interval analysis of tests/hostsim -DTC_BOUND_CHECK walks every job body.
 //   Fr (scalar field, 255 bit) -- off the hot path (Lagrange coefficients only): plain
 //      saturated 8 x u32 Montgomery (R = 2^256), compiler-scheduled.
 //
@@ -231,12 +236,12 @@ TC_HD Fr fr_from_u64(uint64_t x) {
 }
 
 // =======================================================================================
-// Fq: 15 x 26-bit signed limbs, R = 2^390
+// Fq: 14 x 28-bit signed limbs, R = 2^392
 // =======================================================================================
-constexpr int FQ_LIMBS = 15;
-constexpr int FQ_RADIX = 26;
+constexpr int FQ_LIMBS = FQ_LIMBS_GEN;
+constexpr int FQ_RADIX = FQ_RADIX_GEN;
 constexpr int32_t FQ_MASK = (1 << FQ_RADIX) - 1;
-constexpr int FQ_MAX_BOUND_PRODUCT = 128;  // B_a * B_b allowed at a multiplication
+constexpr float FQ_MAX_BOUND_PRODUCT = 8.14f;  // B_a * B_b allowed at a multiplication: 14 * 2^56 * (8 + 1) < 2^63
 
 #if defined(TC_COUNT_OPS)
 // host-only (tests/hostsim): multiplications / squarings executed, for the "ours M/unit"
@@ -273,7 +278,7 @@ struct Fq {
     blo = lo;
     bhi = hi;
     // the limbs themselves are int32: |l_i| < 2^31 = 32 * 2^26 (keep a margin for norm()'s carry-in)
-    if (lo < -31.f || hi > 31.f) tc_bound_fail(lo, hi);
+    if (lo < -7.9f || hi > 7.9f) tc_bound_fail(lo, hi);
   }
   TC_HD void set_val(float v) { bval = v; }
   TC_HD float lo() const { return blo; }
@@ -303,7 +308,7 @@ struct Fq {
     r.set_val(0.f);
     return r;
   }
-  TC_HD static Fq one() { return from_limbs(FQ26_ONE); }
+  TC_HD static Fq one() { return from_limbs(FQL_ONE); }
 
   // ---- lazy linear operations: no carries, no reduction --------------------------------
   TC_HD Fq operator+(const Fq& b) const {
@@ -341,7 +346,7 @@ struct Fq {
     r.l[0] = l[0] & FQ_MASK;
     TC_UNROLL for (int i = 1; i < FQ_LIMBS - 1; i++) r.l[i] = (l[i] & FQ_MASK) + (l[i - 1] >> FQ_RADIX);
     r.l[FQ_LIMBS - 1] = l[FQ_LIMBS - 1] + (l[FQ_LIMBS - 2] >> FQ_RADIX);
-    r.set_range(-0.01f, 1.01f);
+    r.set_range(-0.001f, 1.001f);
     r.set_val(val());
 #if defined(TC_BOUND_CHECK)
     if (val() > 300.f) tc_bound_fail(val(), -1.f);  // the top limb (~ V * 2^17.7) must stay below 2^26 too
@@ -356,15 +361,15 @@ struct Fq {
   // Requires |value| <= 300 p.  ~105 VALU instructions, no multiplier-sized work.
   TC_HD Fq reduce_value() const {
     Fq n = norm();
-    const int32_t k = (int32_t)__builtin_floorf((float)n.l[FQ_LIMBS - 1] * (1.0f / (float)FQ26_P[FQ_LIMBS - 1]));
+    const int32_t k = (int32_t)__builtin_floorf((float)n.l[FQ_LIMBS - 1] * (1.0f / (float)FQL_P[FQ_LIMBS - 1]));
     int64_t t[FQ_LIMBS];
-    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) t[i] = (int64_t)n.l[i] - (int64_t)k * FQ26_P[i];
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) t[i] = (int64_t)n.l[i] - (int64_t)k * FQL_P[i];
     Fq r;
     r.l[0] = (int32_t)((uint32_t)t[0] & (uint32_t)FQ_MASK);
     TC_UNROLL for (int i = 1; i < FQ_LIMBS - 1; i++)
       r.l[i] = (int32_t)((uint32_t)t[i] & (uint32_t)FQ_MASK) + (int32_t)(t[i - 1] >> FQ_RADIX);
     r.l[FQ_LIMBS - 1] = (int32_t)(t[FQ_LIMBS - 1] + (t[FQ_LIMBS - 2] >> FQ_RADIX));
-    r.set_range(-0.01f, 1.01f);
+    r.set_range(-0.001f, 1.001f);
     r.set_val(2.1f);
     return r;
   }
@@ -387,7 +392,7 @@ struct Fq {
 #if defined(TC_BOUND_CHECK)
     if (val() > 300.f) tc_bound_fail(val(), -2.f);
 #endif
-    const uint32_t t = ((uint32_t)l[0] * FQ26_INV) & (uint32_t)FQ_MASK;  // = -k mod 2^26
+    const uint32_t t = ((uint32_t)l[0] * FQL_INV) & (uint32_t)FQ_MASK;  // = -k mod 2^26
     return ((t + 300u) & (uint32_t)FQ_MASK) <= 600u;
   }
   TC_HD_NOINLINE bool is_zero_full() const;
@@ -404,7 +409,7 @@ struct Fq {
 // Product-scanning Montgomery multiplication.  Column k gathers sum a_i b_{k-i} (chain 1, with
 // the carry from column k-1) and sum m_i p_{k-i} (chain 2): two independent v_mad_i64_i32
 // dependency chains, so a lone wave on a SIMD still overlaps multiplier latency.
-//   T = a*b + m*p,  T = 0 mod 2^390,  result = T / 2^390  in (-p/4, 5p/4)
+//   T = a*b + m*p,  T = 0 mod R,  result = T / R  in (-p/4, 5p/4)
 template <bool SQUARE>
 TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
   constexpr int N = FQ_LIMBS;
@@ -430,13 +435,13 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
       TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)a[i] * b[k - i];
     }
     if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
       int64_t s = s1 + s2;
-      m[k] = (int32_t)(((uint32_t)s * FQ26_INV) & (uint32_t)FQ_MASK);
-      s += (int64_t)m[k] * FQ26_P[0];
+      m[k] = (int32_t)(((uint32_t)s * FQL_INV) & (uint32_t)FQ_MASK);
+      s += (int64_t)m[k] * FQL_P[0];
       carry = s >> FQ_RADIX;
     } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
       int64_t s = s1 + s2;
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
@@ -445,12 +450,12 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
   out[N - 1] = (int32_t)carry;
 }
 
-// Two products, one reduction:  out = (x*y + z*w + m*p) / 2^390.  This is what one lane of an
+// Two products, one reduction:  out = (x*y + z*w + m*p) / R.  This is what one lane of an
 // Fq2 lane pair computes for its own coefficient of a product (c0 = a0 b0 - a1 b1 or
-// c1 = a0 b1 + a1 b0): 675 multiply-adds instead of the 900 two separate Montgomery
+// c1 = a0 b1 + a1 b0): 588 multiply-adds instead of the 784 two separate Montgomery
 // multiplications would take, and three independent chains per column.
-// Column bound: 15 * 2^52 * (Bx By + Bz Bw + 1) < 2^63  <=>  Bx By + Bz Bw < 135.
-constexpr int FQ_MAX_BOUND_PRODUCT2 = 134;
+// Column bound: 14 * 2^56 * (Bx By + Bz Bw + 1) < 2^63  <=>  Bx By + Bz Bw < 8.14.
+constexpr float FQ_MAX_BOUND_PRODUCT2 = 8.14f;
 TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, const int32_t* w, int32_t* out) {
   constexpr int N = FQ_LIMBS;
   int32_t m[N];
@@ -467,13 +472,13 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
       s1 += (int64_t)z[i] * w[k - i];
     }
     if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
       int64_t s = s1 + s2;
-      m[k] = (int32_t)(((uint32_t)s * FQ26_INV) & (uint32_t)FQ_MASK);
-      s += (int64_t)m[k] * FQ26_P[0];
+      m[k] = (int32_t)(((uint32_t)s * FQL_INV) & (uint32_t)FQ_MASK);
+      s += (int64_t)m[k] * FQL_P[0];
       carry = s >> FQ_RADIX;
     } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQ26_P[k - i];
+      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
       int64_t s = s1 + s2;
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
@@ -491,22 +496,15 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
 struct FqRaw {
   int32_t l[FQ_LIMBS];
 };
-__device__ __attribute__((noinline)) inline FqRaw fq_mul_call(
-    int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8,
-    int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t a14, int32_t b0, int32_t b1, int32_t b2,
-    int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11,
-    int32_t b12, int32_t b13, int32_t b14) {
-  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
-  const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14};
+__device__ __attribute__((noinline)) inline FqRaw fq_mul_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
+  const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13};
   FqRaw r;
   fq_mul_body<false>(a, b, r.l);
   return r;
 }
-__device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3,
-                                                              int32_t a4, int32_t a5, int32_t a6, int32_t a7,
-                                                              int32_t a8, int32_t a9, int32_t a10, int32_t a11,
-                                                              int32_t a12, int32_t a13, int32_t a14) {
-  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
+__device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
   FqRaw r;
   fq_mul_body<true>(a, a, r.l);
   return r;
@@ -518,13 +516,9 @@ __device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_
 // still passes only its own 15 + 15 limbs (+ the lane parity) in VGPRs.
 //   even lane: c0 = a0 b0 - a1 b1 = mine*mine' + (-other)*other'
 //   odd  lane: c1 = a1 b0 + a0 b1 = mine*other' + other*mine'
-__device__ __attribute__((noinline)) inline FqRaw fq2p_mul_call(
-    int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8,
-    int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t a14, int32_t b0, int32_t b1, int32_t b2,
-    int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11,
-    int32_t b12, int32_t b13, int32_t b14, int32_t odd) {
-  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
-  const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14};
+__device__ __attribute__((noinline)) inline FqRaw fq2p_mul_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13, int32_t odd) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
+  const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13};
   int32_t y[FQ_LIMBS], z[FQ_LIMBS], w[FQ_LIMBS];
   const bool o = odd != 0;
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
@@ -539,11 +533,8 @@ __device__ __attribute__((noinline)) inline FqRaw fq2p_mul_call(
   return r;
 }
 //   even lane: c0 = (a0 + a1)(a0 - a1);   odd lane: c1 = (2 a1) a0
-__device__ __attribute__((noinline)) inline FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3,
-                                                                int32_t a4, int32_t a5, int32_t a6, int32_t a7,
-                                                                int32_t a8, int32_t a9, int32_t a10, int32_t a11,
-                                                                int32_t a12, int32_t a13, int32_t a14, int32_t odd) {
-  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14};
+__device__ __attribute__((noinline)) inline FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t odd) {
+  const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
   int32_t x[FQ_LIMBS], y[FQ_LIMBS];
   const bool o = odd != 0;
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
@@ -565,9 +556,7 @@ TC_HD Fq fq_mul(const Fq& a, const Fq& b) {
 #endif
   Fq r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
-                        a.l[11], a.l[12], a.l[13], a.l[14], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6],
-                        b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12], b.l[13], b.l[14]);
+  FqRaw t = fq_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12], b.l[13]);
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = t.l[i];
 #else
   fq_mul_body<false>(a.l, b.l, r.l);
@@ -577,7 +566,7 @@ TC_HD Fq fq_mul(const Fq& a, const Fq& b) {
 #endif
 #endif
   r.set_range(0.f, 1.f);
-  r.set_val(1.f + a.val() * b.val() / 512.f);  // |a b| / R + p, p / R < 2^-9
+  r.set_val(1.f + a.val() * b.val() / 2048.f);  // |a b| / R + p, p / R < 2^-9
   return r;
 }
 
@@ -588,8 +577,7 @@ TC_HD Fq fq_sqr(const Fq& a) {
 #endif
   Fq r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
-                        a.l[11], a.l[12], a.l[13], a.l[14]);
+  FqRaw t = fq_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13]);
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = t.l[i];
 #else
   fq_mul_body<true>(a.l, a.l, r.l);
@@ -599,7 +587,7 @@ TC_HD Fq fq_sqr(const Fq& a) {
 #endif
 #endif
   r.set_range(0.f, 1.f);
-  r.set_val(1.f + a.val() * a.val() / 512.f);
+  r.set_val(1.f + a.val() * a.val() / 2048.f);
   return r;
 }
 
@@ -608,8 +596,11 @@ TC_HD Fq fq_sqr(const Fq& a) {
 // g++ (test-harness) form, with the static bound bookkeeping.
 TC_HD Fq fq_mul2(const Fq& x, const Fq& y, const Fq& z, const Fq& w) {
 #if defined(TC_BOUND_CHECK)
-  if (x.bound() * y.bound() + z.bound() * w.bound() > (float)FQ_MAX_BOUND_PRODUCT2)
+  if (x.bound() * y.bound() + z.bound() * w.bound() > (float)FQ_MAX_BOUND_PRODUCT2) {
+    fprintf(stderr, "fq_mul2 operand limb intervals: x [%.3f, %.3f] y [%.3f, %.3f] z [%.3f, %.3f] w [%.3f, %.3f]\n", x.lo(), x.hi(),
+            y.lo(), y.hi(), z.lo(), z.hi(), w.lo(), w.hi());
     tc_bound_fail(x.bound() * y.bound(), z.bound() * w.bound());
+  }
   if (x.val() > 300.f || y.val() > 300.f || z.val() > 300.f || w.val() > 300.f) tc_bound_fail(-x.val(), -y.val());
 #endif
   Fq r;
@@ -618,14 +609,15 @@ TC_HD Fq fq_mul2(const Fq& x, const Fq& y, const Fq& z, const Fq& w) {
   g_tc_mul2_count++;
 #endif
   r.set_range(0.f, 1.f);
-  r.set_val(1.f + (x.val() * y.val() + z.val() * w.val()) / 512.f);
+  r.set_val(1.f + (x.val() * y.val() + z.val() * w.val()) / 2048.f);
   return r;
 }
 
 // a / R mod p as the UNIQUE representative in [0, p]: limbs fully carried, all in [0, 2^26).
 // (T = a + m p with m in [0, R): T / R > -1 and <= p for |a| < R.)
 TC_HD void fq_redc_full(const Fq& a, int32_t* out) {
-  const int32_t one[FQ_LIMBS] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t one[FQ_LIMBS];
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) one[i] = (i == 0) ? 1 : 0;
   Fq an = a.norm();  // any lazily grown input is fine: bring limbs back below 2^27 first
   // the column loop masks limbs 0..13 and carries into the next column, so the output is
   // already fully carried: digits in [0, 2^26), top limb >= 0
@@ -638,7 +630,7 @@ TC_HD_NOINLINE bool Fq::is_zero_full() const {
   int32_t z = 0, e = 0;
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
     z |= t[i];
-    e |= (t[i] ^ FQ26_P[i]);
+    e |= (t[i] ^ FQL_P[i]);
   }
   return z == 0 || e == 0;
 }
@@ -649,7 +641,7 @@ TC_HD_NOINLINE Fq fq_inv_fermat(const Fq& a) {
   return field_pow_fixed(a.norm(), [](int i) { return FQ_P_MINUS_2[i]; }, 381);
 }
 
-TC_HD void words12_to_limbs26(const uint32_t* w, int32_t* l);
+TC_HD void words12_to_limbs(const uint32_t* w, int32_t* l);
 
 // Inverse by the binary extended GCD with Kaliski's bookkeeping ("almost Montgomery inverse"),
 // on the canonical integer a as 6 x u64:
@@ -728,42 +720,41 @@ TC_HD_NOINLINE Fq Fq::inv() const {
     sw[2 * i + 1] = (uint32_t)(s[i] >> 32);
   }
   Fq sp, pw;
-  words12_to_limbs26(sw, sp.l);
+  words12_to_limbs(sw, sp.l);
   sp.set_range(0.f, 1.f);
   sp.set_val(1.f);
-  // three Montgomery products take out 2^k and put in R:  s 2^e1 2^e2 2^790 / R^3 = s 2^(390-k)
-  // with e1 + e2 = 770 - k  (0 <= k <= 762), each a single-bit limb vector below 2^390
+  // three Montgomery products take out 2^k and put in R:  s 2^e1 2^e2 C / R^3 = s R 2^-k  with
+  // C = R^4 2^-770 and e1 + e2 = 770 - k  (0 <= k <= 762), each a single-bit limb vector below R
   const uint32_t e = 770u - k;
   const uint32_t e1 = e > 388u ? 388u : e, e2 = e - e1;  // 2^388 < 160 p: inside the multiplier's value bound
   Fq pw2;
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
-    pw.l[i] = ((uint32_t)i == e1 / 26u) ? (int32_t)(1u << (e1 % 26u)) : 0;
-    pw2.l[i] = ((uint32_t)i == e2 / 26u) ? (int32_t)(1u << (e2 % 26u)) : 0;
+    pw.l[i] = ((uint32_t)i == e1 / (uint32_t)FQ_RADIX) ? (int32_t)(1u << (e1 % (uint32_t)FQ_RADIX)) : 0;
+    pw2.l[i] = ((uint32_t)i == e2 / (uint32_t)FQ_RADIX) ? (int32_t)(1u << (e2 % (uint32_t)FQ_RADIX)) : 0;
   }
   pw.set_range(0.f, 0.5f);
   pw.set_val(160.f);
   pw2.set_range(0.f, 0.5f);
   pw2.set_val(160.f);
-  const Fq out = fq_mul(fq_mul(fq_mul(sp, pw), pw2), Fq::from_limbs(FQ26_POW2_790));
+  const Fq out = fq_mul(fq_mul(fq_mul(sp, pw), pw2), Fq::from_limbs(FQL_POW2_INVFIX));
   return Fq::select(nonzero, out, Fq::zero());
 }
 
-// 12 canonical u32 words (an integer < 2^384) -> 15 plain 26-bit limbs
-TC_HD void words12_to_limbs26(const uint32_t* w, int32_t* l) {
+// 12 canonical u32 words (an integer < 2^384) -> plain limbs
+TC_HD void words12_to_limbs(const uint32_t* w, int32_t* l) {
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
-    const int bit = 26 * i;
+    const int bit = FQ_RADIX * i;
     const int wi = bit >> 5, sh = bit & 31;
     uint64_t v = (uint64_t)w[wi] >> sh;
     if (wi + 1 < 12) v |= (uint64_t)w[wi + 1] << (32 - sh);
     l[i] = (int32_t)((uint32_t)v & (uint32_t)FQ_MASK);
   }
-  // limb 14 covers bits 364..389; bits above 383 do not exist in the input
 }
 
-TC_HD void limbs26_to_words12(const int32_t* l, uint32_t* w) {
+TC_HD void limbs_to_words12(const int32_t* l, uint32_t* w) {
   TC_UNROLL for (int i = 0; i < 12; i++) w[i] = 0;
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
-    const int bit = 26 * i;
+    const int bit = FQ_RADIX * i;
     const int wi = bit >> 5, sh = bit & 31;
     const uint64_t v = (uint64_t)(uint32_t)l[i] << sh;
     if (wi < 12) w[wi] |= (uint32_t)v;
@@ -774,10 +765,10 @@ TC_HD void limbs26_to_words12(const int32_t* l, uint32_t* w) {
 // canonical integer (12 little-endian u32 words, < p) -> Montgomery form
 TC_HD Fq Fq::from_canonical(const uint32_t* words12) {
   Fq a;
-  words12_to_limbs26(words12, a.l);
+  words12_to_limbs(words12, a.l);
   a.set_range(0.f, 1.f);
   a.set_val(1.f);
-  return fq_mul(a, Fq::from_limbs(FQ26_R2));
+  return fq_mul(a, Fq::from_limbs(FQL_R2));
 }
 
 // Montgomery form -> canonical integer in [0, p)
@@ -785,22 +776,22 @@ TC_HD void Fq::to_canonical(uint32_t* words12) const {
   int32_t t[FQ_LIMBS];
   fq_redc_full(*this, t);
   int32_t e = 0;
-  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) e |= (t[i] ^ FQ26_P[i]);
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) e |= (t[i] ^ FQL_P[i]);
   if (e == 0) {
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) t[i] = 0;  // the representative p is 0
   }
-  limbs26_to_words12(t, words12);
+  limbs_to_words12(t, words12);
 }
 
 // A 384-bit pattern that IS a Montgomery representation w.r.t. 2^384 (what ff_derive's
-// random() yields): value = pattern * 2^-384, so the R = 2^390 form is pattern * 2^6
-// = montmul(pattern, 2^396 mod p).
+// random() yields): value = pattern * 2^-384, so the R = 2^392 form is pattern * 2^8
+// = montmul(pattern, 2^400 mod p).
 TC_HD Fq Fq::from_mont384(const uint32_t* words12) {
   Fq a;
-  words12_to_limbs26(words12, a.l);
+  words12_to_limbs(words12, a.l);
   a.set_range(0.f, 1.f);
   a.set_val(1.f);
-  return fq_mul(a, Fq::from_limbs(FQ26_FIX384));
+  return fq_mul(a, Fq::from_limbs(FQL_FIX384));
 }
 
 // lexicographic "y > -y" test on the canonical value: y > (p-1)/2

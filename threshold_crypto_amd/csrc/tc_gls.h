@@ -104,8 +104,8 @@ TC_HD void g2_gls_bases(const G2Affine& p, G2Affine* base) {
   base[1] = g2_psi(p);
   base[2] = g2_psi(base[1]);
   base[3] = g2_psi(base[2]);
-  base[1].y = -base[1].y;
-  base[3].y = -base[3].y;
+  base[1].y = (-base[1].y).norm();
+  base[3].y = (-base[3].y).norm();
 }
 
 // [k] P for P in G2 (the order-r subgroup), k < r given as 8 LE u32 words
@@ -197,7 +197,7 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   G1Affine tbl[4];
   tbl[1] = p;
   tbl[2] = g1_phi(p);
-  tbl[2].y = -tbl[2].y;  // -phi(P) = [x^2] P
+  tbl[2].y = (-tbl[2].y).norm();  // -phi(P) = [x^2] P
   // P - phi(P) keeps its Jacobian (X, Y); the other two entries are scaled to its Z (tc_curve.h
   // jac_batch_to_common_z explains the isomorphic-curve argument)
   const G1Jac sum = jac_add_mixed(G1Jac::from_affine(p), tbl[2]);

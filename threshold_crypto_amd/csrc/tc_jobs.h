@@ -120,7 +120,7 @@ TC_HD bool job_combine_small(const uint64_t* idx, const uint8_t* shares, uint8_t
   bool ok = true;
   TC_NOUNROLL for (int k = 0; k < K; k++) {
     ok &= PointIO<F>::decode(shares + (size_t)k * PB, pts[k]);
-    if (c_neg[k]) pts[k].y = -pts[k].y;
+    if (c_neg[k]) pts[k].y = (-pts[k].y).norm();
   }
   if (!ok) {
     PointIO<F>::encode(Affine<F>::infinity(), out);

@@ -16,19 +16,20 @@ struct LineCoeffs {
   Fq2 c0, c1, c2;
 };
 
-// Algorithm 26 of eprint 2010/354 (Jacobian doubling + tangent line), a = 0.
+// Algorithm 26 of eprint 2010/354 (Jacobian doubling + tangent line), a = 0.  Small multiples are
+// applied after the products and sums are carry-normalised where the bound analysis asks (tc_curve.h).
 TC_MILLER_ATTR LineCoeffs miller_doubling_step(G2Jac& r) {
   Fq2 tmp0 = r.x.sqr();
   Fq2 tmp1 = r.y.sqr();
   Fq2 tmp2 = tmp1.sqr();
-  Fq2 tmp3 = ((tmp1 + r.x).sqr() - tmp0 - tmp2).dbl().norm();
-  Fq2 tmp4 = tmp0.dbl() + tmp0;
+  Fq2 t3h = ((tmp1 + r.x).sqr() - tmp0 - tmp2).norm();  // tmp3 = 2 t3h
+  Fq2 tmp4 = (tmp0.dbl() + tmp0).norm();
   Fq2 tmp6 = r.x + tmp4;
   Fq2 tmp5 = tmp4.sqr();
   Fq2 zsq = r.z.sqr();
-  Fq2 nx = (tmp5 - tmp3.dbl()).reduce_value();
+  Fq2 nx = (tmp5 - t3h.dbl().dbl()).reduce_value();
   Fq2 nz = ((r.z + r.y).sqr() - tmp1 - zsq).norm();
-  Fq2 ny = ((tmp3 - nx) * tmp4 - tmp2.dbl().dbl().dbl()).norm();
+  Fq2 ny = ((t3h.dbl() - nx) * tmp4 - tmp2.dbl().dbl().norm().dbl()).norm();
   LineCoeffs l;
   l.c1 = (-((tmp4 * zsq).dbl())).norm();
   l.c2 = (tmp6.sqr() - tmp0 - tmp5 - tmp1.dbl().dbl()).norm();
@@ -47,21 +48,20 @@ TC_MILLER_ATTR LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
   Fq2 t1 = ((q.y + r.z).sqr() - ysq - zsq) * zsq;
   Fq2 t2 = t0 - r.x;
   Fq2 t3 = t2.sqr();
-  Fq2 t4 = t3.dbl().dbl().norm();
-  Fq2 t5 = t4 * t2;
+  Fq2 t5q = t3 * t2;   // t5 = 4 t5q
   Fq2 t6 = (t1 - r.y.dbl()).norm();
   Fq2 t9 = t6 * q.x;
-  Fq2 t7 = t4 * r.x;
-  Fq2 nx = (t6.sqr() - t5 - t7.dbl()).norm();
-  Fq2 nz = ((r.z + t2).sqr() - zsq - t3).norm();
+  Fq2 t7q = t3 * r.x;  // t7 = 4 t7q
+  Fq2 nx = (t6.sqr() - (t5q + t7q.dbl()).norm().dbl().dbl()).norm();
+  Fq2 nz = ((r.z + t2).norm().sqr() - zsq - t3).norm();
   Fq2 t10 = q.y + nz;
-  Fq2 t8 = (t7 - nx) * t6;
-  Fq2 ny = (t8 - (r.y * t5).dbl()).norm();
+  Fq2 t8 = (t7q.dbl().dbl() - nx) * t6;
+  Fq2 ny = (t8 - (r.y * t5q).dbl().dbl().norm().dbl()).norm();
   t10 = t10.sqr() - ysq - nz.sqr();
   t9 = (t9.dbl() - t10).norm();
   LineCoeffs l;
   l.c0 = nz.dbl();
-  l.c1 = (-t6).dbl().norm();
+  l.c1 = (-t6).dbl();
   l.c2 = t9;
   r.x = nx;
   r.y = ny;
@@ -100,6 +100,12 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
     skip[k] = ps[k].inf || qs[k].inf;
     r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one()};
   }
+  // nothing to accumulate (every pair has an identity operand): the product of pairings is 1.
+  // (Also keeps the bare squarings of the loop below, whose outputs are only carry-normalised,
+  // always paired with a line multiplication that reduces the value.)
+  bool all_skipped = true;
+  TC_UNROLL for (int k = 0; k < NP; k++) all_skipped = all_skipped && skip[k];
+  if (all_skipped) return f;
   const uint64_t xs = BLS_X_ABS >> 1;
   LineCoeffs l[NP];
   TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
@@ -159,7 +165,7 @@ TC_HD_NOINLINE Fq12 final_exponentiation(const Fq12& f) {
 
 // e(a, b) == e(c, d)
 TC_HD bool pairing_check(const G1Affine& a, const G2Affine& b, const G1Affine& c, const G2Affine& d) {
-  G1Affine ps[2] = {a, G1Affine{c.x, -c.y, c.inf}};
+  G1Affine ps[2] = {a, G1Affine{c.x, (-c.y).norm(), c.inf}};
   G2Affine qs[2] = {b, d};
   Fq12 f = miller_loop<2>(ps, qs);
   return final_exponentiation(f) == Fq12::one();

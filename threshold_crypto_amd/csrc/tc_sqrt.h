@@ -26,11 +26,11 @@ TC_HD bool fq_sqrt(const Fq& a, Fq& root, Fq* inv_root = nullptr) {
   return root.sqr() == a;
 }
 
-TC_HD Fq fq_half(const Fq& a) { return a * Fq::from_limbs(FQ26_INV2); }
+TC_HD Fq fq_half(const Fq& a) { return a * Fq::from_limbs(FQL_INV2); }
 
 // Legendre symbol (a / q) by the binary Jacobi algorithm on the canonical integer: compares,
 // subtractions and shifts on 6 x u64, ~4x cheaper than the exponentiation a^((q-1)/2).
-// The Montgomery factor R = 2^390 is a square, so the symbol of the representative is the
+// The Montgomery factor R = 2^392 is a square, so the symbol of the representative is the
 // symbol of the value.  Wave-uniform loop (tc_common.h wave_any), branch-free body.
 // Returns +1, -1, or 0 for a = 0.
 TC_HD_NOINLINE int fq_legendre(const Fq& a) {

@@ -37,10 +37,7 @@ struct Fq2 {
     Fq2 r;
 #if defined(__HIP_DEVICE_COMPILE__)
     const Fq& a = m;
-    FqRaw t = fq2p_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
-                            a.l[11], a.l[12], a.l[13], a.l[14], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4],
-                            b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12],
-                            b.m.l[13], b.m.l[14], pair_odd());
+    FqRaw t = fq2p_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13], pair_odd());
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #else
     r = b;
@@ -51,8 +48,7 @@ struct Fq2 {
     Fq2 r;
 #if defined(__HIP_DEVICE_COMPILE__)
     const Fq& a = m;
-    FqRaw t = fq2p_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10],
-                            a.l[11], a.l[12], a.l[13], a.l[14], pair_odd());
+    FqRaw t = fq2p_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], pair_odd());
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #else
     r = *this;
@@ -160,7 +156,7 @@ struct Fq6 {
     Fq2 s0 = c0.sqr();
     Fq2 ab = c0 * c1;
     Fq2 s1 = ab.dbl();
-    Fq2 s2 = (c0 - c1 + c2).sqr();
+    Fq2 s2 = (c0 - c1 + c2).norm().sqr();
     Fq2 bc = c1 * c2;
     Fq2 s3 = bc.dbl();
     Fq2 s4 = c2.sqr();
@@ -194,18 +190,20 @@ struct Fq6 {
   // sparse: times (b1 v)
   TC_FQ6_ATTR Fq6 mul_by_1(const Fq2& b1) const { return TC_FQ6_OUT((Fq6{(c2 * b1).mul_xi(), c0 * b1, c1 * b1})); }
   TC_HD_NOINLINE Fq6 inv() const {
-    Fq2 t0 = c0.sqr() - (c1 * c2).mul_xi();
-    Fq2 t1 = c2.sqr().mul_xi() - c0 * c1;
-    Fq2 t2 = c1.sqr() - c0 * c2;
-    Fq2 d = c0 * t0 + (c2 * t1 + c1 * t2).mul_xi();
+    // (operands carry-normalised: the caller may hand in a difference of products)
+    const Fq6 n = this->norm();
+    Fq2 t0 = (n.c0.sqr() - (n.c1 * n.c2).mul_xi()).norm();
+    Fq2 t1 = (n.c2.sqr().mul_xi() - n.c0 * n.c1).norm();
+    Fq2 t2 = (n.c1.sqr() - n.c0 * n.c2).norm();
+    Fq2 d = (n.c0 * t0 + (n.c2 * t1 + n.c1 * t2).mul_xi()).norm();
     Fq2 di = d.inv();
     return Fq6{t0 * di, t1 * di, t2 * di}.norm();
   }
 };
 
 TC_HD Fq2 frob_coeff(int k, int i) {  // gamma_k[i], i = 1..5
-  const int32_t* a0 = (k == 1) ? FROB26_1_C0[i - 1] : (k == 2) ? FROB26_2_C0[i - 1] : FROB26_3_C0[i - 1];
-  const int32_t* a1 = (k == 1) ? FROB26_1_C1[i - 1] : (k == 2) ? FROB26_2_C1[i - 1] : FROB26_3_C1[i - 1];
+  const int32_t* a0 = (k == 1) ? FROBL_1_C0[i - 1] : (k == 2) ? FROBL_2_C0[i - 1] : FROBL_3_C0[i - 1];
+  const int32_t* a1 = (k == 1) ? FROBL_1_C1[i - 1] : (k == 2) ? FROBL_2_C1[i - 1] : FROBL_3_C1[i - 1];
   return Fq2::make(Fq::from_limbs(a0), Fq::from_limbs(a1));
 }
 
@@ -217,17 +215,17 @@ struct Fq12 {
     Fq6 t0 = c0 * b.c0;
     Fq6 t1 = c1 * b.c1;
     Fq12 r;
-    r.c1 = (c0 + c1) * (b.c0 + b.c1) - t0 - t1;
+    r.c1 = (c0 + c1).norm() * (b.c0 + b.c1).norm() - t0 - t1;
     r.c0 = t0 + t1.mul_by_v();
     return r.reduce_value();
   }
   // complex squaring over Fq6: 2 Fq6 mul
   TC_FQ12_ATTR Fq12 sqr() const {
     Fq6 ab = c0 * c1;
-    Fq6 t = (c0 + c1) * (c0 + c1.mul_by_v()) - ab - ab.mul_by_v();
+    Fq6 t = (c0 + c1).norm() * (c0 + c1.mul_by_v()).norm() - ab - ab.mul_by_v();
     return Fq12{t, ab + ab}.norm();
   }
-  TC_HD Fq12 conj() const { return Fq12{c0, -c1}; }
+  TC_HD Fq12 conj() const { return Fq12{c0, (-c1).norm()}; }
   TC_HD Fq12 norm() const { return Fq12{c0.norm(), c1.norm()}; }
   TC_HD Fq12 reduce_value() const { return Fq12{c0.reduce_value(), c1.reduce_value()}; }
   TC_HD_NOINLINE Fq12 inv() const {
@@ -240,7 +238,7 @@ struct Fq12 {
     Fq6 bb = c1.mul_by_1(d4);
     Fq2 o = d1 + d4;
     Fq12 r;
-    r.c1 = (c1 + c0).mul_by_01(d0, o) - aa - bb;
+    r.c1 = (c1 + c0).norm().mul_by_01(d0, o.norm()) - aa - bb;
     r.c0 = bb.mul_by_v() + aa;
     return r.norm();
   }
@@ -264,7 +262,7 @@ struct Fq12 {
     Fq6 t0 = c0 * l.c0;
     Fq6 t1 = c1.mul_by_12(l.c1.c1, l.c1.c2);
     Fq12 r;
-    r.c1 = (c0 + c1) * (l.c0 + l.c1) - t0 - t1;
+    r.c1 = (c0 + c1).norm() * (l.c0 + l.c1).norm() - t0 - t1;
     r.c0 = t0 + t1.mul_by_v();
     return r.reduce_value();
   }
@@ -289,24 +287,24 @@ struct Fq12 {
     // fp4 square (z0, z1)
     {
       Fq2 a2 = z0.sqr(), b2 = z1.sqr();
-      t0 = b2.mul_xi() + a2;
+      t0 = (b2.mul_xi() + a2).norm();
       t1 = (z0 + z1).sqr() - a2 - b2;
     }
     z0 = (t0 - z0).dbl() + t0;
     z1 = (t1 + z1).dbl() + t1;
     {
       Fq2 a2 = z2.sqr(), b2 = z3.sqr();
-      t0 = b2.mul_xi() + a2;
+      t0 = (b2.mul_xi() + a2).norm();
       t1 = (z2 + z3).sqr() - a2 - b2;
     }
     {
       Fq2 a2 = z4.sqr(), b2 = z5.sqr();
-      t2 = b2.mul_xi() + a2;
+      t2 = (b2.mul_xi() + a2).norm();
       t3 = (z4 + z5).sqr() - a2 - b2;
     }
     z4 = (t0 - z4).dbl() + t0;
     z5 = (t1 + z5).dbl() + t1;
-    Fq2 t3x = t3.mul_xi();
+    Fq2 t3x = t3.mul_xi().norm();
     z2 = (t3x + z2).dbl() + t3x;
     z3 = (t2 - z3).dbl() + t2;
     Fq12 r;

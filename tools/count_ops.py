@@ -2,9 +2,9 @@
 """Counts the limb multiply-adds each per-lane job body executes (host build of the device source
 with -DTC_COUNT_OPS).  Source of the EXECUTED table in bench.py and DESIGN.md.
 
-One 15x15 limb product or one Montgomery reduction is 225 v_mad:
-    Fq product 450, Fq squaring 345, one coefficient of an Fq2 product (two products, one
-    reduction, tc_field.h fq_mul2) 675.
+One 14x14 limb product or one Montgomery reduction is 196 v_mad:
+    Fq product 392, Fq squaring 301 (105 + 196), one coefficient of an Fq2 product (two products,
+    one reduction, tc_field.h fq_mul2) 588.
 In a G2 kernel two lanes work on a job: operations inside Fq2 methods are split between them
 (counted once), Fq operations outside (inversions, square-root exponentiations) run on both lanes
 (counted twice).  G1 kernels run one lane per job."""
@@ -33,7 +33,7 @@ def cnt():
 def macs(c, lanes):
     mul2, smul, ssqr, mul, sqr = c
     local_mul, local_sqr = mul - smul, sqr - ssqr
-    return mul2 * 675 + smul * 450 + ssqr * 345 + lanes * (local_mul * 450 + local_sqr * 345)
+    return mul2 * 588 + smul * 392 + ssqr * 301 + lanes * (local_mul * 392 + local_sqr * 301)
 
 
 rnd = random.Random(1)

@@ -30,19 +30,19 @@ __global__ __launch_bounds__(256) void k_single(const int32_t* in, int32_t* out,
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= jobs) return;
   S2 x, y;
-  for (int i = 0; i < 15; i++) {
-    x.c0.l[i] = in[(j * 4 + 0) * 15 + i];
-    x.c1.l[i] = in[(j * 4 + 1) * 15 + i];
-    y.c0.l[i] = in[(j * 4 + 2) * 15 + i];
-    y.c1.l[i] = in[(j * 4 + 3) * 15 + i];
+  for (int i = 0; i < FQ_LIMBS; i++) {
+    x.c0.l[i] = in[(j * 4 + 0) * FQ_LIMBS + i];
+    x.c1.l[i] = in[(j * 4 + 1) * FQ_LIMBS + i];
+    y.c0.l[i] = in[(j * 4 + 2) * FQ_LIMBS + i];
+    y.c1.l[i] = in[(j * 4 + 3) * FQ_LIMBS + i];
   }
   TC_NOUNROLL for (int it = 0; it < ITERS; it++) {
     x = x * y;
     y = y.sqr() + x;
   }
-  for (int i = 0; i < 15; i++) {
-    out[(j * 2 + 0) * 15 + i] = y.c0.norm().l[i];
-    out[(j * 2 + 1) * 15 + i] = y.c1.norm().l[i];
+  for (int i = 0; i < FQ_LIMBS; i++) {
+    out[(j * 2 + 0) * FQ_LIMBS + i] = y.c0.norm().l[i];
+    out[(j * 2 + 1) * FQ_LIMBS + i] = y.c1.norm().l[i];
   }
 }
 
@@ -52,20 +52,16 @@ struct P {
 __device__ __forceinline__ P pmul(const P& a, const P& b, int odd) {
   P r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq2p_mul_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8],
-                          a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], a.m.l[14], b.m.l[0], b.m.l[1],
-                          b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10],
-                          b.m.l[11], b.m.l[12], b.m.l[13], b.m.l[14], odd);
-  for (int i = 0; i < 15; i++) r.m.l[i] = t.l[i];
+  FqRaw t = fq2p_mul_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13], odd);
+  for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #endif
   return r;
 }
 __device__ __forceinline__ P psqr(const P& a, int odd) {
   P r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq2p_sqr_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8],
-                          a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], a.m.l[14], odd);
-  for (int i = 0; i < 15; i++) r.m.l[i] = t.l[i];
+  FqRaw t = fq2p_sqr_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], odd);
+  for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #endif
   return r;
 }
@@ -75,32 +71,32 @@ __global__ __launch_bounds__(256) void k_pair(const int32_t* in, int32_t* out, i
   const int j = t >> 1, odd = t & 1;
   if (j >= jobs) return;
   P x, y;
-  for (int i = 0; i < 15; i++) {
-    x.m.l[i] = in[(j * 4 + 0 + odd) * 15 + i];
-    y.m.l[i] = in[(j * 4 + 2 + odd) * 15 + i];
+  for (int i = 0; i < FQ_LIMBS; i++) {
+    x.m.l[i] = in[(j * 4 + 0 + odd) * FQ_LIMBS + i];
+    y.m.l[i] = in[(j * 4 + 2 + odd) * FQ_LIMBS + i];
   }
   TC_NOUNROLL for (int it = 0; it < ITERS; it++) {
     x = pmul(x, y, odd);
     P s = psqr(y, odd);
-    for (int i = 0; i < 15; i++) y.m.l[i] = s.m.l[i] + x.m.l[i];
+    for (int i = 0; i < FQ_LIMBS; i++) y.m.l[i] = s.m.l[i] + x.m.l[i];
   }
-  for (int i = 0; i < 15; i++) out[(j * 2 + odd) * 15 + i] = y.m.norm().l[i];
+  for (int i = 0; i < FQ_LIMBS; i++) out[(j * 2 + odd) * FQ_LIMBS + i] = y.m.norm().l[i];
 }
 
 int main(int argc, char** argv) {
   const int jobs = argc > 1 ? atoi(argv[1]) : 65536;
-  int32_t* h = (int32_t*)malloc((size_t)jobs * 60 * 4);
+  int32_t* h = (int32_t*)malloc((size_t)jobs * 4 * FQ_LIMBS * 4);
   uint64_t s = 88172645463325252ull;
-  for (size_t i = 0; i < (size_t)jobs * 60; i++) {
+  for (size_t i = 0; i < (size_t)jobs * 4 * FQ_LIMBS; i++) {
     s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-    h[i] = (int32_t)(s & 0x3ffffff);
-    if (i % 15 == 14) h[i] &= 0xfffff;  // keep the value below ~p
+    h[i] = (int32_t)(s & ((1 << FQ_RADIX) - 1));
+    if (i % FQ_LIMBS == FQ_LIMBS - 1) h[i] &= 0xffff;  // keep the value below ~p
   }
   int32_t *d_in, *d_a, *d_b;
-  hipMalloc(&d_in, (size_t)jobs * 60 * 4);
-  hipMalloc(&d_a, (size_t)jobs * 30 * 4);
-  hipMalloc(&d_b, (size_t)jobs * 30 * 4);
-  hipMemcpy(d_in, h, (size_t)jobs * 60 * 4, hipMemcpyHostToDevice);
+  hipMalloc(&d_in, (size_t)jobs * 4 * FQ_LIMBS * 4);
+  hipMalloc(&d_a, (size_t)jobs * 2 * FQ_LIMBS * 4);
+  hipMalloc(&d_b, (size_t)jobs * 2 * FQ_LIMBS * 4);
+  hipMemcpy(d_in, h, (size_t)jobs * 4 * FQ_LIMBS * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -120,15 +116,15 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     if (r && ms < ms_b) ms_b = ms;
   }
-  int32_t* ha = (int32_t*)malloc((size_t)jobs * 30 * 4);
-  int32_t* hb = (int32_t*)malloc((size_t)jobs * 30 * 4);
-  hipMemcpy(ha, d_a, (size_t)jobs * 30 * 4, hipMemcpyDeviceToHost);
-  hipMemcpy(hb, d_b, (size_t)jobs * 30 * 4, hipMemcpyDeviceToHost);
+  int32_t* ha = (int32_t*)malloc((size_t)jobs * 2 * FQ_LIMBS * 4);
+  int32_t* hb = (int32_t*)malloc((size_t)jobs * 2 * FQ_LIMBS * 4);
+  hipMemcpy(ha, d_a, (size_t)jobs * 2 * FQ_LIMBS * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(hb, d_b, (size_t)jobs * 2 * FQ_LIMBS * 4, hipMemcpyDeviceToHost);
   // the two representations may differ by multiples of p; compare through a canonical check
   // on the host is overkill here: print a few limbs for eyeballing and the raw mismatch count
   size_t diff = 0;
-  for (size_t i = 0; i < (size_t)jobs * 30; i++) diff += (ha[i] != hb[i]);
-  const double macs = (double)jobs * ITERS * (1350.0 + 900.0);
+  for (size_t i = 0; i < (size_t)jobs * 2 * FQ_LIMBS; i++) diff += (ha[i] != hb[i]);
+  const double macs = (double)jobs * ITERS * (double)(6 * FQ_LIMBS * FQ_LIMBS + 4 * FQ_LIMBS * FQ_LIMBS);
   printf("{\"jobs\": %d, \"iters\": %d, \"single_ms\": %.3f, \"pair_ms\": %.3f, \"single_TMACs\": %.2f, \"pair_TMACs\": %.2f, \"limb_mismatch\": %zu}\n",
          jobs, ITERS, ms_a, ms_b, macs / ms_a * 1e-9, macs / ms_b * 1e-9, diff);
   return 0;
