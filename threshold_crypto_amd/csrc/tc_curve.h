@@ -110,7 +110,7 @@ TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   Jac<F> r;
   r.x = coord_norm((rr.sqr() - j - v.dbl()).norm().dbl().dbl());
   r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (s1 * j).dbl().dbl()).norm().dbl());
-  r.z = coord_norm(((p.z + q.z).norm().sqr() - z1z1 - z2z2).norm() * h);
+  r.z = coord_norm(((p.z + q.z).sqr() - z1z1 - z2z2) * h);
   if (q_inf) r = p;
   if (p_inf) r = q;
   return r;
@@ -118,7 +118,7 @@ TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
 
 template <class F>
 TC_HD Jac<F> jac_neg(const Jac<F>& p) {
-  return Jac<F>{p.x, (-p.y).norm(), p.z};
+  return Jac<F>{p.x, (-p.y), p.z};
 }
 
 template <class F>

@@ -24,11 +24,11 @@ TC_HD Fq2 psi_cy() { return Fq2::make(Fq::from_limbs(PSI_CY_C0), Fq::from_limbs(
 
 TC_HD G2Affine g2_psi(const G2Affine& p) {
   if (p.inf) return p;
-  return G2Affine{(p.x.conj() * psi_cx()).norm(), (p.y.conj() * psi_cy()).norm(), false};
+  return G2Affine{(p.x.conj() * psi_cx()), (p.y.conj() * psi_cy()), false};
 }
 
 TC_HD_NOINLINE G2Jac g2_psi(const G2Jac& p) {
-  return G2Jac{(p.x.conj() * psi_cx()).norm(), (p.y.conj() * psi_cy()).norm(), p.z.conj().norm()};
+  return G2Jac{(p.x.conj() * psi_cx()), (p.y.conj() * psi_cy()), p.z.conj()};
 }
 
 // k (8 little-endian u32 words, < r < |x|^4) -> four base-|x| digits.  Binary long division on
@@ -197,7 +197,7 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   G1Affine tbl[4];
   tbl[1] = p;
   tbl[2] = g1_phi(p);
-  tbl[2].y = (-tbl[2].y).norm();  // -phi(P) = [x^2] P
+  tbl[2].y = (-tbl[2].y);  // -phi(P) = [x^2] P
   // P - phi(P) keeps its Jacobian (X, Y); the other two entries are scaled to its Z (tc_curve.h
   // jac_batch_to_common_z explains the isomorphic-curve argument)
   const G1Jac sum = jac_add_mixed(G1Jac::from_affine(p), tbl[2]);

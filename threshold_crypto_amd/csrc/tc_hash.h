@@ -215,7 +215,7 @@ TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words) {
     const Fq2 negy = -y;
     // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
     const bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
-    G2Affine cand{pick.x, (y_lt_negy ^ pick.greatest) ? y : negy.norm(), false};
+    G2Affine cand{pick.x, (y_lt_negy ^ pick.greatest) ? y : negy, false};
     res = g2_clear_cofactor(cand);  // = [h2] cand, the value scale_by_cofactor returns
     done = !res.is_inf();
 #if defined(TC_TEST_HOOKS)

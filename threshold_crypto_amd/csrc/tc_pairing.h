@@ -31,9 +31,9 @@ TC_MILLER_ATTR LineCoeffs miller_doubling_step(G2Jac& r) {
   Fq2 nz = ((r.z + r.y).sqr() - tmp1 - zsq).norm();
   Fq2 ny = ((t3h.dbl() - nx) * tmp4 - tmp2.dbl().dbl().norm().dbl()).norm();
   LineCoeffs l;
-  l.c1 = (-((tmp4 * zsq).dbl())).norm();
+  l.c1 = (-((tmp4 * zsq).dbl()));
   l.c2 = (tmp6.sqr() - tmp0 - tmp5 - tmp1.dbl().dbl()).norm();
-  l.c0 = (nz * zsq).dbl().norm();
+  l.c0 = (nz * zsq).dbl();
   r.x = nx;
   r.y = ny;
   r.z = nz;
@@ -165,7 +165,7 @@ TC_HD_NOINLINE Fq12 final_exponentiation(const Fq12& f) {
 
 // e(a, b) == e(c, d)
 TC_HD bool pairing_check(const G1Affine& a, const G2Affine& b, const G1Affine& c, const G2Affine& d) {
-  G1Affine ps[2] = {a, G1Affine{c.x, (-c.y).norm(), c.inf}};
+  G1Affine ps[2] = {a, G1Affine{c.x, (-c.y), c.inf}};
   G2Affine qs[2] = {b, d};
   Fq12 f = miller_loop<2>(ps, qs);
   return final_exponentiation(f) == Fq12::one();

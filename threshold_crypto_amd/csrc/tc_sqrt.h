@@ -15,7 +15,7 @@ namespace tc {
 
 // a^((q-3)/4).  For a square a != 0:  a * w is a square root of a and w = 1 / (a * w).
 TC_HD_NOINLINE Fq fq_pow_qm3d4(const Fq& a) {
-  return field_pow_fixed(a.norm(), [](int i) { return FQ_P_MINUS_3_DIV_4[i]; }, 379);
+  return field_pow_fixed(a, [](int i) { return FQ_P_MINUS_3_DIV_4[i]; }, 379);
 }
 
 // root of a in Fq; false if a is not a square.  inv_root (optional) receives 1/root.
@@ -120,12 +120,12 @@ TC_HD_NOINLINE Fq2 fq2_sqrt_of_square(const Fq2& a, const Fq& norm) {
   Fq x0, x0inv;
 #if TC_PAIR
   const bool odd = pair_odd() != 0;
-  const bool mine_ok = fq_sqrt(Fq::select(odd, dm, dp).norm(), x0, &x0inv);
+  const bool mine_ok = fq_sqrt(Fq::select(odd, dm, dp), x0, &x0inv);
   x0 = Fq::select(mine_ok, x0, Fq2{x0}.other());
   x0inv = Fq::select(mine_ok, x0inv, Fq2{x0inv}.other());
   // (exactly one lane succeeds: dp * dm = -a1^2 / 4 is a non-square)
 #else
-  if (!fq_sqrt(dp, x0, &x0inv)) fq_sqrt(dm.norm(), x0, &x0inv);
+  if (!fq_sqrt(dp, x0, &x0inv)) fq_sqrt(dm, x0, &x0inv);
 #endif
   return Fq2::make(x0, fq_half(im * x0inv));
 }
@@ -170,7 +170,7 @@ TC_HD bool g1_decode_compressed(const uint8_t* b, G1Affine& p) {
   if (!fq_sqrt(x.sqr() * x + g1_b(), y)) return false;
   const bool greatest = (f & 0x20) != 0;
   if (fq_lex_largest(y) != greatest) y = -y;
-  p = G1Affine{x, y.norm(), false};
+  p = G1Affine{x, y, false};
   return g1_in_subgroup(p);
 }
 
@@ -188,7 +188,7 @@ TC_HD bool g2_decode_compressed(const uint8_t* b, G2Affine& p) {
   if (!fq2_sqrt(x.sqr() * x + g2_b(), y)) return false;
   const bool greatest = (f & 0x20) != 0;
   if (fq2_lex_largest(y) != greatest) y = -y;
-  p = G2Affine{x, y.norm(), false};
+  p = G2Affine{x, y, false};
   return g2_in_subgroup(p);
 }
 

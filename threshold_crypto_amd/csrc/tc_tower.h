@@ -192,12 +192,12 @@ struct Fq6 {
   TC_HD_NOINLINE Fq6 inv() const {
     // (operands carry-normalised: the caller may hand in a difference of products)
     const Fq6 n = this->norm();
-    Fq2 t0 = (n.c0.sqr() - (n.c1 * n.c2).mul_xi()).norm();
-    Fq2 t1 = (n.c2.sqr().mul_xi() - n.c0 * n.c1).norm();
-    Fq2 t2 = (n.c1.sqr() - n.c0 * n.c2).norm();
+    Fq2 t0 = (n.c0.sqr() - (n.c1 * n.c2).mul_xi());
+    Fq2 t1 = (n.c2.sqr().mul_xi() - n.c0 * n.c1);
+    Fq2 t2 = (n.c1.sqr() - n.c0 * n.c2);
     Fq2 d = (n.c0 * t0 + (n.c2 * t1 + n.c1 * t2).mul_xi()).norm();
     Fq2 di = d.inv();
-    return Fq6{t0 * di, t1 * di, t2 * di}.norm();
+    return Fq6{t0 * di, t1 * di, t2 * di};
   }
 };
 
@@ -230,7 +230,7 @@ struct Fq12 {
   TC_HD Fq12 reduce_value() const { return Fq12{c0.reduce_value(), c1.reduce_value()}; }
   TC_HD_NOINLINE Fq12 inv() const {
     Fq6 t = (c0.sqr() - c1.sqr().mul_by_v()).inv();
-    return Fq12{c0 * t, -(c1 * t)}.norm();
+    return Fq12{c0 * t, -(c1 * t)};
   }
   // sparse multiplication by (d0 + d1 v) + (d4 v) w -- the Miller-loop line shape
   TC_FQ12_ATTR Fq12 mul_by_014(const Fq2& d0, const Fq2& d1, const Fq2& d4) const {
@@ -253,8 +253,8 @@ struct Fq12 {
     Fq2 u = (d0 + d4) * (e0 + e4) - t0 - t3;
     Fq2 w = (d1 + d4) * (e1 + e4) - t1 - t3;
     Fq12 r;
-    r.c0 = Fq6{(t0 + t3.mul_xi()).norm(), t2.norm(), t1};
-    r.c1 = Fq6{Fq2::zero(), u.norm(), w.norm()};
+    r.c0 = Fq6{(t0 + t3.mul_xi()).norm(), t2, t1};
+    r.c1 = Fq6{Fq2::zero(), u, w.norm()};
     return r;
   }
   // times an element whose c1 is (0, *, *) (a line product): 6 + 5 + 6 Fq2 products
@@ -276,7 +276,7 @@ struct Fq12 {
     r.c1.c0 = (cj ? c1.c0.conj() : c1.c0) * frob_coeff(k, 1);
     r.c1.c1 = (cj ? c1.c1.conj() : c1.c1) * frob_coeff(k, 3);
     r.c1.c2 = (cj ? c1.c2.conj() : c1.c2) * frob_coeff(k, 5);
-    return r.norm();
+    return r;
   }
   // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part
   // of the final exponentiation): 9 Fq2 squarings' worth instead of 2 Fq6 mul.
