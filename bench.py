@@ -30,7 +30,7 @@ W_FQMUL = {"combine_g2_t3": 31148, "g2_mul": 7771, "verify_g2": 41226, "hash_g2"
 MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient digits (CIOS)
 # what the kernels actually execute per unit, in v_mad (one 14x14 limb product or one Montgomery
 # reduction = 196): counted by running the same per-lane job bodies in the host build
-# (tools/count_ops.py, tests/hostsim -DTC_COUNT_OPS).  Two lanes work on a G2 job; work inside Fq2
+# (tests/count_ops.py, tests/hostsim -DTC_COUNT_OPS).  Two lanes work on a G2 job; work inside Fq2
 # operations is split between them, Fq work outside (inversions, root exponentiations) is done
 # by both and counted twice.
 EXECUTED_MACS = {"combine_g2_t3_fast": 1403192, "combine_g2_t3_general": 4429418, "g2_mul": 1316938,

@@ -1,6 +1,6 @@
 """Randomised differential soak test on the GPU: random batch shapes, signer subsets, message lengths,
 valid / invalid / identity operands -- EVERY job compared with the C oracle (oracle/c, test
-infrastructure).  Usage on an MI355X:  python tools/soak.py [seconds] [seed]
+infrastructure).  Usage on an MI355X:  python tests/soak.py [seconds] [seed]
 Exits non-zero on the first mismatch and prints the reproducer (seed, round, entry point, job)."""
 import os
 import random

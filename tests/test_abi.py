@@ -56,3 +56,9 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "tc_oracle" not in src and "c_oracle" not in src and "hostsim" not in src.replace(
                     "tests/hostsim", ""), f
+    # developer tools stay oracle-free too (the fixture generator is the one sanctioned exception);
+    # everything that checks against the oracle lives under tests/
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py") and f != "gen_golden.py":
+            src = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "tc_oracle" not in src and "c_oracle" not in src and "\"oracle\"" not in src, f

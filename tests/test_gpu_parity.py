@@ -512,11 +512,11 @@ def test_lincomb_with_infinity_points_zero_scalars_and_ragged_chunks(engine, rnd
 
 
 def test_randomised_soak_short():
-    """tools/soak.py for a few seconds: random shapes, index patterns, message lengths and
-    operand validity, every job against the C oracle (the long run is `python tools/soak.py 600`)."""
+    """tests/soak.py for a few seconds: random shapes, index patterns, message lengths and
+    operand validity, every job against the C oracle (the long run is `python tests/soak.py 600`)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "10", "7"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "soak.py"), "10", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SOAK-OK" in r.stdout, (r.stdout[-500:], r.stderr[-500:])

@@ -248,7 +248,7 @@ constexpr float FQ_MAX_BOUND_PRODUCT = 8.14f;  // B_a * B_b allowed at a multipl
 // column of DESIGN.md and bench.py's executed-MAC roofline.  In the lane-pair build an Fq
 // operation INSIDE an Fq2 method is one lane's half of that method (counted once: "split"); an
 // Fq operation outside (inversions, square-root exponentiations, G1 work in a G2 kernel) is
-// executed by both lanes ("local", counted twice for a G2 kernel by tools/count_ops.py).
+// executed by both lanes ("local", counted twice for a G2 kernel by tests/count_ops.py).
 inline uint64_t g_tc_mul_count = 0, g_tc_sqr_count = 0, g_tc_mul2_count = 0;
 inline uint64_t g_tc_split_mul_count = 0, g_tc_split_sqr_count = 0;
 inline int g_tc_split_depth = 0;
