@@ -107,7 +107,10 @@ def test_inverse_by_binary_gcd(L, rnd):
     # Fq::inv (binary extended GCD + two Montgomery products for the power of two) against Fermat
     # and Python; edge values exercise long runs of trailing zeros and both ends of the k range
     vals = [0, 1, 2, 3, 4, o.Q - 1, o.Q - 2, (o.Q - 1) // 2, (o.Q + 1) // 2, 1 << 380, 1 << 64, (1 << 64) + 1, 1 << 128, (1 << 320) - 1,
-            pow(2, -1, o.Q), pow(1 << 200, -1, o.Q), 3 << 370] + [rnd.randrange(o.Q) for _ in range(500)] + [rnd.randrange(1 << 70) for _ in range(50)]
+            pow(2, -1, o.Q), pow(1 << 200, -1, o.Q), 3 << 370] + [rnd.randrange(o.Q) for _ in range(1500)] + [rnd.randrange(1 << 70) for _ in range(50)]
+    # values that keep a and b close to each other (the approximated comparison decides wrongly more often)
+    vals += [(o.Q >> k) + d for k in (1, 2, 3, 33, 64, 65, 190) for d in (-1, 0, 1)] + [o.Q - (1 << k) for k in range(1, 381, 19)]
+    vals += [(o.Q * 618033988749894848) // (1 << 60) % o.Q, pow(3, 200, o.Q), (1 << 381) % o.Q]
     for a in vals:
         g, f = buf(48), buf(48)
         assert L.hs_fq_inv_both(be(a), g, f) == 0

@@ -643,101 +643,150 @@ TC_HD_NOINLINE Fq fq_inv_fermat(const Fq& a) {
 
 TC_HD void words12_to_limbs(const uint32_t* w, int32_t* l);
 
-// Inverse by the binary extended GCD with Kaliski's bookkeeping ("almost Montgomery inverse"),
-// on the canonical integer a as 6 x u64:
-//     invariants   a r = -u 2^k,   a s = v 2^k  (mod p),   u s + v r = p   (so r, s <= p)
-//     u > v (both odd):  u = (u - v) >> j,  r = r + s,  s <<= j      (j = trailing zeros, k += j)
-//     v > u           :  v = (v - u) >> j,  s = s + r,  r <<= j
-//     u = v = 1       :  s = a^-1 2^k
-// ~380 subtract-and-shift rounds of ~280 VALU instructions against 381 + 110 field
-// multiplications: 2.3x cheaper, and every job ends with one inversion (both lanes of a pair).
-// Wave-uniform loop (tc_common.h wave_any), branch-free body.  0 -> 0.
-TC_HD_NOINLINE Fq Fq::inv() const {
-  uint32_t w[12];
-  this->to_canonical(w);
-  uint64_t u[6], v[6], r[6], s[6];
-  uint64_t any = 0;
-  TC_UNROLL for (int i = 0; i < 6; i++) {
-    u[i] = (uint64_t)FQ_P[2 * i] | ((uint64_t)FQ_P[2 * i + 1] << 32);
-    v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
-    r[i] = 0;
-    s[i] = (i == 0) ? 1 : 0;
-    any |= v[i];
+// y^-1 mod p on canonical 12 x u32 words (0 -> 0): Pornin's optimised binary GCD (eprint
+// 2020/972).  Plain binary GCD keeps  a = y u,  b = y v  (mod p)  while halving a / replacing it by
+// (a - b) / 2; after at most 2 * 381 - 1 steps a = 0, b = 1 and v = 1 / y.  Here 30 steps at a time
+// run on 64-bit APPROXIMATIONS of a and b (their exact low 31 bits and the top 33 bits of the
+// longer one) and only produce four small factors with |f0| + |g0|, |f1| + |g1| <= 2^30; the
+// long numbers are then updated in one go,
+//     (a, b) <- ((a f0 + b g0) / 2^30, (a f1 + b g1) / 2^30)       exact; a wrong comparison in
+//                                                                  the approximation shows up as
+//                                                                  a negative value and is undone
+//     (u, v) <- the same combination, divided by 2^30 modulo p     (one Montgomery-style step)
+// 26 rounds of 30 steps, no data-dependent control flow at all: ~4x fewer instructions than the
+// bit-by-bit GCD it replaced (which in turn beat the Fermat power 2.3x), and every job ends with
+// one inversion for its affine output.
+TC_HD void fq_inv_linear_update(const uint32_t* a, const uint32_t* b, int32_t f, int32_t g, uint32_t* w13) {
+  // w13 = a f + b g as 13 two's-complement words
+  int64_t acc = 0;
+  TC_UNROLL for (int i = 0; i < 12; i++) {
+    acc += (int64_t)(uint64_t)a[i] * f + (int64_t)(uint64_t)b[i] * g;
+    w13[i] = (uint32_t)acc;
+    acc >>= 32;
   }
-  const bool nonzero = any != 0;
-  uint32_t k = 0;
-  bool busy = nonzero;
-  TC_NOUNROLL while (wave_any(busy)) {
-    if (!busy) continue;
-    const bool ue = (u[0] & 1ull) == 0, ve = (v[0] & 1ull) == 0;
-    const bool odd2 = !ue && !ve;
-    uint64_t d1[6], d2[6], rs[6];  // u - v, v - u, r + s
-    uint64_t b1 = 0, b2 = 0, c = 0, nz = 0;
-    TC_UNROLL for (int i = 0; i < 6; i++) {
-      const uint64_t t1 = u[i] - v[i];
-      const uint64_t n1 = (uint64_t)(u[i] < v[i]) | (uint64_t)(t1 < b1);
-      d1[i] = t1 - b1;
-      b1 = n1;
-      const uint64_t t2 = v[i] - u[i];
-      const uint64_t n2 = (uint64_t)(v[i] < u[i]) | (uint64_t)(t2 < b2);
-      d2[i] = t2 - b2;
-      b2 = n2;
-      const uint64_t t3 = r[i] + s[i];
-      const uint64_t n3 = (uint64_t)(t3 < r[i]);
-      rs[i] = t3 + c;
-      c = n3 | (uint64_t)(rs[i] < t3);
-      nz |= d1[i];
+  w13[12] = (uint32_t)acc;
+}
+
+TC_HD void fq_inv_words(const uint32_t* y, uint32_t* out) {
+  uint32_t a[12], b[12], u[12], v[12];
+  TC_UNROLL for (int i = 0; i < 12; i++) {
+    a[i] = y[i];
+    b[i] = FQ_P[i];
+    u[i] = (i == 0) ? 1u : 0u;
+    v[i] = 0;
+  }
+  TC_NOUNROLL for (int round = 0; round < 26; round++) {
+    // ---- approximations ----------------------------------------------------------------------
+    uint32_t hw = 0;
+    int top = 0;
+    TC_UNROLL for (int i = 0; i < 12; i++) {
+      const uint32_t w = a[i] | b[i];
+      top = w ? i : top;
+      hw = w ? w : hw;
     }
-    const bool finished = odd2 && nz == 0;       // u == v (== 1)
-    const bool upd_u = ue || (odd2 && b1 == 0);  // otherwise v is the one that changes
-    // the value that gets its trailing zeros stripped, and the coefficient that is shifted left
-    uint64_t x[6], y[6];
-    TC_UNROLL for (int i = 0; i < 6; i++) {
-      x[i] = upd_u ? (ue ? u[i] : d1[i]) : (ve ? v[i] : d2[i]);
-      y[i] = upd_u ? s[i] : r[i];
+    const int n = hw ? 32 * top + 32 - __builtin_clz(hw) : 0;  // bit length of max(a, b)
+    const uint64_t alo = (uint64_t)a[0] | ((uint64_t)a[1] << 32), blo = (uint64_t)b[0] | ((uint64_t)b[1] << 32);
+    const int s = n > 64 ? n - 33 : 0;
+    const int sw = s >> 5, off = s & 31;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+    TC_UNROLL for (int i = 0; i < 12; i++) {
+      a0 = (i == sw) ? a[i] : a0;
+      b0 = (i == sw) ? b[i] : b0;
+      a1 = (i == sw + 1) ? a[i] : a1;
+      b1 = (i == sw + 1) ? b[i] : b1;
+      a2 = (i == sw + 2) ? a[i] : a2;
+      b2 = (i == sw + 2) ? b[i] : b2;
     }
-    const int j = x[0] ? __builtin_ctzll(x[0]) : 63;  // >= 1; a longer run of zeros takes another round
-    TC_UNROLL for (int i = 0; i < 5; i++) x[i] = (x[i] >> j) | (x[i + 1] << (64 - j));
-    x[5] >>= j;
-    TC_UNROLL for (int i = 5; i > 0; i--) y[i] = (y[i] << j) | (y[i - 1] >> (64 - j));
-    y[0] <<= j;
-    if (!finished) {
-      TC_UNROLL for (int i = 0; i < 6; i++) {
-        const uint64_t ri = r[i], si = s[i];
-        u[i] = upd_u ? x[i] : u[i];
-        v[i] = upd_u ? v[i] : x[i];
-        r[i] = upd_u ? (odd2 ? rs[i] : ri) : y[i];
-        s[i] = upd_u ? y[i] : (odd2 ? rs[i] : si);
+    const uint64_t m33 = (1ull << 33) - 1;
+    const uint64_t ahi = ((((uint64_t)a0 >> off) | ((uint64_t)a1 << (32 - off))) | (off ? ((uint64_t)a2 << (64 - off)) : 0)) & m33;
+    const uint64_t bhi = ((((uint64_t)b0 >> off) | ((uint64_t)b1 << (32 - off))) | (off ? ((uint64_t)b2 << (64 - off)) : 0)) & m33;
+    uint64_t abar = n > 64 ? ((alo & 0x7fffffffull) | (ahi << 31)) : alo;
+    uint64_t bbar = n > 64 ? ((blo & 0x7fffffffull) | (bhi << 31)) : blo;
+    // ---- 30 steps on the approximations ------------------------------------------------------
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+    TC_UNROLL for (int i = 0; i < 30; i++) {
+      const bool odd = (abar & 1ull) != 0;
+      const bool swp = odd && (abar < bbar);
+      const uint64_t ta = swp ? bbar : abar, tb = swp ? abar : bbar;
+      const int32_t nf0 = swp ? f1 : f0, ng0 = swp ? g1 : g0, nf1 = swp ? f0 : f1, ng1 = swp ? g0 : g1;
+      abar = (ta - (odd ? tb : 0)) >> 1;
+      bbar = tb;
+      f0 = nf0 - (odd ? nf1 : 0);
+      g0 = ng0 - (odd ? ng1 : 0);
+      f1 = nf1 << 1;
+      g1 = ng1 << 1;
+    }
+    // ---- (a, b) <- exact combinations / 2^30, made non-negative -------------------------------
+    uint32_t wa[13], wb[13];
+    fq_inv_linear_update(a, b, f0, g0, wa);
+    fq_inv_linear_update(a, b, f1, g1, wb);
+    const bool na = (wa[12] >> 31) != 0, nb = (wb[12] >> 31) != 0;
+    {
+      uint32_t ca = na ? 1u : 0u, cb = nb ? 1u : 0u;
+      const uint32_t xa = na ? 0xffffffffu : 0u, xb = nb ? 0xffffffffu : 0u;
+      TC_UNROLL for (int i = 0; i < 13; i++) {  // conditional two's-complement negation
+        const uint64_t t1 = (uint64_t)(wa[i] ^ xa) + ca;
+        wa[i] = (uint32_t)t1;
+        ca = (uint32_t)(t1 >> 32);
+        const uint64_t t2 = (uint64_t)(wb[i] ^ xb) + cb;
+        wb[i] = (uint32_t)t2;
+        cb = (uint32_t)(t2 >> 32);
       }
-      k += (uint32_t)j;
     }
-    busy = !finished;
+    TC_UNROLL for (int i = 0; i < 12; i++) {
+      a[i] = (wa[i] >> 30) | (wa[i + 1] << 2);
+      b[i] = (wb[i] >> 30) | (wb[i + 1] << 2);
+    }
+    if (na) {
+      f0 = -f0;
+      g0 = -g0;
+    }
+    if (nb) {
+      f1 = -f1;
+      g1 = -g1;
+    }
+    // ---- (u, v) <- the same combinations / 2^30 mod p -----------------------------------------
+    uint32_t wu[13], wv[13];
+    fq_inv_linear_update(u, v, f0, g0, wu);
+    fq_inv_linear_update(u, v, f1, g1, wv);
+    TC_UNROLL for (int which = 0; which < 2; which++) {
+      uint32_t* w = which ? wv : wu;
+      // add t p with t = -w p^-1 mod 2^30: the low 30 bits vanish
+      const uint32_t t = (w[0] * FQ_INV32) & 0x3fffffffu;
+      uint64_t c = 0;
+      TC_UNROLL for (int i = 0; i < 12; i++) {
+        c += (uint64_t)FQ_P[i] * t + w[i];
+        w[i] = (uint32_t)c;
+        c >>= 32;
+      }
+      w[12] += (uint32_t)c;  // two's-complement top word: value now in (-p 2^30, 2 p 2^30)
+      uint32_t r[12];
+      TC_UNROLL for (int i = 0; i < 12; i++) r[i] = (w[i] >> 30) | (w[i + 1] << 2);
+      const bool neg = (w[12] >> 31) != 0;  // value in (-p, 2p): bring it into [0, p)
+      // r + p (if negative) or r - p (if that does not borrow)
+      uint32_t rp[12], rm[12];
+      uint64_t cc = 0, bb = 0;
+      TC_UNROLL for (int i = 0; i < 12; i++) {
+        cc += (uint64_t)r[i] + FQ_P[i];
+        rp[i] = (uint32_t)cc;
+        cc >>= 32;
+        const uint64_t d = (uint64_t)r[i] - FQ_P[i] - bb;
+        rm[i] = (uint32_t)d;
+        bb = (d >> 63) & 1;
+      }
+      const bool ge = !neg && bb == 0;
+      uint32_t* dst = which ? v : u;
+      TC_UNROLL for (int i = 0; i < 12; i++) dst[i] = neg ? rp[i] : (ge ? rm[i] : r[i]);
+    }
   }
-  // s = a^-1 2^k, s <= p.  Plain limbs of s, then the two products.
-  uint32_t sw[12];
-  TC_UNROLL for (int i = 0; i < 6; i++) {
-    sw[2 * i] = (uint32_t)s[i];
-    sw[2 * i + 1] = (uint32_t)(s[i] >> 32);
-  }
-  Fq sp, pw;
-  words12_to_limbs(sw, sp.l);
-  sp.set_range(0.f, 1.f);
-  sp.set_val(1.f);
-  // three Montgomery products take out 2^k and put in R:  s 2^e1 2^e2 C / R^3 = s R 2^-k  with
-  // C = R^4 2^-770 and e1 + e2 = 770 - k  (0 <= k <= 762), each a single-bit limb vector below R
-  const uint32_t e = 770u - k;
-  const uint32_t e1 = e > 388u ? 388u : e, e2 = e - e1;  // 2^388 < 160 p: inside the multiplier's value bound
-  Fq pw2;
-  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
-    pw.l[i] = ((uint32_t)i == e1 / (uint32_t)FQ_RADIX) ? (int32_t)(1u << (e1 % (uint32_t)FQ_RADIX)) : 0;
-    pw2.l[i] = ((uint32_t)i == e2 / (uint32_t)FQ_RADIX) ? (int32_t)(1u << (e2 % (uint32_t)FQ_RADIX)) : 0;
-  }
-  pw.set_range(0.f, 0.5f);
-  pw.set_val(160.f);
-  pw2.set_range(0.f, 0.5f);
-  pw2.set_val(160.f);
-  const Fq out = fq_mul(fq_mul(fq_mul(sp, pw), pw2), Fq::from_limbs(FQL_POW2_INVFIX));
-  return Fq::select(nonzero, out, Fq::zero());
+  TC_UNROLL for (int i = 0; i < 12; i++) out[i] = v[i];
+}
+
+TC_HD_NOINLINE Fq Fq::inv() const {
+  uint32_t w[12], r[12];
+  this->to_canonical(w);
+  fq_inv_words(w, r);
+  return Fq::from_canonical(r);
 }
 
 // 12 canonical u32 words (an integer < 2^384) -> plain limbs
