@@ -93,7 +93,8 @@ struct Fq2 {
   TC_HD Fq2 norm() const { return Fq2{c0.norm(), c1.norm()}; }
   TC_HD Fq2 reduce_value() const { return Fq2{c0.reduce_value(), c1.reduce_value()}; }
 #if defined(__HIP_DEVICE_COMPILE__)
-  // one-lane-per-job device build (-DTC_NO_PAIR, kept for A/B measurements): Karatsuba, 3 Fq mul
+  // one-lane-per-job device build (-DTC_NO_PAIR): Karatsuba, 3 Fq mul.  TIMING EXPERIMENTS ONLY -- its
+  // outputs have wider limb intervals than the coefficient formulas the 28-bit bound analysis covers
   TC_HD Fq2 operator*(const Fq2& b) const {
     Fq aa = c0 * b.c0;
     Fq bb = c1 * b.c1;
