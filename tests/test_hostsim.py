@@ -414,3 +414,17 @@ def test_encrypt_and_commitment_evaluate(L, rnd):
             out = buf(96)
             assert L.hs_commitment_evaluate(blob, t, ctypes.c_uint64(i), out) == 0
             assert out.raw == o.g1_uncompressed(o.public_key_share(commit, i)), (t, i)
+
+
+def test_whole_suite_under_the_bound_analysis():
+    """Every test of this file again, with the device source built -DTC_BOUND_CHECK: each job body,
+    edge case and error path is walked with limb intervals and value bounds carried through every
+    operation (an overflow-prone multiplication or lazy sum aborts the run).  With 28-bit limbs the
+    budget is tight, so the proof is re-established on every run of the CPU suite."""
+    if os.environ.get("TC_HOSTSIM_BOUND_CHECK"):
+        pytest.skip("already inside the bound-checked run")
+    env = dict(os.environ, TC_HOSTSIM_BOUND_CHECK="1")
+    r = subprocess.run([os.sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not under_the_bound_analysis and not bound_check_build"],
+                       capture_output=True, text=True, timeout=1800, env=env, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
