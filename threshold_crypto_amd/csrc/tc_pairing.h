@@ -16,56 +16,56 @@ struct LineCoeffs {
   Fq2 c0, c1, c2;
 };
 
-// Algorithm 26 of eprint 2010/354 (Jacobian doubling + tangent line), a = 0.  Small multiples are
-// applied after the products and sums are carry-normalised where the bound analysis asks (tc_curve.h).
+// The Miller-loop point T runs in HOMOGENEOUS projective coordinates (X : Y : Z), stored with the
+// third coordinate doubled (zt = 2 Z) so that the twist constant b' = 4 (1 + u) turns into small
+// multiples:  9 b' Z^2 = 9 xi zt^2,  27 b'^2 Z^4 = 3 (3 xi zt^2)^2.
+//   doubling (3M + 6S; Costello-Lange-Naehrig / Aranha et al. 2011, a = 0):
+//     X3 = 2 XY (Y^2 - 9 b' Z^2),  Y3 = (Y^2 + 9 b' Z^2)^2 - 108 b'^2 Z^4,  Z3 = 8 Y^3 Z
+//     tangent at T, evaluated at P = (xP, yP), up to a factor of Fq2 (which the final
+//     exponentiation removes):   2 Y Z yP w^3  -  3 X^2 xP w^2  +  (Y^2 - 3 b' Z^2)
+//   mixed addition of the affine Q (11M + 2S):  theta = Y - y2 Z, lambda = X - x2 Z, ... and the
+//     chord  lambda yP w^3 - theta xP w^2 + (theta x2 - lambda y2)
+// (the pairing crate's Jacobian steps, Algorithms 26/27 of eprint 2010/354, cost 3M + 8S and
+// 7M + 8S; only the boolean of the product check is observable, so any correct line will do.)
+// Small multiples are applied after the products and sums are carry-normalised where the bound
+// analysis asks (tc_curve.h).
 TC_MILLER_ATTR LineCoeffs miller_doubling_step(G2Jac& r) {
-  Fq2 tmp0 = r.x.sqr();
-  Fq2 tmp1 = r.y.sqr();
-  Fq2 tmp2 = tmp1.sqr();
-  Fq2 t3h = ((tmp1 + r.x).sqr() - tmp0 - tmp2).norm();  // tmp3 = 2 t3h
-  Fq2 tmp4 = (tmp0.dbl() + tmp0).norm();
-  Fq2 tmp6 = r.x + tmp4;
-  Fq2 tmp5 = tmp4.sqr();
-  Fq2 zsq = r.z.sqr();
-  Fq2 nx = (tmp5 - t3h.dbl().dbl()).reduce_value();
-  Fq2 nz = ((r.z + r.y).sqr() - tmp1 - zsq).norm();
-  Fq2 ny = ((t3h.dbl() - nx) * tmp4 - tmp2.dbl().dbl().norm().dbl()).norm();
+  const Fq2 B = r.y.sqr();
+  const Fq2 C = r.z.sqr();
+  const Fq2 xc = C.mul_xi();
+  const Fq2 E = (xc.dbl() + xc).norm();  // 3 b' Z^2 = 3 xi zt^2
+  const Fq2 F = (E.dbl() + E).norm();    // 9 b' Z^2
+  const Fq2 XY = r.x * r.y;
+  const Fq2 H = (r.y + r.z).sqr() - B - C;  // 2 Y zt
+  const Fq2 J = r.x.sqr();
   LineCoeffs l;
-  l.c1 = (-((tmp4 * zsq).dbl()));
-  l.c2 = (tmp6.sqr() - tmp0 - tmp5 - tmp1.dbl().dbl()).norm();
-  l.c0 = (nz * zsq).dbl();
-  r.x = nx;
-  r.y = ny;
-  r.z = nz;
+  l.c0 = H;
+  l.c1 = -(J.dbl() + J).dbl();
+  l.c2 = (B - E).dbl().norm();
+  r.x = (XY * (B - F)).dbl().reduce_value();
+  const Fq2 e4 = E.sqr().dbl().dbl().norm();  // 4 E^2
+  r.y = ((B + F).sqr() - (e4.dbl() + e4)).norm();
+  r.z = (B * H).dbl().dbl().norm();
   return l;
 }
 
-// Algorithm 27 of eprint 2010/354 (mixed addition + chord line).
 TC_MILLER_ATTR LineCoeffs miller_addition_step(G2Jac& r, const G2Affine& q) {
-  Fq2 zsq = r.z.sqr();
-  Fq2 ysq = q.y.sqr();
-  Fq2 t0 = zsq * q.x;
-  Fq2 t1 = ((q.y + r.z).sqr() - ysq - zsq) * zsq;
-  Fq2 t2 = t0 - r.x;
-  Fq2 t3 = t2.sqr();
-  Fq2 t5q = t3 * t2;   // t5 = 4 t5q
-  Fq2 t6 = (t1 - r.y.dbl()).norm();
-  Fq2 t9 = t6 * q.x;
-  Fq2 t7q = t3 * r.x;  // t7 = 4 t7q
-  Fq2 nx = (t6.sqr() - (t5q + t7q.dbl()).norm().dbl().dbl()).norm();
-  Fq2 nz = ((r.z + t2).norm().sqr() - zsq - t3).norm();
-  Fq2 t10 = q.y + nz;
-  Fq2 t8 = (t7q.dbl().dbl() - nx) * t6;
-  Fq2 ny = (t8 - (r.y * t5q).dbl().dbl().norm().dbl()).norm();
-  t10 = t10.sqr() - ysq - nz.sqr();
-  t9 = (t9.dbl() - t10).norm();
+  const Fq2 X2 = r.x.dbl(), Y2 = r.y.dbl();
+  const Fq2 theta = (Y2 - q.y * r.z).norm();
+  const Fq2 lambda = (X2 - q.x * r.z).norm();
+  const Fq2 C = theta.sqr();
+  const Fq2 D = lambda.sqr();
+  const Fq2 E = lambda * D;
+  const Fq2 F = r.z * C;
+  const Fq2 G = X2 * D;
+  const Fq2 Hh = E + F - G.dbl();
   LineCoeffs l;
-  l.c0 = nz.dbl();
-  l.c1 = (-t6).dbl();
-  l.c2 = t9;
-  r.x = nx;
-  r.y = ny;
-  r.z = nz;
+  l.c0 = lambda;
+  l.c1 = -theta;
+  l.c2 = (theta * q.x - lambda * q.y).norm();
+  r.x = (lambda * Hh).norm();
+  r.y = (theta * (G - Hh) - E * Y2).norm();
+  r.z = (r.z * E).dbl().norm();
   return l;
 }
 
@@ -98,7 +98,7 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
   bool skip[NP];
   TC_UNROLL for (int k = 0; k < NP; k++) {
     skip[k] = ps[k].inf || qs[k].inf;
-    r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one()};
+    r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
   }
   // nothing to accumulate (every pair has an identity operand): the product of pairings is 1.
   // (Also keeps the bare squarings of the loop below, whose outputs are only carry-normalised,
