@@ -34,7 +34,7 @@ MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient d
 # operations is split between them, Fq work outside (inversions, root exponentiations) is done
 # by both and counted twice.
 EXECUTED_MACS = {"combine_g2_t3_fast": 1403192, "combine_g2_t3_general": 4429418, "g2_mul": 1316938,
-                 "verify_g2": 7353402, "hash_g2": 3080441, "combine_g1_t3_fast": 658735}
+                 "verify_g2": 7154266, "hash_g2": 3080441, "combine_g1_t3_fast": 658735}
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
 # profiles/r01_e_radix28_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
