@@ -86,6 +86,28 @@ TC_JAC_ATTR Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
   return r;
 }
 
+// mmadd-2007-bl: two AFFINE points (z1 = z2 = 1), 4M + 2S; same rescaling as jac_add_mixed
+// (h = x2 - x1, r = y2 - y1, z3 = 2 h).  Table builders start with these.
+template <class F>
+TC_JAC_ATTR Jac<F> jac_add_affine(const Affine<F>& p, const Affine<F>& q) {
+  if (q.inf) return Jac<F>::from_affine(p);
+  if (p.inf) return Jac<F>::from_affine(q);
+  F h = q.x - p.x;
+  F rr = q.y - p.y;
+  if (h.is_zero()) {
+    if (rr.is_zero()) return jac_dbl(Jac<F>::from_affine(p));
+    return Jac<F>::infinity();
+  }
+  F hh = h.sqr();
+  F j = h * hh;
+  F v = p.x * hh;
+  Jac<F> r;
+  r.x = coord_norm((rr.sqr() - j - v.dbl()).norm().dbl().dbl());
+  r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (p.y * j).dbl().dbl()).norm().dbl());
+  r.z = coord_norm(h.dbl());
+  return r;
+}
+
 // add-2007-bl with the exceptional cases handled (same rescaling as above: r is half the
 // formulas' r, i = hh is a quarter of theirs).
 template <class F>

@@ -7,8 +7,8 @@
 //   on G2:  psi(P) = [q mod r] P = [x] P = -[|x|] P        (x = -0xd201000000010000)
 //   so for k = d0 + d1|x| + d2|x|^2 + d3|x|^3 (base-|x| digits, each < 2^64):
 //       [k] P = d0 P - d1 psi(P) + d2 psi^2(P) - d3 psi^3(P)
-//   and one joint double-and-add over 64 bits with a 15-entry subset-sum table replaces the
-//   255-bit ladder.
+//   and one joint double-and-add over 64 bits with an 8-entry table (sign-aligned digits,
+//   sac_recode4) replaces the 255-bit ladder.
 //   on all of E'(Fq2):  psi^2 - t psi + q = 0, which gives (Budroni-Pintore)
 //       [x^2-x-1] P + [x-1] psi(P) + psi^2(2P) = [3(x^2-1) h2] P,
 //   and because [h2]P lies in the order-r subgroup, [h2] P = [c] of that with
@@ -56,43 +56,72 @@ TC_HD void gls_decompose(const uint32_t* k, uint64_t* d) {
   d[3] = n[0];  // k < r < |x|^4  =>  the last quotient fits one word
 }
 
-// sum_i d_i * B_i for four AFFINE base points and 64-bit scalars: joint double-and-add over a
-// 15-entry subset-sum table.  The 11 proper sums are brought to one common Z (no inversion:
-// jac_batch_to_common_z) and the four bases scaled to it, so every addition of the 64-step ladder
-// is a mixed one on the isomorphic curve (7M + 4S instead of 11M + 5S in Fq2): about a fifth
-// fewer multiply-adds for the whole multiplication, and a table of two coordinates per entry.
+// Sign-aligned recoding of four 64-bit scalars (GLV-SAC, Faz-Hernandez, Longa, Sanchez 2013):
+//   d0 (odd)  = sum_{i <= 64} s_i 2^i            s_64 = +1,  s_i = 2 bit_{i+1}(d0) - 1  for i < 64
+//   d_j       = sum_{i <= 64} s_i u_j[i] 2^i     u_j[i] in {0, 1}      (j = 1, 2, 3)
+// so that column i of the joint ladder adds  s_i (B0 + u_1[i] B1 + u_2[i] B2 + u_3[i] B3):  a table
+// of 8 sums that all contain B0 (7 additions to build) instead of the 15 subset sums (11), and no
+// zero columns.  An even d0 is replaced by d0 + 1; the caller subtracts B0 at the end (fix).
+struct SacDigits {
+  uint64_t neg;   // bit i: s_i = -1 (i < 64)
+  uint64_t u[3];  // bit i of u[j-1]: u_j[i] (i < 64)
+  uint32_t top;   // bit j-1: u_j[64]
+  bool fix;
+};
+TC_HD SacDigits sac_recode4(const uint64_t* d) {
+  SacDigits r;
+  r.fix = (d[0] & 1ull) == 0;
+  r.neg = ~((d[0] | 1ull) >> 1);
+  r.top = 0;
+  TC_NOUNROLL for (int j = 0; j < 3; j++) {
+    uint64_t k = d[j + 1], u = 0;
+    TC_NOUNROLL for (int i = 0; i < 64; i++) {
+      const uint64_t odd = k & 1ull;
+      u |= odd << i;
+      k = (k >> 1) + (odd & (r.neg >> i));  // (k - s_i) / 2
+    }
+    r.u[j] = u;
+    r.top |= (uint32_t)k << j;  // k - 1 <= (d_j - 1) / 2^64 < 1: k is 0 or 1
+  }
+  return r;
+}
+
+// sum_i d_i * B_i for four AFFINE base points and 64-bit scalars: joint double-and-add over the
+// 8-entry table B0 + (subset sums of B1, B2, B3) with sign-aligned digits (above).  The 7 proper
+// sums are brought to one common Z (no inversion: jac_batch_to_common_z) and B0 scaled to it, so
+// every addition of the 64-step ladder is a mixed one on the isomorphic curve (7M + 4S instead of
+// 11M + 5S in Fq2), and a table entry is two coordinates.
 TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Affine* base, const uint64_t* d) {
-  G2Affine tbl[16];
+  const SacDigits sd = sac_recode4(d);
+  G2Affine tbl[8];
   Fq2 zc;
   {
-    G2Jac sums[11];
-    G2Affine sums_aff[11];
-    int slot[16];
-    int ns = 0;
-    TC_NOUNROLL for (int m = 1; m < 16; m++) {
+    G2Jac sums[7];
+    G2Affine sums_aff[7];
+    TC_NOUNROLL for (int m = 1; m < 8; m++) {
       const int low = __builtin_ctz((unsigned)m);
       const int rest = m & (m - 1);
-      if (!rest) {
-        slot[m] = -1;
-      } else {
-        const int rs = slot[rest];
-        const G2Jac prev = (rs < 0) ? G2Jac::from_affine(base[__builtin_ctz((unsigned)rest)]) : sums[rs];
-        sums[ns] = jac_add_mixed(prev, base[low]);
-        slot[m] = ns++;
-      }
+      sums[m - 1] = rest ? jac_add_mixed(sums[rest - 1], base[low + 1]) : jac_add_affine(base[0], base[low + 1]);
     }
-    zc = jac_batch_to_common_z(sums, sums_aff, 11);
+    zc = jac_batch_to_common_z(sums, sums_aff, 7);
     const Fq2 zc2 = zc.sqr();
     const Fq2 zc3 = zc2 * zc;
-    TC_NOUNROLL for (int m = 1; m < 16; m++)
-      tbl[m] = (slot[m] >= 0) ? sums_aff[slot[m]] : affine_scale_z(base[__builtin_ctz((unsigned)m)], zc2, zc3);
+    tbl[0] = affine_scale_z(base[0], zc2, zc3);
+    TC_NOUNROLL for (int m = 1; m < 8; m++) tbl[m] = sums_aff[m - 1];
   }
-  G2Jac acc = G2Jac::infinity();
+  G2Jac acc = G2Jac::from_affine(tbl[sd.top]);
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
     acc = jac_dbl(acc);
-    const uint32_t m = (uint32_t)((d[0] >> bit) & 1) | ((uint32_t)((d[1] >> bit) & 1) << 1) |
-                       ((uint32_t)((d[2] >> bit) & 1) << 2) | ((uint32_t)((d[3] >> bit) & 1) << 3);
-    if (m) acc = jac_add_mixed(acc, tbl[m]);
+    const uint32_t m = (uint32_t)((sd.u[0] >> bit) & 1) | ((uint32_t)((sd.u[1] >> bit) & 1) << 1) |
+                       ((uint32_t)((sd.u[2] >> bit) & 1) << 2);
+    G2Affine e = tbl[m];
+    e.y = Fq2::select((sd.neg >> bit) & 1, -e.y, e.y);
+    acc = jac_add_mixed(acc, e);
+  }
+  if (wave_any(sd.fix)) {
+    G2Affine e = tbl[0];
+    e.y = -e.y;
+    acc = G2Jac::select(sd.fix, jac_add_mixed(acc, e), acc);
   }
   acc.z = coord_norm(acc.z * zc);
   return acc;
@@ -109,12 +138,28 @@ TC_HD void g2_gls_bases(const G2Affine& p, G2Affine* base) {
 }
 
 // [k] P for P in G2 (the order-r subgroup), k < r given as 8 LE u32 words
+// The ladder wants an odd first digit, and d0 = k mod 2 because |x| is even: an even k is
+// replaced by the odd r - k and the result negated.
+TC_HD bool gls_decompose_odd(const uint32_t* k, uint64_t* d) {
+  const bool flip = (k[0] & 1u) == 0;
+  uint32_t kk[8];
+  uint32_t borrow = 0;
+  TC_UNROLL for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)FR_P[i] - k[i] - borrow;
+    borrow = (uint32_t)(t >> 63);
+    kk[i] = flip ? (uint32_t)t : k[i];
+  }
+  gls_decompose(kk, d);
+  return flip;
+}
 TC_HD G2Jac g2_mul_gls(const G2Affine& p, const uint32_t* k) {
   uint64_t d[4];
-  gls_decompose(k, d);
+  const bool flip = gls_decompose_odd(k, d);
   G2Affine base[4];
   g2_gls_bases(p, base);
-  return g2_joint_mul4(base, d);
+  G2Jac r = g2_joint_mul4(base, d);
+  r.y = Fq2::select(flip, -r.y, r.y);
+  return r;
 }
 // Jacobian input without an inversion: scale (X, Y, Z) by conj(Z) so that the third coordinate
 // becomes the norm N = Z conj(Z), an element of Fq.  psi keeps a real Z, so all four psi-images
@@ -132,8 +177,10 @@ TC_HD G2Jac g2_gls_digits_mul(const G2Jac& p, const uint64_t* d) {
 }
 TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) {
   uint64_t d[4];
-  gls_decompose(k, d);
-  return g2_gls_digits_mul(p, d);
+  const bool flip = gls_decompose_odd(k, d);
+  G2Jac r = g2_gls_digits_mul(p, d);
+  r.y = Fq2::select(flip, -r.y, r.y);
+  return r;
 }
 
 // [|x|] P by the 64-bit ladder (|x| has Hamming weight 6: 63 doublings, 5 additions)
@@ -200,7 +247,7 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   tbl[2].y = (-tbl[2].y);  // -phi(P) = [x^2] P
   // P - phi(P) keeps its Jacobian (X, Y); the other two entries are scaled to its Z (tc_curve.h
   // jac_batch_to_common_z explains the isomorphic-curve argument)
-  const G1Jac sum = jac_add_mixed(G1Jac::from_affine(p), tbl[2]);
+  const G1Jac sum = jac_add_affine(p, tbl[2]);
   const bool sum_inf = sum.is_inf();
   const Fq zc = Fq::select(sum_inf, Fq::one(), sum.z);
   const Fq zc2 = zc.sqr();

@@ -48,8 +48,7 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
         slot[m] = -1;
       } else {
         const int rs = slot[rest];
-        const Jac<F> prev = (rs < 0) ? Jac<F>::from_affine(pts[__builtin_ctz((unsigned)rest)]) : sums[rs];
-        sums[ns] = jac_add_mixed(prev, pts[low]);
+        sums[ns] = (rs < 0) ? jac_add_affine(pts[__builtin_ctz((unsigned)rest)], pts[low]) : jac_add_mixed(sums[rs], pts[low]);
         slot[m] = ns++;
       }
     }
@@ -225,7 +224,10 @@ TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   tbl[0] = Jac<F>::infinity();
   TC_NOUNROLL for (int m = 1; m < (1 << K); m++) {
     const int low = __builtin_ctz((unsigned)m);
-    tbl[m] = jac_add_mixed(tbl[m & (m - 1)], pts[low]);
+    const int rest = m & (m - 1);
+    if (!rest) tbl[m] = Jac<F>::from_affine(pts[low]);
+    else if (!(rest & (rest - 1))) tbl[m] = jac_add_affine(pts[__builtin_ctz((unsigned)rest)], pts[low]);
+    else tbl[m] = jac_add_mixed(tbl[rest], pts[low]);
   }
   uint64_t any = 0;
   TC_UNROLL for (int k = 0; k < K; k++) any |= c[k];
