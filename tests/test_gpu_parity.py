@@ -52,6 +52,20 @@ def test_g2_mul_matches_oracle(engine, rnd):
             assert bytes(out[j, s]) == o.g2_uncompressed(o.E2.mul(pts[j], sks[s])), (j, s)
 
 
+def test_g2_mul_edge_scalars_of_the_sign_aligned_ladder(engine, rnd):
+    """tc_gls.h sac_recode4: even scalars (run as r - k), first digit 1, digits |x| - 1, short digits."""
+    X = o.BLS_X
+    ks = [0, 1, 2, 3, 4, o.R - 1, o.R - 2, o.R - 3, X - 1, X, X + 1, X ** 2, X ** 3, 1 + X ** 3, 2 * X + 2,
+          1 + (X - 1) * X + (X - 1) * X ** 2 + (X - 2) * X ** 3, (X - 1) + (X - 1) * X, (X - 1) * X ** 2,
+          rnd.randrange(o.R) & ~1, rnd.randrange(o.R) | 1]
+    pts = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)), o.G2_GEN]
+    out, st = engine.g2_mul(frs(ks), g2s(pts))
+    assert not st.any()
+    for j, P in enumerate(pts):
+        for s, k in enumerate(ks):
+            assert bytes(out[j, s]) == o.g2_uncompressed(o.E2.mul(P, k)), (j, hex(k))
+
+
 def test_g1_mul_matches_oracle(engine, rnd):
     """decrypt_share_no_verify (src/lib.rs:460-462)."""
     S, B = 2, 65

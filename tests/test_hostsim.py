@@ -289,7 +289,13 @@ def test_fast_combine_for_every_signer_subset_of_ten(L, rnd):
 def test_gls_and_cofactor_probe(L, rnd):
     """GLS scalar multiplication edge scalars; cofactor clearing is covered by test_hash_and_kdf."""
     Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
-    for k in [0, 1, o.BLS_X - 1, o.BLS_X, o.BLS_X + 1, o.BLS_X ** 2, o.BLS_X ** 3, o.R - 1, (1 << 254) + 12345]:
+    X = o.BLS_X
+    # the ladder recodes the base-|x| digits sign-aligned to an ODD first digit (tc_gls.h sac_recode4):
+    # even scalars (handled as r - k), first digit 1 (every column negative), digits |x| - 1
+    # (carries into the 65th column), short digits
+    sac = [2, 3, 4, o.R - 2, o.R - 3, 1 + (X - 1) * X + (X - 1) * X ** 2 + (X - 2) * X ** 3, (X - 1) + (X - 1) * X,
+           (X - 1) * X ** 2, 1 + X ** 3, 2 * X + 2, rnd.randrange(o.R) & ~1, rnd.randrange(o.R) | 1]
+    for k in [0, 1, X - 1, X, X + 1, X ** 2, X ** 3, o.R - 1, (1 << 254) + 12345] + sac:
         out = buf(192)
         assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0
         assert out.raw == o.g2_uncompressed(o.E2.mul(Q2, k)), hex(k)
