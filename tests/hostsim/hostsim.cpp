@@ -142,7 +142,13 @@ int hs_cyclo_check(const uint8_t* a, const uint8_t* b) {
   Fq12 f = miller_loop<1>(ps, qs);
   Fq12 r = f.conj() * f.inv();
   r = r.frobenius(2) * r;
-  return (r.cyclotomic_sqr() == r.sqr()) && (r.sqr() == r * r) ? 1 : 0;
+  // Karabina form: compressed squaring and the shared-inversion decompression, identity included
+  const Fq12 r2 = r.cyclotomic_sqr();
+  const CycloCompressed c[3] = {CycloCompressed::from(r).sqr(), CycloCompressed::from(Fq12::one()), CycloCompressed::from(r2).sqr()};
+  Fq12 back[3];
+  cyclotomic_decompress3(c, back);
+  const bool karabina = back[0] == r2 && back[1] == Fq12::one() && back[2] == r2.cyclotomic_sqr();
+  return karabina && (r2 == r.sqr()) && (r.sqr() == r * r) ? 1 : 0;
 }
 // ---- Fq12-level probes (12 x 48 B big-endian, tower order c0.c0.c0, c0.c0.c1, c0.c1.c0, ...) ----
 static void fq12_read(const uint8_t* in, Fq12& f) {

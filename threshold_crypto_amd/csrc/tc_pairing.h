@@ -125,16 +125,82 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
   return f.conj();  // x < 0
 }
 
-// f^|x| followed by conjugation (x < 0), for f in the cyclotomic subgroup
+// Three compressed cyclotomic elements back to Fq12 with ONE shared inversion (Montgomery's trick).
+//   z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2),   or  2 z4 z5 / z3  when z2 = 0;
+//   z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1.
+// z2 = z3 = 0 only happens for the identity (then z4 = z5 = 0 as well): its denominator is
+// replaced by 1 in the shared product and z1 = 0, z0 = 1 come out of the same formulas.
+TC_HD_NOINLINE void cyclotomic_decompress3(const CycloCompressed* c, Fq12* out) {
+  Fq2 num[3], den[3];
+  bool dz[3];
+  TC_NOUNROLL for (int i = 0; i < 3; i++) {
+    const bool z2_zero = c[i].z2.is_zero();
+    const Fq2 s4 = c[i].z4.sqr();
+    const Fq2 n_a = (c[i].z5.sqr().mul_xi() + (s4.dbl() + s4) - c[i].z3.dbl()).norm();
+    const Fq2 n_b = (c[i].z4 * c[i].z5).dbl();
+    num[i] = Fq2::select(z2_zero, n_b, n_a);
+    const Fq2 d = Fq2::select(z2_zero, c[i].z3, c[i].z2.dbl().dbl().norm());
+    dz[i] = d.is_zero();
+    den[i] = Fq2::select(dz[i], Fq2::one(), d);
+  }
+  const Fq2 p01 = den[0] * den[1];
+  const Fq2 all = (p01 * den[2]).inv();
+  const Fq2 t = all * den[2];
+  Fq2 inv[3];
+  inv[2] = all * p01;
+  inv[1] = t * den[0];
+  inv[0] = t * den[1];
+  TC_NOUNROLL for (int i = 0; i < 3; i++) {
+    const Fq2 z1 = Fq2::select(dz[i], Fq2::zero(), num[i] * inv[i]);
+    const Fq2 m34 = c[i].z3 * c[i].z4;
+    const Fq2 z0 = ((z1.sqr().dbl() + c[i].z2 * c[i].z5 - (m34.dbl() + m34)).norm().mul_xi() + Fq2::one()).norm();
+    out[i].c0.c0 = z0;
+    out[i].c0.c1 = c[i].z4;
+    out[i].c0.c2 = c[i].z3;
+    out[i].c1.c0 = c[i].z2;
+    out[i].c1.c1 = z1;
+    out[i].c1.c2 = c[i].z5;
+  }
+}
+
+// f^|x| followed by conjugation (x < 0), for f in the cyclotomic subgroup.  |x| (and |x| >> 1) has
+// six set bits p0 < ... < p5 with long gaps below p2 (16, 48, 57) and short ones above: the powers
+// f^(2^p0), f^(2^p1), f^(2^p2) come from ONE chain of compressed squarings (6 Fq2 squarings each,
+// Karabina) and are decompressed together; the remaining six squarings run on full elements
+// (Granger-Scott, 9 each).
 TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
-  Fq12 r = f;
+#if defined(TC_PLAIN_CYCLO_EXP)  // experiment switch: 63 full squarings, no decompression
+  Fq12 r0 = f;
   bool started = false;
   TC_NOUNROLL for (int i = 63; i >= 0; i--) {
-    if (started) r = r.cyclotomic_sqr();
+    if (started) r0 = r0.cyclotomic_sqr();
     if ((x >> i) & 1ull) {
-      if (started) r = r * f;
+      if (started) r0 = r0 * f;
       started = true;
     }
+  }
+  return r0.conj();
+#endif
+  CycloCompressed saved[3];
+  int bit = 0;
+  {
+    CycloCompressed c = CycloCompressed::from(f);
+    int ns = 0;
+    TC_NOUNROLL for (;; bit++) {
+      if ((x >> bit) & 1ull) {
+        saved[ns++] = c;
+        if (ns == 3) break;
+      }
+      c = c.sqr();
+    }
+  }
+  Fq12 pw[3];
+  cyclotomic_decompress3(saved, pw);
+  Fq12 r = pw[0] * pw[1] * pw[2];
+  Fq12 t = pw[2];
+  TC_NOUNROLL for (bit++; bit < 64; bit++) {
+    t = t.cyclotomic_sqr();
+    if ((x >> bit) & 1ull) r = r * t;
   }
   return r.conj();
 }

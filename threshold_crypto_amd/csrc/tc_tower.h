@@ -317,4 +317,35 @@ struct Fq12 {
   }
 };
 
+// Karabina's compressed form of an element of the cyclotomic subgroup: four of its six Fq2
+// coefficients, in the Granger-Scott numbering of cyclotomic_sqr() above
+//     f = z0 + z2 w + z4 w^2 + z1 w^3 + z3 w^4 + z5 w^5        (w^6 = xi).
+// The squaring formulas for (z2, z3, z4, z5) never read (z0, z1): 6 Fq2 squarings instead of 9.
+// decompress() (tc_pairing.h) recovers z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2) and
+// z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1.
+struct CycloCompressed {
+  Fq2 z2, z3, z4, z5;
+  TC_HD static CycloCompressed from(const Fq12& f) { return CycloCompressed{f.c1.c0, f.c0.c2, f.c0.c1, f.c1.c2}; }
+  TC_CYCLO_ATTR CycloCompressed sqr() const {
+    Fq2 t0, t1, t2, t3;
+    {
+      Fq2 a2 = z2.sqr(), b2 = z3.sqr();
+      t0 = (b2.mul_xi() + a2).norm();
+      t1 = (z2 + z3).sqr() - a2 - b2;
+    }
+    {
+      Fq2 a2 = z4.sqr(), b2 = z5.sqr();
+      t2 = (b2.mul_xi() + a2).norm();
+      t3 = (z4 + z5).sqr() - a2 - b2;
+    }
+    const Fq2 t3x = t3.mul_xi().norm();
+    CycloCompressed r;
+    r.z4 = ((t0 - z4).dbl() + t0).reduce_value();
+    r.z5 = ((t1 + z5).dbl() + t1).reduce_value();
+    r.z2 = ((t3x + z2).dbl() + t3x).reduce_value();
+    r.z3 = ((t2 - z3).dbl() + t2).reduce_value();
+    return r;
+  }
+};
+
 }  // namespace tc
