@@ -76,13 +76,15 @@ TC_HD void miller_ell(Fq12& f, const LineCoeffs& l, const G1Affine& p) {
 
 // f *= product of the lines of all pairs.  Two lines are multiplied with each other first (6 Fq2
 // products) and f by the result (17) -- 23 instead of the 2 x 13 of two sparse multiplications.
+// `fresh` (wave-uniform): f is still 1, the product of the two lines simply becomes f.
 template <int NP>
-TC_HD void miller_apply_lines(Fq12& f, const LineCoeffs* l, const G1Affine* ps, const bool* skip) {
+TC_HD void miller_apply_lines(Fq12& f, const LineCoeffs* l, const G1Affine* ps, const bool* skip, bool fresh = false) {
   if (NP == 2) {
     if (!skip[0] && !skip[1]) {
       const Fq12 lp = Fq12::line_product(l[0].c2, l[0].c1.scale(ps[0].x), l[0].c0.scale(ps[0].y), l[1].c2,
                                          l[1].c1.scale(ps[1].x), l[1].c0.scale(ps[1].y));
-      f = f.mul_by_line_product(lp);
+      if (fresh) f = lp;
+      else f = f.mul_by_line_product(lp);
       return;
     }
   }
@@ -111,7 +113,7 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
   TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
     TC_UNROLL for (int k = 0; k < NP; k++)
       if (!skip[k]) l[k] = miller_doubling_step(r[k]);
-    miller_apply_lines<NP>(f, l, ps, skip);
+    miller_apply_lines<NP>(f, l, ps, skip, i == 61);
     if ((xs >> i) & 1ull) {
       TC_UNROLL for (int k = 0; k < NP; k++)
         if (!skip[k]) l[k] = miller_addition_step(r[k], qs[k]);
