@@ -44,6 +44,8 @@ res = {}
 cnt()
 L.hs_g2_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g2_uncompressed(P2), buf(192)); res["g2_mul"] = (cnt(), 2)
 L.hs_g1_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g1_uncompressed(P1), buf(96)); res["g1_mul"] = (cnt(), 1)
+L.hs_g2_mul_shared(b"".join(o.fr_to_bytes(rnd.randrange(o.R)) for _ in range(4)), 4, o.g2_uncompressed(P2), buf(768), buf(4))
+res["g2_mul_x4_one_point"] = (tuple(x // 4 for x in cnt()), 2)
 poly = [rnd.randrange(o.R) for _ in range(4)]
 shares_g2 = {i: o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in range(10)}
 shares_g1 = {i: o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in range(10)}

@@ -159,6 +159,35 @@ def test_point_mul(L, rnd):
     assert L.hs_g2_mul(o.fr_to_bytes(5), bytes(bad), out) == 3
 
 
+def test_g2_mul_several_scalars_share_one_table(L, rnd):
+    """tc_jobs.h job_g2_mul_shared: the S signers of tc_g2_mul_batch over one hash point."""
+    Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    for n in (1, 2, 3, 4):
+        ks = [rnd.randrange(o.R) for _ in range(n)]
+        if n == 3:
+            ks[1] = 0
+        if n == 4:
+            ks[2] = o.R - 1
+        out, st = buf(192 * n), buf(n)
+        L.hs_g2_mul_shared(b"".join(o.fr_to_bytes(k) for k in ks), n, o.g2_uncompressed(Q2), out, st)
+        assert st.raw == bytes(n)
+        for s, k in enumerate(ks):
+            assert out.raw[192 * s:192 * s + 192] == o.g2_uncompressed(o.E2.mul(Q2, k)), (n, s)
+    # a scalar >= r fails alone; a bad point fails every output; infinity in, infinity out
+    frs = o.fr_to_bytes(5) + (o.R).to_bytes(32, "little") + o.fr_to_bytes(7)
+    out, st = buf(192 * 3), buf(3)
+    L.hs_g2_mul_shared(frs, 3, o.g2_uncompressed(Q2), out, st)
+    assert st.raw == bytes([0, 3, 0])
+    assert out.raw[:192] == o.g2_uncompressed(o.E2.mul(Q2, 5)) and out.raw[384:] == o.g2_uncompressed(o.E2.mul(Q2, 7))
+    assert out.raw[192:384] == o.g2_uncompressed(None)
+    bad = bytearray(o.g2_uncompressed(Q2))
+    bad[191] ^= 1
+    L.hs_g2_mul_shared(frs, 3, bytes(bad), out, st)
+    assert st.raw == bytes([3, 3, 3]) and out.raw == o.g2_uncompressed(None) * 3
+    L.hs_g2_mul_shared(frs, 3, o.g2_uncompressed(None), out, st)
+    assert st.raw == bytes([0, 3, 0]) and out.raw == o.g2_uncompressed(None) * 3
+
+
 @pytest.mark.parametrize("t", [0, 1, 3, 4, 6])
 def test_combine(L, rnd, t):
     poly = [rnd.randrange(o.R) for _ in range(t + 1)]

@@ -20,6 +20,20 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   if (status && (L == 1 || pair_leader())) status[o] = st;
 }
 
+// S > 1 scalars over the same G2 points: a lane pair takes one point and a chunk of up to
+// kMulShare scalars (chunk-major lane order, so a wave shares its scalars).
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_shared(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts, size_t S,
+                                                                     size_t B, uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+  const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const size_t chunks = (S + kMulShare - 1) / kMulShare;
+  if (tid >= chunks * B) return;
+  const size_t c = tid / B, j = tid % B;
+  const size_t s0 = c * kMulShare;
+  const int n = (int)((S - s0 < (size_t)kMulShare) ? S - s0 : (size_t)kMulShare);
+  const size_t o = j * S + s0;
+  job_g2_mul_shared(fr + s0 * 32, n, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
+}
+
 template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_compress(const uint8_t* __restrict__ in, size_t B,
                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
@@ -50,7 +64,13 @@ void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t
 }
 void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {
-  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+  if (!(S * B)) return;
+  if (S > 1) {
+    const size_t chunks = (S + kMulShare - 1) / kMulShare;
+    hipLaunchKernelGGL(k_g2_mul_shared, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+  } else {
+    hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+  }
 }
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_compress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);

@@ -151,6 +151,27 @@ TC_HD_NOINLINE Affine<F> jac_to_affine(const Jac<F>& p) {
   return Affine<F>{p.x * zi2, p.y * zi2 * zi, false};
 }
 
+// n <= N Jacobian points to affine with ONE inversion (Montgomery's trick); infinity stays infinity
+template <class F, int N>
+TC_HD void jac_batch_to_affine(const Jac<F>* in, Affine<F>* out, int n) {
+  F pre[N];
+  bool inf[N];
+  F acc = F::one();
+  TC_NOUNROLL for (int i = 0; i < n; i++) {
+    inf[i] = in[i].is_inf();
+    pre[i] = acc;
+    acc = acc * F::select(inf[i], F::one(), in[i].z);
+  }
+  F inv = acc.inv();
+  TC_NOUNROLL for (int i = n - 1; i >= 0; i--) {
+    const F zi = inv * pre[i];
+    inv = inv * F::select(inf[i], F::one(), in[i].z);
+    const F zi2 = zi.sqr();
+    out[i] = Affine<F>{in[i].x * zi2, in[i].y * (zi2 * zi), inf[i]};
+    if (inf[i]) out[i] = Affine<F>::infinity();
+  }
+}
+
 // Brings n <= 16 Jacobian points to ONE common Z without an inversion:
 //     out[i] = (X_i F_i^2, Y_i F_i^3),   F_i = prod_{k != i} Z_k,   Zc = prod_k Z_k  (returned)
 // (X_i, Y_i, Z_i) ~ (X_i F_i^2, Y_i F_i^3, Zc), so every out[i] is an AFFINE point of the

@@ -91,40 +91,50 @@ TC_HD SacDigits sac_recode4(const uint64_t* d) {
 // sums are brought to one common Z (no inversion: jac_batch_to_common_z) and B0 scaled to it, so
 // every addition of the 64-step ladder is a mixed one on the isomorphic curve (7M + 4S instead of
 // 11M + 5S in Fq2), and a table entry is two coordinates.
-TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Affine* base, const uint64_t* d) {
-  const SacDigits sd = sac_recode4(d);
-  G2Affine tbl[8];
+struct G2SacTable {
+  G2Affine tbl[8];  // B0 + (subset sums of B1, B2, B3), affine on the curve scaled by zc
   Fq2 zc;
-  {
-    G2Jac sums[7];
-    G2Affine sums_aff[7];
-    TC_NOUNROLL for (int m = 1; m < 8; m++) {
-      const int low = __builtin_ctz((unsigned)m);
-      const int rest = m & (m - 1);
-      sums[m - 1] = rest ? jac_add_mixed(sums[rest - 1], base[low + 1]) : jac_add_affine(base[0], base[low + 1]);
-    }
-    zc = jac_batch_to_common_z(sums, sums_aff, 7);
-    const Fq2 zc2 = zc.sqr();
-    const Fq2 zc3 = zc2 * zc;
-    tbl[0] = affine_scale_z(base[0], zc2, zc3);
-    TC_NOUNROLL for (int m = 1; m < 8; m++) tbl[m] = sums_aff[m - 1];
+};
+TC_HD void g2_sac_table(const G2Affine* base, G2SacTable& t) {
+  G2Jac sums[7];
+  G2Affine sums_aff[7];
+  TC_NOUNROLL for (int m = 1; m < 8; m++) {
+    const int low = __builtin_ctz((unsigned)m);
+    const int rest = m & (m - 1);
+    sums[m - 1] = rest ? jac_add_mixed(sums[rest - 1], base[low + 1]) : jac_add_affine(base[0], base[low + 1]);
   }
-  G2Jac acc = G2Jac::from_affine(tbl[sd.top]);
+  t.zc = jac_batch_to_common_z(sums, sums_aff, 7);
+  const Fq2 zc2 = t.zc.sqr();
+  const Fq2 zc3 = zc2 * t.zc;
+  t.tbl[0] = affine_scale_z(base[0], zc2, zc3);
+  TC_NOUNROLL for (int m = 1; m < 8; m++) t.tbl[m] = sums_aff[m - 1];
+}
+TC_HD G2Jac g2_sac_ladder(const G2SacTable& t, const uint64_t* d) {
+  const SacDigits sd = sac_recode4(d);
+  G2Jac acc = G2Jac::from_affine(t.tbl[sd.top]);
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((sd.u[0] >> bit) & 1) | ((uint32_t)((sd.u[1] >> bit) & 1) << 1) |
                        ((uint32_t)((sd.u[2] >> bit) & 1) << 2);
-    G2Affine e = tbl[m];
+    G2Affine e = t.tbl[m];
     e.y = Fq2::select((sd.neg >> bit) & 1, -e.y, e.y);
     acc = jac_add_mixed(acc, e);
   }
   if (wave_any(sd.fix)) {
-    G2Affine e = tbl[0];
+    G2Affine e = t.tbl[0];
     e.y = -e.y;
     acc = G2Jac::select(sd.fix, jac_add_mixed(acc, e), acc);
   }
-  acc.z = coord_norm(acc.z * zc);
+  acc.z = coord_norm(acc.z * t.zc);
   return acc;
+}
+// out-of-line forms for callers that run several ladders over one table (tc_jobs.h job_g2_mul_shared)
+TC_HD_NOINLINE void g2_sac_table_call(const G2Affine* base, G2SacTable& t) { g2_sac_table(base, t); }
+TC_HD_NOINLINE G2Jac g2_sac_ladder_call(const G2SacTable& t, const uint64_t* d) { return g2_sac_ladder(t, d); }
+TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Affine* base, const uint64_t* d) {
+  G2SacTable t;
+  g2_sac_table(base, t);
+  return g2_sac_ladder(t, d);
 }
 
 // the four psi-images the digits multiply:  P, -psi(P), psi^2(P), -psi^3(P)

@@ -65,6 +65,37 @@ TC_HD uint8_t job_point_mul(const uint8_t* fr_le32, const uint8_t* pt, uint8_t* 
   return TC_JOB_OK;
 }
 
+// out[s] = fr[s] * pt for n <= C scalars and ONE G2 point (the S signers of tc_g2_mul_batch over the
+// same hash point): one decode, one table of psi-images (tc_gls.h g2_sac_table) and one inversion
+// for the n results.  A bad point fails all n outputs, a bad scalar only its own.
+constexpr int kMulShare = 4;
+TC_HD void job_g2_mul_shared(const uint8_t* fr_le32, int n, const uint8_t* pt, uint8_t* out, uint8_t* status, bool leader) {
+  G2Affine p;
+  const bool pok = g2_decode_uncompressed(pt, p);
+  if (!pok) p = G2Affine::infinity();
+  G2Affine base[4];
+  g2_gls_bases(p, base);
+  G2SacTable tb;
+  g2_sac_table_call(base, tb);
+  G2Jac res[kMulShare];
+  bool ok[kMulShare];
+  TC_NOUNROLL for (int s = 0; s < n; s++) {
+    uint32_t k[8];
+    ok[s] = fr_from_le32(fr_le32 + 32 * s, k) && pok;
+    uint64_t d[4];
+    const bool flip = gls_decompose_odd(k, d);
+    G2Jac r = g2_sac_ladder_call(tb, d);
+    r.y = Fq2::select(flip, -r.y, r.y);
+    res[s] = G2Jac::select(ok[s], r, G2Jac::infinity());
+  }
+  G2Affine aff[kMulShare];
+  jac_batch_to_affine<Fq2, kMulShare>(res, aff, n);
+  TC_NOUNROLL for (int s = 0; s < n; s++) {
+    g2_encode_uncompressed(aff[s], out + (size_t)s * 192);
+    if (status && leader) status[s] = ok[s] ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+  }
+}
+
 // Lagrange coefficient (job, position i) -> 8 canonical LE words
 TC_HD uint8_t job_lagrange(const uint64_t* idx, int t, int i, uint32_t* out_words) {
   Fr lam;
