@@ -172,16 +172,16 @@ TC_HD void jac_batch_to_affine(const Jac<F>* in, Affine<F>* out, int n) {
   }
 }
 
-// Brings n <= 16 Jacobian points to ONE common Z without an inversion:
+// Brings n <= CAP Jacobian points to ONE common Z without an inversion:
 //     out[i] = (X_i F_i^2, Y_i F_i^3),   F_i = prod_{k != i} Z_k,   Zc = prod_k Z_k  (returned)
 // (X_i, Y_i, Z_i) ~ (X_i F_i^2, Y_i F_i^3, Zc), so every out[i] is an AFFINE point of the
 // isomorphic curve y^2 = x^3 + b Zc^6.  The a = 0 group law never reads b: a ladder can run on
 // those affine points with mixed additions, and its result (X, Y, Z) is (X, Y, Z Zc) on the
 // original curve.  Points at infinity stay flagged and count as Z = 1.
-template <class F>
+template <class F, int CAP = 16>
 TC_HD F jac_batch_to_common_z(const Jac<F>* in, Affine<F>* out, int n) {
-  F pre[16];
-  bool inf[16];
+  F pre[CAP];
+  bool inf[CAP];
   F acc = F::one();
   TC_NOUNROLL for (int i = 0; i < n; i++) {
     inf[i] = in[i].is_inf();

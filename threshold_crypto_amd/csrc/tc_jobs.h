@@ -129,7 +129,7 @@ TC_HD uint8_t job_lincomb(int n, const uint8_t* points, const uint32_t* scalars,
         for (int w = 0; w < 8; w++) sc[j][w] = 0;
       }
     }
-    Jac<F> part = straus_chunk<F, 4>(pts, sc);
+    Jac<F> part = lincomb_chunk4(pts, sc);
     total = jac_add(total, part);
   }
   if (!ok) {
