@@ -137,6 +137,18 @@ TC_HD bool wave_any(bool c) {
   return c;
 #endif
 }
+// A value every lane of the wave holds identically (a constant handed to an out-of-line function
+// arrives in a VGPR): read it from the first lane so loops steered by it compile to scalar
+// branches instead of exec-masked ones.
+TC_HD uint64_t wave_uniform(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+#else
+  return v;
+#endif
+}
 }  // namespace tc
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -170,7 +170,8 @@ TC_HD_NOINLINE void cyclotomic_decompress3(const CycloCompressed* c, Fq12* out) 
 // f^(2^p0), f^(2^p1), f^(2^p2) come from ONE chain of compressed squarings (6 Fq2 squarings each,
 // Karabina) and are decompressed together; the remaining six squarings run on full elements
 // (Granger-Scott, 9 each).
-TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x) {
+TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x_arg) {
+  const uint64_t x = wave_uniform(x_arg);  // |x| or |x| >> 1, the same in every lane
 #if defined(TC_PLAIN_CYCLO_EXP)  // experiment switch: 63 full squarings, no decompression
   Fq12 r0 = f;
   bool started = false;
