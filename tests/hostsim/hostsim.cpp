@@ -221,6 +221,10 @@ void hs_chacha_words(const uint8_t* seed32, int n, uint32_t* out) {
   for (int i = 0; i < n; i++) out[i] = rng.next_u32();
 }
 void hs_hash_g2(const uint8_t* msg, size_t len, uint8_t* out192) { job_hash_g2(msg, len, out192); }
+// the hash point before its last constant multiplication, and the two ways of folding that constant
+void hs_hash_g2_unfixed(const uint8_t* msg, size_t len, uint8_t* out192) { job_hash_g2(msg, len, out192, false); }
+void hs_fr_scale_cofactor_fix(const uint8_t* fr, uint8_t* out) { job_fr_scale_cofactor_fix(fr, out); }
+void hs_g1_scale_cofactor_fix(const uint8_t* in96, uint8_t* out96) { job_g1_scale_cofactor_fix(in96, out96); }
 #if defined(TC_TEST_HOOKS)
 void hs_force_extra_hash_rounds(int n) { g_tc_force_extra_rounds = n; }
 #endif

@@ -258,6 +258,35 @@ def test_hash_and_kdf(L, rnd):
     assert out.raw == o.g2_compressed(Qp)
 
 
+def test_hash_constant_folds_into_scalars_and_g1_operands(L, rnd):
+    """tc_gls.h g2_clear_cofactor(fix=false): hash_g2(m) = [c] Q' with c = (3 (x^2 - 1))^-1 mod r; the composed
+    entry points (sign, verify, ciphertext checks, encrypt) move c into a scalar or a G1 point."""
+    c = pow(3 * (o.BLS_X ** 2 - 1), -1, o.R)
+    for m in [b"", b"Test message", bytes(range(150))]:
+        out = buf(192)
+        L.hs_hash_g2_unfixed(m, len(m), out)
+        q = o.g2_from_uncompressed(out.raw)
+        assert o.E2.mul(q, o.R) is None                       # already in G2
+        assert o.E2.mul(q, c) == o.hash_g2(m)
+    for k in [0, 1, 5, o.R - 1, rnd.randrange(o.R)]:
+        out = buf(32)
+        L.hs_fr_scale_cofactor_fix(o.fr_to_bytes(k), out)
+        assert out.raw == o.fr_to_bytes(k * c % o.R)
+    out = buf(32)
+    L.hs_fr_scale_cofactor_fix((o.R + 1).to_bytes(32, "little"), out)
+    assert out.raw == b"\xff" * 32                            # stays invalid for the multiplication kernel
+    P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    out = buf(96)
+    L.hs_g1_scale_cofactor_fix(o.g1_uncompressed(P), out)
+    assert out.raw == o.g1_uncompressed(o.E1.mul(P, c))
+    L.hs_g1_scale_cofactor_fix(o.g1_uncompressed(None), out)
+    assert out.raw == o.g1_uncompressed(None)
+    bad = bytearray(o.g1_uncompressed(P))
+    bad[95] ^= 1
+    L.hs_g1_scale_cofactor_fix(bytes(bad), out)
+    assert out.raw == bytes(bad)                              # passes through: the pairing kernel rejects it
+
+
 def test_inverse_of_small_denominator(L, rnd):
     # D^-1 mod r by 64-bit Euclid + exact division (tc_threshold.h), the fast path's only inversion
     L.hs_fr_inverse_of_small.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p]

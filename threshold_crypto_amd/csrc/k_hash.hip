@@ -5,18 +5,18 @@
 namespace tc {
 
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g2(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
-                                                    size_t B, uint8_t* __restrict__ out) {
+                                                    size_t B, uint8_t* __restrict__ out, int fix) {
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
-  job_hash_g2(msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192);
+  job_hash_g2(msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192, fix != 0);
 }
 
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g1_g2(const uint8_t* __restrict__ g1, const uint8_t* __restrict__ msgs,
                                                        const uint64_t* __restrict__ off, size_t B,
-                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ status, int fix) {
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
-  uint8_t st = job_hash_g1_g2(g1 + j * 96, msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192);
+  uint8_t st = job_hash_g1_g2(g1 + j * 96, msgs + off[j], (size_t)(off[j + 1] - off[j]), out + j * 192, fix != 0);
   if (status && pair_leader()) status[j] = st;
 }
 
@@ -60,12 +60,12 @@ void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t,
                                 uint8_t* status) {
   if (M) hipLaunchKernelGGL(k_commitment_evaluate, dim3(grid_for(M)), dim3(kBlock), 0, st, commit, t, idx, M, out, status);
 }
-void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out) {
-  if (B) hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out);
+void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix) {
+  if (B) hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
 }
 void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
-                       uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status);
+                       uint8_t* out, uint8_t* status, bool fix) {
+  if (B) hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
 }
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                           uint8_t* out, uint8_t* status) {

@@ -54,8 +54,22 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
-__global__ void k_fill_g1_generator(uint8_t* out96) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) g1_encode_uncompressed(g1_generator(), out96);
+// scalars / G1 points folded with the hash's constant FR_COFACTOR_FIX (tc_jobs.h)
+__global__ void k_fr_scale_cofactor_fix(const uint8_t* __restrict__ fr, size_t S, uint8_t* __restrict__ out) {
+  const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s < S) job_fr_scale_cofactor_fix(fr + s * 32, out + s * 32);
+}
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_g1_scale_cofactor_fix(const uint8_t* __restrict__ in, size_t stride, size_t n,
+                                                                            uint8_t* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < n) job_g1_scale_cofactor_fix(in + j * stride, out + j * 96);
+}
+
+__global__ void k_fill_g1_generator(uint8_t* out96, uint8_t* out96_unfix) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    g1_encode_uncompressed(g1_generator(), out96);
+    g1_encode_uncompressed(jac_to_affine(g1_mul_glv(g1_generator(), FR_COFACTOR_UNFIX)), out96_unfix);
+  }
 }
 
 void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
@@ -84,8 +98,14 @@ void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* 
 void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
 }
-void launch_fill_g1_generator(hipStream_t st, uint8_t* out96) {
-  hipLaunchKernelGGL(k_fill_g1_generator, dim3(1), dim3(64), 0, st, out96);
+void launch_fr_scale_cofactor_fix(hipStream_t st, const uint8_t* fr, size_t S, uint8_t* out) {
+  if (S) hipLaunchKernelGGL(k_fr_scale_cofactor_fix, dim3(grid_for(S)), dim3(kBlock), 0, st, fr, S, out);
+}
+void launch_g1_scale_cofactor_fix(hipStream_t st, const uint8_t* in, size_t stride, size_t n, uint8_t* out) {
+  if (n) hipLaunchKernelGGL(k_g1_scale_cofactor_fix, dim3(grid_for(n)), dim3(kBlock), 0, st, in, stride, n, out);
+}
+void launch_fill_g1_generator(hipStream_t st, uint8_t* out96, uint8_t* out96_unfix) {
+  hipLaunchKernelGGL(k_fill_g1_generator, dim3(1), dim3(64), 0, st, out96, out96_unfix);
 }
 
 }  // namespace tc

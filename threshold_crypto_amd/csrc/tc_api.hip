@@ -30,6 +30,10 @@ struct tc_ctx {
   std::vector<Slot> slots;  // grow-only device staging buffers, reused across calls
   size_t next_slot = 0;
   uint8_t* g1_gen = nullptr;  // 96 B uncompressed G1 generator on the device
+  // [3 (x^2 - 1)] g1: the generator side of a pairing check whose other side holds a hash point without
+  // its last constant multiplication (tc_gls.h g2_clear_cofactor): e(pk, [c] Q') == e(g1, sig)  <=>
+  // e(pk, Q') == e([1/c] g1, sig)
+  uint8_t* g1_gen_unfix = nullptr;
 };
 
 namespace {
@@ -166,12 +170,12 @@ int tc_ctx_create(tc_ctx** out, int device) {
   c->device = device;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-      hipMalloc((void**)&c->g1_gen, 96) != hipSuccess) {
+      hipMalloc((void**)&c->g1_gen, 96) != hipSuccess || hipMalloc((void**)&c->g1_gen_unfix, 96) != hipSuccess) {
     tc_ctx_destroy(c);
     return TC_ERR_HIP;
   }
   c->stream = c->own_stream;
-  tc::launch_fill_g1_generator(c->stream, c->g1_gen);
+  tc::launch_fill_g1_generator(c->stream, c->g1_gen, c->g1_gen_unfix);
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
     // typically: no gfx950 code object for this device
     tc_ctx_destroy(c);
@@ -187,6 +191,7 @@ void tc_ctx_destroy(tc_ctx* c) {
   for (auto& s : c->slots)
     if (s.p) (void)hipFree(s.p);
   if (c->g1_gen) (void)hipFree(c->g1_gen);
+  if (c->g1_gen_unfix) (void)hipFree(c->g1_gen_unfix);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -303,12 +308,16 @@ int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uin
   const uint8_t* d_msgs = k.in(msgs, (size_t)total);
   const uint64_t* d_off = k.in(off, B + 1);
   uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_frc = k.temp<uint8_t>(S * 32);
+  if (d_frc) k.wipe.emplace_back(d_frc, S * 32);
   uint8_t* d_out = k.out(out_g2, S * B * 192);
   uint8_t* d_st = k.out(status, S * B);
   k.begin_timing();
   if (!k.failed) {
-    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash);
-    tc::launch_g2_mul(ctx->stream, d_fr, d_hash, S, B, d_out, d_st);
+    // sk * hash_g2(m) = (sk c) * Q': the hash skips its last constant multiplication, the scalars carry it
+    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
+    tc::launch_fr_scale_cofactor_fix(ctx->stream, d_fr, S, d_frc);
+    tc::launch_g2_mul(ctx->stream, d_frc, d_hash, S, B, d_out, d_st);
   }
   k.end_timing();
   return k.finish();
@@ -494,8 +503,10 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
   if (!k.failed) {
-    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash);
-    tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen, 0, d_sig, 192, B, d_ok);
+    // e(pk, [c] Q') == e(g1, sig)  <=>  e(pk, Q') == e([1/c] g1, sig): the hash skips its last constant
+    // multiplication and the generator side uses the context's pre-scaled generator
+    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
+    tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen_unfix, 0, d_sig, 192, B, d_ok);
   }
   k.end_timing();
   return k.finish();
@@ -519,9 +530,9 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
   k.begin_timing();
   if (!k.failed) {
     // an undecodable u leaves an infinity hash; the pairing kernel then rejects u itself
-    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr);
-    // e(g1, w) == e(u, hash)                                            (src/lib.rs:511)
-    tc::launch_pairing_check(ctx->stream, ctx->g1_gen, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok);
+    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
+    // e(g1, w) == e(u, [c] Q')  <=>  e([1/c] g1, w) == e(u, Q')         (src/lib.rs:511)
+    tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok);
   }
   k.end_timing();
   return k.finish();
@@ -546,12 +557,14 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
   const uint8_t* d_w = k.in(w, B * 192);
   uint8_t* d_hash = k.temp<uint8_t>(B * 192);
   uint8_t* d_st = k.temp<uint8_t>(B);
+  uint8_t* d_sharec = k.temp<uint8_t>(B * 96);
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
   if (!k.failed) {
-    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st);
-    // e(share, hash) == e(pk_share, w)                                  (src/lib.rs:185)
-    tc::launch_pairing_check(ctx->stream, d_share, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok);
+    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st, /*fix=*/false);
+    tc::launch_g1_scale_cofactor_fix(ctx->stream, d_share, 96, B, d_sharec);
+    // e(share, hash) = e([c] share, Q') == e(pk_share, w)               (src/lib.rs:185)
+    tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok);
   }
   k.end_timing();
   return k.finish();

@@ -204,7 +204,10 @@ TC_HD_NOINLINE G2Jac g2_mul_by_x_abs(const G2Jac& p) {
 }
 
 // [h2] P for ANY point of E'(Fq2): the value the reference's scale_by_cofactor returns.
-TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa) {
+// fix = false stops before the last multiplication and returns Q' = [3(x^2-1) h2] P, the point of G2
+// with [h2] P = [c] Q', c = FR_COFACTOR_FIX: callers that multiply the hash point by a scalar or pair
+// it with a G1 point fold c into that scalar / that point instead (tc_jobs.h).
+TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa, bool fix = true) {
   const G2Jac p = G2Jac::from_affine(pa);
   G2Jac t1 = jac_neg(g2_mul_by_x_abs(p));            // [x] P          (x < 0)
   G2Jac t2 = g2_psi(p);                              // psi(P)
@@ -215,6 +218,7 @@ TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa) {
   t3 = jac_add(t3, t2);
   t3 = jac_add(t3, jac_neg(t1));
   t3 = jac_add(t3, jac_neg(p));                      // = [3(x^2-1) h2] P, in G2
+  if (!fix) return t3;
   return g2_gls_digits_mul(t3, G2_COFACTOR_FIX_DIGITS);
 }
 

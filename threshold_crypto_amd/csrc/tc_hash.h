@@ -168,7 +168,7 @@ TC_HD G2Candidate g2_draw_candidate(ChaChaRng& rng) {
 // identity, to walk the otherwise unreachable second round of the outer loop
 inline int g_tc_force_extra_rounds = 0;
 #endif
-TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words) {
+TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words, bool fix = true) {
   ChaChaRng rng;
 #if defined(TC_TEST_HOOKS)
   int forced = g_tc_force_extra_rounds;
@@ -216,7 +216,7 @@ TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words) {
     // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
     const bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
     G2Affine cand{pick.x, (y_lt_negy ^ pick.greatest) ? y : negy, false};
-    res = g2_clear_cofactor(cand);  // = [h2] cand, the value scale_by_cofactor returns
+    res = g2_clear_cofactor(cand, fix);  // = [h2] cand, the value scale_by_cofactor returns (fix = false: tc_gls.h)
     done = !res.is_inf();
 #if defined(TC_TEST_HOOKS)
     if (forced > 0) {

@@ -96,6 +96,36 @@ TC_HD void job_g2_mul_shared(const uint8_t* fr_le32, int n, const uint8_t* pt, u
   }
 }
 
+// k * c mod r for c = FR_COFACTOR_FIX (canonical words in and out)
+TC_HD void fr_mul_cofactor_fix(const uint32_t* k, uint32_t* out) {
+  (Fr::from_canonical(k) * Fr::from_canonical(FR_COFACTOR_FIX)).to_canonical(out);
+}
+// scalar of a signer folded with the hash's constant: out = fr * c mod r; a non-canonical scalar stays
+// non-canonical (all ones) so that the multiplication kernel flags it as before
+TC_HD void job_fr_scale_cofactor_fix(const uint8_t* fr_le32, uint8_t* out_le32) {
+  uint32_t k[8], kc[8];
+  const bool ok = fr_from_le32(fr_le32, k);
+  fr_mul_cofactor_fix(k, kc);
+  TC_UNROLL for (int i = 0; i < 8; i++) {
+    const uint32_t w = ok ? kc[i] : 0xffffffffu;
+    out_le32[4 * i] = (uint8_t)w;
+    out_le32[4 * i + 1] = (uint8_t)(w >> 8);
+    out_le32[4 * i + 2] = (uint8_t)(w >> 16);
+    out_le32[4 * i + 3] = (uint8_t)(w >> 24);
+  }
+}
+// G1 operand of a pairing against a hash point, folded with the hash's constant: out = [c] P.
+// An encoding that does not decode is passed through unchanged, so the pairing kernel rejects it
+// exactly as it would have rejected the original.
+TC_HD void job_g1_scale_cofactor_fix(const uint8_t* in96, uint8_t* out96) {
+  G1Affine p;
+  if (!g1_decode_uncompressed(in96, p)) {
+    for (int i = 0; i < 96; i++) out96[i] = in96[i];
+    return;
+  }
+  g1_encode_uncompressed(jac_to_affine(g1_mul_glv(p, FR_COFACTOR_FIX)), out96);
+}
+
 // Lagrange coefficient (job, position i) -> 8 canonical LE words
 TC_HD uint8_t job_lagrange(const uint64_t* idx, int t, int i, uint32_t* out_words) {
   Fr lam;
@@ -206,17 +236,19 @@ TC_HD uint8_t job_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_
 }
 
 // hash_g2(msg)      (src/lib.rs:691-694)
-TC_HD G2Jac hash_g2_point(const uint8_t* msg, size_t len) {
+// fix = false: the point Q' with hash_g2(msg) = [FR_COFACTOR_FIX] Q' (tc_gls.h g2_clear_cofactor), for the
+// composed entry points that fold the constant into a scalar or into the G1 operand of a pairing.
+TC_HD G2Jac hash_g2_point(const uint8_t* msg, size_t len, bool fix = true) {
   uint32_t seed[8];
   sha3_256_words(msg, len, seed);
-  return g2_random_from_seed(seed);
+  return g2_random_from_seed(seed, fix);
 }
-TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2) {
-  g2_encode_uncompressed(jac_to_affine(hash_g2_point(msg, len)), out_g2);
+TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix = true) {
+  g2_encode_uncompressed(jac_to_affine(hash_g2_point(msg, len, fix)), out_g2);
 }
 
 // hash_g1_g2(g1, msg)   (src/lib.rs:697-707)
-TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len) {
+TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, bool fix = true) {
   uint8_t buf[64 + 48];
   size_t n;
   if (len > 64) {
@@ -235,15 +267,15 @@ TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len) 
     n = len;
   }
   g1_encode_compressed(p, buf + n);
-  return hash_g2_point(buf, n + 48);
+  return hash_g2_point(buf, n + 48, fix);
 }
-TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2) {
+TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix = true) {
   G1Affine p;
   if (!g1_decode_uncompressed(g1, p)) {
     g2_encode_uncompressed(G2Affine::infinity(), out_g2);
     return TC_JOB_INVALID_ENCODING;
   }
-  g2_encode_uncompressed(jac_to_affine(hash_g1_g2_point(p, msg, len)), out_g2);
+  g2_encode_uncompressed(jac_to_affine(hash_g1_g2_point(p, msg, len, fix)), out_g2);
   return TC_JOB_OK;
 }
 
@@ -311,7 +343,10 @@ TC_HD uint8_t job_encrypt(const uint8_t* pk96, const uint8_t* r_le32, const uint
   job_xor_with_hash(g, msg, len, out_v);
   // (G2 values never round-trip through a per-lane byte buffer: in the lane-pair build each
   // lane only holds half of an encoding)
-  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(hash_g1_g2_point(u, out_v, len), k)), out_w);
+  // w = [r] [c] Q' = [r c mod r] Q': the cofactor-fix multiplication of the hash folds into this one
+  uint32_t kc[8];
+  fr_mul_cofactor_fix(k, kc);
+  g2_encode_uncompressed(jac_to_affine(g2_mul_gls(hash_g1_g2_point(u, out_v, len, false), kc)), out_w);
   return TC_JOB_OK;
 }
 

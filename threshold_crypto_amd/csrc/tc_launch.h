@@ -43,15 +43,20 @@ void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const u
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok);
 
-void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out);
+// fix = false: the hash point WITHOUT its last constant multiplication (tc_gls.h g2_clear_cofactor); the
+// caller folds the constant into a scalar (launch_fr_scale_cofactor_fix) or a G1 operand
+// (launch_g1_scale_cofactor_fix)
+void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix = true);
 void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
-                       uint8_t* out, uint8_t* status);
+                       uint8_t* out, uint8_t* status, bool fix = true);
+void launch_fr_scale_cofactor_fix(hipStream_t st, const uint8_t* fr, size_t S, uint8_t* out);
+void launch_g1_scale_cofactor_fix(hipStream_t st, const uint8_t* in, size_t stride, size_t n, uint8_t* out);
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                           uint8_t* out, uint8_t* status);
 void launch_encrypt(hipStream_t st, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status);
 void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                                 uint8_t* status);
-void launch_fill_g1_generator(hipStream_t st, uint8_t* out96);
+void launch_fill_g1_generator(hipStream_t st, uint8_t* out96, uint8_t* out96_unfix);
 
 }  // namespace tc
