@@ -143,6 +143,59 @@ while time.time() < t_end:
         if int(ok[j]) != int(c_oracle.pairing_check(bytes(a_[j]), bytes(b_[j]), bytes(c_[j]), bytes(d_[j])) == 1):
             fail("pairing_check", rounds, j)
     checked += Bp
+    # ---- composed entry points (the hash's constant folded into a scalar / the generator side) -----------
+    Bc = min(B, 40)
+    cm = msgs[:Bc]
+    cflat, coff = pack_messages(cm)
+    Sc = rnd.choice([1, 2, 5])
+    sks = [rnd.choice([0, 1, o.R - 1, rnd.randrange(o.R)]) for _ in range(Sc)]
+    sg, sst = e.sign(np.stack([u8(fr(k)) for k in sks]), cflat, coff)
+    for j in range(Bc):
+        hj = c_oracle.hash_g2(cm[j])
+        for s_ in range(Sc):
+            rc, want = c_oracle.g2_mul(fr(sks[s_]), hj)
+            if sst[j, s_] != 0 or rc != 0 or bytes(sg[j, s_]) != want:
+                fail("sign", rounds, j, "s=%d" % s_)
+    sk0 = rnd.randrange(1, o.R)
+    pk0 = c_oracle.g1_mul(fr(sk0), G1U)[1]
+    pks = np.zeros((Bc, 96), np.uint8); sigs = np.zeros((Bc, 192), np.uint8)
+    for j in range(Bc):
+        good = rnd.random() < 0.6
+        pks[j] = u8(maybe_corrupt(pk0 if rnd.random() > 0.05 else o.g1_uncompressed(None)))
+        sj = c_oracle.g2_mul(fr((sk0 + (0 if good else 1)) % o.R), c_oracle.hash_g2(cm[j]))[1]
+        sigs[j] = u8(maybe_corrupt(sj if rnd.random() > 0.05 else o.g2_uncompressed(None)))
+    okv = e.verify_sig(pks, sigs, cflat, coff)
+    oks = e.verify_sig(pks[0], sigs, cflat, coff)  # one shared key (stride 0)
+    for j in range(Bc):
+        hj = c_oracle.hash_g2(cm[j])
+        if int(okv[j]) != int(c_oracle.pairing_check(bytes(pks[j]), hj, G1U, bytes(sigs[j])) == 1):
+            fail("verify_sig", rounds, j)
+        if int(oks[j]) != int(c_oracle.pairing_check(bytes(pks[0]), hj, G1U, bytes(sigs[j])) == 1):
+            fail("verify_sig(shared key)", rounds, j)
+    us = np.zeros((Bc, 96), np.uint8); ws = np.zeros((Bc, 192), np.uint8)
+    shs = np.zeros((Bc, 96), np.uint8); pss = np.zeros((Bc, 96), np.uint8)
+    for j in range(Bc):
+        rj = rnd.randrange(1, o.R)
+        uj = c_oracle.g1_mul(fr(rj), G1U)[1]
+        us[j] = u8(maybe_corrupt(uj))
+        rc, hj = c_oracle.hash_g1_g2(bytes(us[j]), cm[j])
+        good = rnd.random() < 0.6
+        wj = c_oracle.g2_mul(fr((rj + (0 if good else 1)) % o.R), hj)[1] if rc == 0 else o.g2_uncompressed(None)
+        ws[j] = u8(maybe_corrupt(wj))
+        ski = rnd.randrange(1, o.R)
+        pss[j] = u8(maybe_corrupt(c_oracle.g1_mul(fr(ski), G1U)[1]))
+        shs[j] = u8(maybe_corrupt(c_oracle.g1_mul(fr((ski + (0 if rnd.random() < 0.6 else 1)) % o.R), uj)[1]))
+    okc = e.ciphertext_verify(us, cflat, coff, ws)
+    okd = e.verify_decryption_share(pss, shs, us, cflat, coff, ws)
+    for j in range(Bc):
+        rc, hj = c_oracle.hash_g1_g2(bytes(us[j]), cm[j])
+        want_c = rc == 0 and c_oracle.pairing_check(G1U, bytes(ws[j]), bytes(us[j]), hj) == 1
+        if int(okc[j]) != int(want_c):
+            fail("ciphertext_verify", rounds, j)
+        want_d = rc == 0 and c_oracle.pairing_check(bytes(shs[j]), hj, bytes(pss[j]), bytes(ws[j])) == 1
+        if int(okd[j]) != int(want_d):
+            fail("verify_decryption_share", rounds, j)
+    checked += Bc * (Sc + 4)
     # ---- compressed round trip ------------------------------------------------------------------------
     c2, stc = e.g2_compress(np.stack([u8(p) for p in pts2]))
     d2, std = e.g2_decompress(c2)

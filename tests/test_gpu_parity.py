@@ -281,6 +281,14 @@ def test_ciphertext_verify_and_decryption_shares(engine, rnd):
     w = g2s([ct[2]] * N)
     assert engine.verify_decryption_share(pks, g1s(dsh), u, v1, off1, w).all()
     assert engine.verify_decryption_share(pks, g1s(dsh_bad), u, v1, off1, w).tolist() == [1, 0, 1, 1, 1]
+    # an undecodable U fails both checks even when the remaining operands are identities (the pair that
+    # would carry the hash must not be skipped)
+    u_bad = u.copy()
+    u_bad[3, 95] ^= 1
+    inf1, inf2 = g1s([None] * N), g2s([None] * N)
+    assert engine.verify_decryption_share(inf1, inf1, u_bad, v1, off1, inf2).tolist() == [1, 1, 1, 0, 1]
+    assert engine.verify_decryption_share(pks, g1s(dsh), u_bad, v1, off1, w).tolist() == [1, 1, 1, 0, 1]
+    assert engine.ciphertext_verify(u_bad, v1, off1, w).tolist() == [1, 1, 1, 0, 1]
 
 
 def test_compress(engine, rnd):

@@ -272,7 +272,10 @@ TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, 
 TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix = true) {
   G1Affine p;
   if (!g1_decode_uncompressed(g1, p)) {
-    g2_encode_uncompressed(G2Affine::infinity(), out_g2);
+    // public form: infinity + status.  Internal (fix = false) form, consumed by a pairing check: an
+    // encoding that does not decode, so the check fails instead of skipping the pair
+    if (fix) g2_encode_uncompressed(G2Affine::infinity(), out_g2);
+    else for (int i = 0; i < 192; i++) out_g2[i] = 0xff;
     return TC_JOB_INVALID_ENCODING;
   }
   g2_encode_uncompressed(jac_to_affine(hash_g1_g2_point(p, msg, len, fix)), out_g2);
