@@ -491,6 +491,42 @@ def test_heterogeneous_waves_every_job_checked(engine, rnd):
         assert int(ok[j]) == int(c_oracle.pairing_check(bytes(a_[j]), bytes(b_[j]), bytes(c_[j]), bytes(d_[j])) == 1), j
 
 
+def test_combine_grouped_by_denominator_class_matches_ungrouped_and_oracle(engine, rnd):
+    """Batches of >= 4096 G2 jobs are regrouped by the class of their Lagrange denominator (k_combine.hip):
+    same outputs as the same jobs run in small, ungrouped batches; sampled jobs against the C oracle; large
+    indices (general path), a flagged job and an invalid share ride along."""
+    import c_oracle
+    c_oracle.load()
+    t, N, B = 3, 10, 4096 + 77
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    sks = [o.secret_key_share(poly, i) for i in range(N)]
+    ks = [rnd.randrange(1, o.R) for _ in range(B)]
+    G2U = np.frombuffer(o.g2_uncompressed(o.G2_GEN), np.uint8)
+    pts, _ = engine.g2_mul(frs(ks), G2U[None].copy())          # (1, B, 192)?  -> one point, B scalars
+    pts = np.ascontiguousarray(pts.reshape(B, 192))
+    shares_all, st = engine.g2_mul(frs(sks), pts)               # (B, N, 192)
+    assert not st.any()
+    idx = np.zeros((B, t + 1), np.uint64)
+    shares = np.zeros((B, t + 1, 192), np.uint8)
+    for j in range(B):
+        ids = sorted(rnd.sample(range(N), t + 1))
+        idx[j] = ids
+        shares[j] = shares_all[j, ids]
+    idx[5] += np.uint64(1 << 40)            # large indices: general path (wrong interpolation points, still deterministic)
+    idx[9, 1] = idx[9, 0]                   # duplicate index quirk (src/lib.rs:758)
+    shares[13, 2, 191] ^= 1                 # leaves the curve
+    got, gst = engine.combine_g2(t, idx, shares)
+    ref = np.zeros_like(got); rst = np.zeros_like(gst)
+    for lo in range(0, B, 1024):
+        ref[lo:lo + 1024], rst[lo:lo + 1024] = engine.combine_g2(t, idx[lo:lo + 1024].copy(), shares[lo:lo + 1024].copy())
+    assert (gst == rst).all() and gst[13] == 3 and (got == ref).all()
+    for j in [0, 5, 9, 13, B - 1] + rnd.sample(range(B), 40):
+        rc, want = c_oracle.combine_g2(t, [int(x) for x in idx[j]], [bytes(shares[j, k]) for k in range(t + 1)])
+        assert (gst[j] != 0) == (rc != 0), j
+        if rc == 0:
+            assert bytes(got[j]) == want, j
+
+
 def test_lincomb_with_infinity_points_zero_scalars_and_ragged_chunks(engine, rnd):
     """sum_i s_i P_i (Commitment::evaluate's shape, src/poly.rs:497-508) for n = 1..6 points, with the
     identity among the points, zero scalars and repeated points: the affine window tables of the

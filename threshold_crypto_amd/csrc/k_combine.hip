@@ -18,6 +18,49 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t
   if (st && status) status[j] = st;
 }
 
+// ---- grouping jobs by denominator class (tc_jobs.h combine_divide) -----------------------------------
+// Three tiny kernels turn the batch into a permutation in which every class occupies a run of whole
+// waves (runs padded to kCombinePad jobs with the marker 0xffffffff), so that the lanes of a wave take
+// the same branch of combine_divide.  Correctness does not depend on it: a mixed wave runs every
+// branch its lanes need.
+//   counters[c]      jobs of class c            (k_combine_classify)
+//   counters[4 + c]  next free slot of class c  (k_combine_offsets, k_combine_scatter)
+constexpr uint32_t kCombinePad = 64;
+__global__ void k_combine_classify(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
+                                   uint8_t* __restrict__ cls, uint32_t* __restrict__ counters) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const int c = (j < B) ? combine_job_class(idx + j * n_per_job, (int)t) : -1;
+  if (j < B) cls[j] = (uint8_t)c;
+  // one atomic per wave and class (tens of thousands of same-address atomics would serialise)
+  for (int k = 0; k < kCombineClasses; k++) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(c == k);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&counters[k], (uint32_t)__builtin_popcountll(m));
+  }
+}
+__global__ void k_combine_offsets(uint32_t* counters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t base = 0;
+  for (int c = 0; c < kCombineClasses; c++) {
+    counters[4 + c] = base;
+    base += (counters[c] + kCombinePad - 1) / kCombinePad * kCombinePad;
+  }
+}
+__global__ void k_combine_scatter(const uint8_t* __restrict__ cls, size_t B, uint32_t* __restrict__ counters,
+                                  uint32_t* __restrict__ perm) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const int c = (j < B) ? (int)cls[j] : -1;
+  const unsigned lane = threadIdx.x & 63;
+  for (int k = 0; k < kCombineClasses; k++) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(c == k);
+    if (!m) continue;
+    const unsigned leader = (unsigned)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&counters[4 + k], (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    if (c == k) perm[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)j;
+  }
+}
+
 template <class F>
 TC_D bool combine_fast(size_t t, const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* st) {
   if (t == 1) return job_combine_small<F, 2>(idx, shares, out, st);
@@ -31,11 +74,14 @@ template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                     const uint8_t* __restrict__ shares,
                                                     const uint32_t* __restrict__ lam, size_t B,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status,
+                                                    const uint32_t* __restrict__ perm, size_t slots) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
-  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
-  if (j >= B) return;
+  const size_t slot = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
+  if (slot >= slots) return;
+  const size_t j = perm ? (size_t)perm[slot] : slot;  // grouped by denominator class, or the identity
+  if (j >= B) return;                                 // padding between two classes
   if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
     PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
     return;
@@ -76,11 +122,25 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
 }
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_combine<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status);
+  if (B) hipLaunchKernelGGL(k_combine<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, (const uint32_t*)nullptr, B);
 }
+size_t combine_group_slots(size_t B) { return B + (size_t)kCombineClasses * kCombinePad; }
+// cls: B bytes, counters: 8 words, perm: combine_group_slots(B) words (scratch of the caller); pass
+// perm = nullptr to run the jobs in their own order
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status);
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
+                       uint32_t* perm) {
+  if (!B) return;
+  size_t slots = B;
+  if (perm) {
+    slots = combine_group_slots(B);
+    (void)hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st);
+    (void)hipMemsetAsync(perm, 0xff, slots * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_combine_classify, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, cls, counters);
+    hipLaunchKernelGGL(k_combine_offsets, dim3(1), dim3(64), 0, st, counters);
+    hipLaunchKernelGGL(k_combine_scatter, dim3(grid_for(B)), dim3(kBlock), 0, st, cls, B, counters, perm);
+  }
+  hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, (const uint32_t*)perm, slots);
 }
 
 }  // namespace tc

@@ -355,6 +355,13 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
   uint32_t* d_lam = k.temp<uint32_t>(B * (t + 1) * 8);
   uint8_t* d_st = k.out(status, B, /*zero=*/true);
   uint8_t* d_pt = plain ? k.temp<uint8_t>(B * PB) : k.out(out, B * PB);
+  // G2, t <= 3: jobs are grouped by the class of their Lagrange denominator so that whole waves take
+  // the cheap forms of the final division (tc_jobs.h combine_divide); not worth three launches for a
+  // batch that fills a fraction of the machine anyway
+  const bool group = g2 && t >= 1 && t <= 3 && B >= 4096;
+  uint8_t* d_cls = group ? k.temp<uint8_t>(B) : nullptr;
+  uint32_t* d_counters = group ? k.temp<uint32_t>(8) : nullptr;
+  uint32_t* d_perm = group ? k.temp<uint32_t>(tc::combine_group_slots(B)) : nullptr;
   const uint8_t* d_v = nullptr;
   const uint64_t* d_off = nullptr;
   uint8_t* d_plain = nullptr;
@@ -366,7 +373,7 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
   k.begin_timing();
   if (!k.failed) {
     if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, g2);
-    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st);
+    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm);
     else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
   }

@@ -170,6 +170,51 @@ TC_HD uint8_t job_lincomb(int n, const uint8_t* points, const uint32_t* scalars,
   return TC_JOB_OK;
 }
 
+// Classes of the common denominator D of the small-index fast path (below).  The last step of that
+// path is [1/D] Q, in general one full GLS multiplication; two classes are much cheaper, and the
+// combine kernels group jobs by class so that a wave takes ONE of the branches (k_combine.hip):
+//   D = 1            nothing to do
+//   D = 2^a, a <= 16 |x| = 2^16 * 0xd20100000001 and x^2 - x^4 = 1 (mod r), so on G2
+//                    [1/D] Q = [|x| / D] (psi^3(Q) - psi(Q)):  16 - a doublings, then the 48-bit ladder of
+//                    |x| >> 16 (Hamming weight 6): 62 doublings + 5 additions instead of 64 + 64 + a table
+constexpr int kCombineClassGeneric = 0, kCombineClassOne = 1, kCombineClassPow2 = 2, kCombineClasses = 3;
+TC_HD int combine_denominator_class(uint64_t d_abs) {
+  if (d_abs == 1) return kCombineClassOne;
+  if ((d_abs & (d_abs - 1)) == 0 && d_abs <= (1ull << 16)) return kCombineClassPow2;
+  return kCombineClassGeneric;
+}
+// [sign / d_abs] q
+TC_HD G1Jac combine_divide(const G1Jac& q, uint64_t d_abs, bool d_neg) {
+  uint32_t dinv[8];
+  fr_inverse_of_small(d_abs, d_neg, dinv);
+  return point_mul_scalar(q, dinv);
+}
+TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
+  const int cls = combine_denominator_class(d_abs);
+  G2Jac r = q;
+  if (wave_any(cls == kCombineClassGeneric)) {
+    uint32_t dinv[8];
+    fr_inverse_of_small(d_abs, false, dinv);
+    r = G2Jac::select(cls == kCombineClassGeneric, point_mul_scalar(q, dinv), r);
+  }
+  if (wave_any(cls == kCombineClassPow2)) {
+    const G2Jac p1 = g2_psi(q);
+    const G2Jac p3 = g2_psi(g2_psi(p1));
+    G2Jac base = jac_add(p3, jac_neg(p1));  // psi^3(Q) - psi(Q)
+    const int pre = 16 - (int)__builtin_ctzll(d_abs | (1ull << 16));  // 16 - a doublings first
+    TC_NOUNROLL for (int i = 0; i < 15; i++) base = G2Jac::select(i < pre, jac_dbl(base), base);
+    const uint64_t s = BLS_X_ABS >> 16;
+    G2Jac acc = base;
+    TC_NOUNROLL for (int bit = 46; bit >= 0; bit--) {  // bit 47 is the leading one
+      acc = jac_dbl(acc);
+      if ((s >> bit) & 1ull) acc = jac_add(acc, base);
+    }
+    r = G2Jac::select(cls == kCombineClassPow2, acc, r);
+  }
+  r.y = Fq2::select(d_neg, -r.y, r.y);
+  return r;
+}
+
 // combination through the small-index fast path (tc_threshold.h); false => not applicable
 template <class F, int K>
 TC_HD bool job_combine_small(const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* status) {
@@ -189,11 +234,20 @@ TC_HD bool job_combine_small(const uint64_t* idx, const uint8_t* shares, uint8_t
     return true;
   }
   Jac<F> a = straus_small<F, K>(pts, c_abs);
-  uint32_t dinv[8];
-  fr_inverse_of_small(d_abs, d_neg, dinv);
-  PointIO<F>::encode(jac_to_affine(point_mul_scalar(a, dinv)), out);
+  PointIO<F>::encode(jac_to_affine(combine_divide(a, d_abs, d_neg)), out);
   *status = TC_JOB_OK;
   return true;
+}
+
+// class of the job's denominator (kCombineClass*); generic when the fast path does not apply
+TC_HD int combine_job_class(const uint64_t* idx, int t) {
+  uint64_t c_abs[4], d_abs = 0;
+  bool c_neg[4], d_neg;
+  bool applies = false;
+  if (t == 1) applies = lagrange_small_coeffs<2>(idx, c_abs, c_neg, &d_abs, &d_neg);
+  if (t == 2) applies = lagrange_small_coeffs<3>(idx, c_abs, c_neg, &d_abs, &d_neg);
+  if (t == 3) applies = lagrange_small_coeffs<4>(idx, c_abs, c_neg, &d_abs, &d_neg);
+  return applies ? combine_denominator_class(d_abs) : kCombineClassGeneric;
 }
 
 // true when job_combine_small will handle the job (so the Lagrange kernel can skip it)

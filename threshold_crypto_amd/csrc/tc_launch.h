@@ -33,8 +33,10 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
                      uint8_t* status, bool g2);
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status);
+size_t combine_group_slots(size_t B);
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status);
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
+                       uint32_t* perm);
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status);
 void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
