@@ -36,10 +36,10 @@ MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient d
 EXECUTED_MACS = {"combine_g2_t3_fast": 1057343, "combine_g2_t3_general": 3921386, "g2_mul": 1273034, "g2_mul_4_scalars_per_point": 1172080,
                  "verify_g2": 6625332, "hash_g2": 3104745, "combine_g1_t3_fast": 629713}
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
-# profiles/r01_g_sac_karabina_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
+# profiles/r01_h_grouped_combine_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
 # (register-spill / window-table) traffic, several hundred times the algorithmic bytes.
-PROFILED_TRAFFIC_BYTES = {65536: int((2 * 4093037.1 + 5763549.0) * 1024)}
+PROFILED_TRAFFIC_BYTES = {65536: int((2 * 2692958.3 + 4148507.2) * 1024)}
 P_INT_TMACS = 27.2             # measured v_mad_u64_u32 issue rate, tools/ubench_valu (profiles/)
 HBM_PEAK_GBPS = 8000.0
 
@@ -198,7 +198,7 @@ def main():
             roofline = {"bound": "valu_int32_mac", "achieved": round(ach, 3), "peak": P_INT_TMACS, "unit": "TMAC/s",
                         "frac": round(ach / P_INT_TMACS, 4),
                         "traffic": PROFILED_TRAFFIC_BYTES.get(B) if world == 1 else None,
-                        "traffic_is": "bytes per launch, L2<->fabric (scratch spills), profiles/r01_g_sac_karabina_rocprofv3_summary.csv",
+                        "traffic_is": "bytes per launch, L2<->fabric (scratch spills), profiles/r01_h_grouped_combine_rocprofv3_summary.csv",
                         "achieved_is": "reference-algorithm work (31148 Fq-mul x 300 MAC per combine, SURVEY 8d) / kernel "
                                        "time; exceeds 1.0 because the kernel needs 4x fewer multiply-adds than the "
                                        "reference algorithm (SURVEY 8d: a smarter algorithm legitimately raises it); "
