@@ -33,7 +33,7 @@ MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient d
 # (tests/count_ops.py, tests/hostsim -DTC_COUNT_OPS).  Two lanes work on a G2 job; work inside Fq2
 # operations is split between them, Fq work outside (inversions, root exponentiations) is done
 # by both and counted twice.
-EXECUTED_MACS = {"combine_g2_t3_fast": 1057343, "combine_g2_t3_general": 3921386, "g2_mul": 1273034, "g2_mul_4_scalars_per_point": 1172080,
+EXECUTED_MACS = {"combine_g2_t3_fast": 1057343, "combine_g2_t3_fast_general_denominator": 1530396, "combine_g2_t3_general": 3921386, "g2_mul": 1273034, "g2_mul_4_scalars_per_point": 1172080,
                  "verify_g2": 6625332, "hash_g2": 2710967, "combine_g1_t3_fast": 629713}
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
 # profiles/r01_h_grouped_combine_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
@@ -204,6 +204,11 @@ def main():
                                        "reference algorithm (SURVEY 8d: a smarter algorithm legitimately raises it); "
                                        "executed_* is the kernel's own multiply-add count against the same peak",
                         "executed_TMACs": round(executed, 3), "executed_frac": round(executed / P_INT_TMACS, 4),
+                        "executed_is": "average job (1.06 M v_mad over the 4-of-10 subsets; denominators 1 and 2^a "
+                                       "divide cheaply); one round of 2048 waves lasts as long as its slowest class "
+                                       "(1.53 M v_mad per job), whose waves run at executed_frac_slowest_class",
+                        "executed_frac_slowest_class": round(EXECUTED_MACS["combine_g2_t3_fast_general_denominator"] * B
+                                                             / (avg_kernel_ms * 1e-3) / 1e12 / P_INT_TMACS, 4),
                         "kernel": "k_lagrange + k_combine<Fq2>", "kernel_ms": round(avg_kernel_ms, 3),
                         "algorithmic_bytes_per_launch": alg_bytes,
                         "hbm_achieved_GBps": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9, 3),
