@@ -258,6 +258,39 @@ def test_hash_and_kdf(L, rnd):
     assert out.raw == o.g2_compressed(Qp)
 
 
+def test_denominator_classes_of_the_fast_combine_path(L):
+    """tc_jobs.h combine_job_class: 0 general, 1 for D = 1, 2 for D = 2^a -- D the common denominator of the
+    Lagrange coefficients at 0 after the common factor of the numerators is removed (exact rationals here)."""
+    from fractions import Fraction
+    from itertools import combinations
+    from math import gcd, lcm
+    seen = {0: 0, 1: 0, 2: 0}
+    for t in (1, 2, 3):
+        for ids in combinations(range(10), t + 1):
+            xs = [i + 1 for i in ids]
+            lam = []
+            for i in xs:
+                num, den = 1, 1
+                for j in xs:
+                    if j != i:
+                        num, den = num * j, den * (j - i)
+                lam.append(Fraction(num, den))
+            D = 1
+            for l in lam:
+                D = lcm(D, l.denominator)
+            g = 0
+            for l in lam:
+                g = gcd(g, abs(int(l * D)))
+            D = abs(Fraction(D, g).numerator)
+            want = 1 if D == 1 else 2 if D & (D - 1) == 0 else 0
+            got = L.hs_combine_job_class((ctypes.c_uint64 * (t + 1))(*ids), t)
+            assert got == want, (ids, D, got)
+            seen[want] += 1
+    assert all(seen.values())
+    big = (ctypes.c_uint64 * 4)(1 << 40, (1 << 40) + 1, (1 << 40) + 2, (1 << 40) + 3)
+    assert L.hs_combine_job_class(big, 3) == 0   # outside the small-index path
+
+
 def test_hash_constant_folds_into_scalars_and_g1_operands(L, rnd):
     """tc_gls.h g2_clear_cofactor(fix=false): hash_g2(m) = [c] Q' with c = (3 (x^2 - 1))^-1 mod r; the composed
     entry points (sign, verify, ciphertext checks, encrypt) move c into a scalar or a G1 point."""
