@@ -33,8 +33,8 @@ MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient d
 # (tests/count_ops.py, tests/hostsim -DTC_COUNT_OPS).  Two lanes work on a G2 job; work inside Fq2
 # operations is split between them, Fq work outside (inversions, root exponentiations) is done
 # by both and counted twice.
-EXECUTED_MACS = {"combine_g2_t3_fast": 1057343, "combine_g2_t3_fast_general_denominator": 1530396, "combine_g2_t3_general": 3921386, "g2_mul": 1273034, "g2_mul_4_scalars_per_point": 1172080,
-                 "verify_g2": 6625332, "hash_g2": 2710967, "combine_g1_t3_fast": 629713}
+EXECUTED_MACS = {"combine_g2_t3_fast": 1052443, "combine_g2_t3_fast_general_denominator": 1530396, "combine_g2_t3_general": 3921386, "g2_mul": 1273034, "g2_mul_4_scalars_per_point": 1172080,
+                 "verify_g2": 6625332, "hash_g2": 2511439, "combine_g1_t3_fast": 629713}
 # L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
 # profiles/r01_h_grouped_combine_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch

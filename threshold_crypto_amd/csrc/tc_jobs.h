@@ -204,11 +204,13 @@ TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
     const int pre = 16 - (int)__builtin_ctzll(d_abs | (1ull << 16));  // 16 - a doublings first
     TC_NOUNROLL for (int i = 0; i < 15; i++) base = G2Jac::select(i < pre, jac_dbl(base), base);
     const uint64_t s = BLS_X_ABS >> 16;
-    G2Jac acc = base;
+    const G2Affine ba{base.x, base.y, base.is_inf()};  // affine on the curve scaled by base.z (tc_gls.h)
+    G2Jac acc = G2Jac::from_affine(ba);
     TC_NOUNROLL for (int bit = 46; bit >= 0; bit--) {  // bit 47 is the leading one
       acc = jac_dbl(acc);
-      if ((s >> bit) & 1ull) acc = jac_add(acc, base);
+      if ((s >> bit) & 1ull) acc = jac_add_mixed(acc, ba);
     }
+    acc.z = coord_norm(acc.z * base.z);
     r = G2Jac::select(cls == kCombineClassPow2, acc, r);
   }
   r.y = Fq2::select(d_neg, -r.y, r.y);
