@@ -39,7 +39,7 @@ EXECUTED_MACS = {"combine_g2_t3_fast": 1052443, "combine_g2_t3_fast_general_deno
 # profiles/r01_h_grouped_combine_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
 # MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
 # (register-spill / window-table) traffic, several hundred times the algorithmic bytes.
-PROFILED_TRAFFIC_BYTES = {65536: int((2 * 2696554.5 + 4149919.8) * 1024)}
+PROFILED_TRAFFIC_BYTES = {65536: int((2 * 2683116.9 + 4130343.4) * 1024)}
 P_INT_TMACS = 27.2             # measured v_mad_u64_u32 issue rate, tools/ubench_valu (profiles/)
 HBM_PEAK_GBPS = 8000.0
 
