@@ -1,0 +1,99 @@
+// Effective shader clock and per-instruction issue cost of the multiply-add forms on gfx950, so the
+// roofline peak in bench.py / DESIGN.md carries its clock (VERDICT r01 "peak re-measured with the clock
+// recorded").  s_memtime counts shader cycles, s_memrealtime a constant 100 MHz: their ratio over a
+// busy kernel is the clock the chip actually sustains under that instruction mix.
+//   build: hipcc --offload-arch=gfx950 -O3 tools/ubench_clock.hip -o tools/ubench_clock
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include <algorithm>
+
+#define ITERS 8192
+#define NACC 8
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t* ticks, uint32_t seed) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t acc[NACC];
+  int64_t sacc[NACC];
+  for (int i = 0; i < NACC; i++) {
+    acc[i] = (uint64_t)tid * 0x9e3779b97f4a7c15ull + i + seed;
+    sacc[i] = (int64_t)acc[i];
+  }
+  const uint32_t b = seed | 1u;
+  const int32_t sb = (int32_t)(seed | 1u);
+  const uint64_t t0 = __builtin_readcyclecounter();   // s_memtime
+  const uint64_t r0 = wall_clock64();                 // s_memrealtime (100 MHz)
+#pragma unroll 1
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int kx = 0; kx < NACC; kx++) {
+      if (OP == 0) acc[kx] = (uint64_t)(uint32_t)acc[(kx + 1) & (NACC - 1)] * b + acc[kx];        // v_mad_u64_u32
+      if (OP == 1) sacc[kx] = (int64_t)(int32_t)sacc[(kx + 1) & (NACC - 1)] * sb + sacc[kx];        // v_mad_i64_i32
+      if (OP == 2) acc[kx] = acc[kx] + (acc[(kx + 1) & (NACC - 1)] << 3);                          // v_lshl_add_u64
+      if (OP == 3) acc[kx] = (uint64_t)((int64_t)acc[kx] >> 28) + kx;                              // v_ashrrev_i64 (+add)
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  const uint64_t r1 = wall_clock64();
+  uint64_t s = 0;
+  for (int i = 0; i < NACC; i++) s += acc[i] + (uint64_t)sacc[i];
+  out[tid] = s;
+  if ((threadIdx.x & 63) == 0) {
+    const uint32_t w = tid >> 6;
+    ticks[2 * w] = t1 - t0;
+    ticks[2 * w + 1] = r1 - r0;
+  }
+}
+
+template <int OP>
+void run(const char* name, uint64_t* d_out, uint64_t* d_ticks, int blocks, int waves_per_simd) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int nw = blocks * 4;
+  std::vector<uint64_t> h(2 * nw);
+  float best = 1e30f;
+  for (int r = 0; r < 4; r++) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, 777u + r);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  hipMemcpy(h.data(), d_ticks, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> clk, cyc;
+  for (int w = 0; w < nw; w++) {
+    const double cycles = (double)h[2 * w], real = (double)h[2 * w + 1];
+    if (real > 0) clk.push_back(cycles / (real / 100e6) / 1e9);
+    cyc.push_back(cycles / ((double)ITERS * NACC));
+  }
+  std::sort(clk.begin(), clk.end());
+  std::sort(cyc.begin(), cyc.end());
+  const double ops = (double)blocks * 256 * ITERS * NACC;
+  printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"kernel_ms\": %.4f, \"lane_ops_per_s\": %.4e, \"effective_clock_GHz_median\": %.3f, "
+         "\"shader_cycles_per_instr_per_wave_median\": %.3f, \"cycles_per_instr_per_simd\": %.3f}\n",
+         name, waves_per_simd, best, ops / (best * 1e-3), clk[clk.size() / 2], cyc[cyc.size() / 2], cyc[cyc.size() / 2] / waves_per_simd);
+}
+
+int main() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fprintf(stderr, "no HIP device\n"); return 1; }
+  hipDeviceProp_t p;
+  hipGetDeviceProperties(&p, 0);
+  printf("{\"device\": \"%s\", \"cus\": %d, \"max_clock_mhz\": %d}\n", p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000);
+  const int cus = p.multiProcessorCount;
+  uint64_t *d_out, *d_ticks;
+  hipMalloc(&d_out, (size_t)cus * 8 * 256 * 8);
+  hipMalloc(&d_ticks, (size_t)cus * 8 * 4 * 16);
+  for (int wps : {1, 2, 8}) {
+    run<0>("v_mad_u64_u32", d_out, d_ticks, cus * wps, wps);
+    run<1>("v_mad_i64_i32", d_out, d_ticks, cus * wps, wps);
+  }
+  run<2>("v_lshl_add_u64", d_out, d_ticks, cus * 2, 2);
+  run<3>("v_ashrrev_i64+add", d_out, d_ticks, cus * 2, 2);
+  return 0;
+}
