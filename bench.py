@@ -1,47 +1,106 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--t T] [--signers N]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|5] [--batch B] [--t T] [--signers N]
 
-A "step" is one pass of the hot path over one batch: PublicKeySet::combine_signatures
-(src/lib.rs:608-615) for `batch` independent (message, share-set) jobs -- BASELINE config
-"t=3, N=10, batch=65 536 threshold signatures on 1xMI355X" -- through the C ABI
-(tc_combine_g2_batch) with every input already resident in HBM.  The same batch is then
-verified (PublicKey::verify_g2, src/lib.rs:108-110) and re-signed, and those rates are
-reported next to the headline value.  One process per GPU; for N > 1 the batch is per-rank
-(weak scaling), the key-set parameters are broadcast from rank 0 over RCCL and there is no
-data-path collective (jobs are independent).
+--config 2 (default; BASELINE "t=3, N=10, batch=65 536 threshold signatures on 1xMI355X"): a "step" is
+one pass of PublicKeySet::combine_signatures (src/lib.rs:608-615) over `batch` independent
+(message, share-set) jobs through the C ABI (tc_combine_g2_batch) with every input already resident in
+HBM.  The same batch is then verified (PublicKey::verify_g2, src/lib.rs:108-110; every 16th signature
+replaced by its neighbour's, so the expected ok-vector is known), re-signed, verified with hashing on the
+device, and run through the threshold-decryption path (BASELINE configs 3 and 4); each of those legs
+carries its own roofline object and ANY failing leg fails the run.
 
-Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline leg
-and to spot-check the GPU output of the timed batch bit-for-bit.
+--config 5 (BASELINE "t=67, N=200, batch=1 048 576 mixed sign+combine+verify sharded across 8 GPUs"):
+one step = sign the t+1 selected shares of every job ON the device, combine them, verify the result;
+131 072 jobs per GPU (weak scaling: --gpus 8 is the BASELINE batch), nothing larger than the key set
+crosses PCIe or xGMI.
+
+One process per GPU; for N > 1 the batch is per-rank (weak scaling), the key-set parameters are broadcast
+from rank 0 over RCCL and the per-rank valid counts are all-reduced; there is no data-path collective
+(jobs are independent).  Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the
+cpu_baseline leg and to check the GPU output of the timed batch bit-for-bit.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# frozen reference-algorithm work constants (Fq multiplications+squarings per unit), measured
-# with Oracle B's counter (oracle/c/tc_oracle.c or_fq_mul_count; see DESIGN.md "Work constants")
-W_FQMUL = {"combine_g2_t3": 31148, "g2_mul": 7771, "verify_g2": 41226, "hash_g2": 19604}
-MAC_PER_FQMUL = 300            # 12x12 product + 12x12 reduction + 12 quotient digits (CIOS)
-# what the kernels actually execute per unit, in v_mad (one 14x14 limb product or one Montgomery
-# reduction = 196): counted by running the same per-lane job bodies in the host build
-# (tests/count_ops.py, tests/hostsim -DTC_COUNT_OPS).  Two lanes work on a G2 job; work inside Fq2
-# operations is split between them, Fq work outside (inversions, root exponentiations) is done
-# by both and counted twice.
-EXECUTED_MACS = {"combine_g2_t3_fast": 1052443, "combine_g2_t3_fast_general_denominator": 1530396, "combine_g2_t3_general": 3921386, "g2_mul": 1273034, "g2_mul_4_scalars_per_point": 1172080,
-                 "verify_g2": 6625332, "hash_g2": 2511439, "combine_g1_t3_fast": 629713}
-# L2<->fabric traffic of one k_combine<Fq2> launch at batch 65 536 from the PMC passes committed as
-# profiles/r01_h_grouped_combine_rocprofv3_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the gfx950 note of
-# MI355X_MICROARCH.md.  Recorded, not measured live (PMC collection needs rocprofv3).  It is scratch
-# (register-spill / window-table) traffic, several hundred times the algorithmic bytes.
-PROFILED_TRAFFIC_BYTES = {65536: int((2 * 2683116.9 + 4130343.4) * 1024)}
-P_INT_TMACS = 27.2             # measured v_mad_u64_u32 issue rate, tools/ubench_valu (profiles/)
+# frozen reference-algorithm work constants (Fq multiplications+squarings per unit), measured with
+# Oracle B's counter (oracle/c/tc_oracle.c or_fq_mul_count; DESIGN.md "Work constants"); 1 Fq-mul = 300
+# 32-bit multiply-adds (12x12 product + 12x12 reduction + 12 quotient digits, CIOS: SURVEY 8d)
+W_FQMUL = {"combine_g2_t3": 31148, "g2_mul": 7771, "verify_g2": 41226, "hash_g2": 19604, "combine_g1_t3": 12800,
+           "combine_g2_t67": 530000}
+MAC_PER_FQMUL = 300
+# what the kernels execute per unit, in v_mad_i64_i32 lane-instructions (one 14x14 limb product or one
+# Montgomery reduction = 196): counted by running the same per-lane job bodies in the host build
+# (tests/count_ops.py).  Two lanes work on a G2 job; work inside Fq2 operations is split between them, Fq
+# work outside (inversions, root exponentiations) is done by both and counted twice.
+EXECUTED_MACS = json.load(open(os.path.join(ROOT, "profiles", "executed_macs.json")))
+# algorithmic bytes per unit (canonical uncompressed affine I/O)
+ALG_BYTES = {"combine_g2": lambda t: (t + 1) * (192 + 8) + 192, "verify_g2": lambda t: 385, "g2_mul": lambda t: 192,
+             "hash_g2": lambda t: 207, "combine_g1": lambda t: (t + 1) * (96 + 8) + 96 + 32}
+# Roofline peak: the issue rate of the multiplier's own instruction (v_mad_i64_i32) with every SIMD full,
+# measured LIVE by tools/ubench_clock --peak when that binary is present (sustained ~25 ms launches, clock
+# read from s_memtime / s_memrealtime); otherwise the value recorded in profiles/r02_ubench_clock.txt.
+PEAK_RECORDED = {"tmacs": 29.37, "clock_ghz": 2.10, "source": "profiles/r02_ubench_clock.txt (v_mad_i64_i32, 8 waves/SIMD)"}
 HBM_PEAK_GBPS = 8000.0
+# L2<->fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes, FETCH doubled per the
+# gfx950 note of MI355X_MICROARCH.md) and SQ_INSTS_VALU per launch at batch 65 536, from the profile named
+PROFILE = json.load(open(os.path.join(ROOT, "profiles", "profile_constants.json")))
+
+
+def measure_peak():
+    exe = os.path.join(ROOT, "tools", "ubench_clock")
+    try:
+        out = subprocess.run([exe, "--peak"], capture_output=True, text=True, timeout=120).stdout
+        for line in out.splitlines():
+            d = json.loads(line)
+            if d.get("op") == "v_mad_i64_i32" and d.get("waves_per_simd") == 8:
+                return {"tmacs": round(d["lane_ops_per_s"] / 1e12, 3), "clock_ghz": d["effective_clock_GHz_median"],
+                        "source": "measured live: tools/ubench_clock --peak (v_mad_i64_i32, 8 waves/SIMD, %.1f ms launch)"
+                                  % d["kernel_ms"]}
+    except Exception:
+        pass
+    return dict(PEAK_RECORDED)
+
+
+def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traffic_key=None, extra=None):
+    """frac = the kernel's OWN multiply-add count / time / peak (utilisation of the integer multiplier);
+    algorithmic_speedup = reference-algorithm work / executed work (what the smarter algorithm buys)."""
+    sec = kernel_ms * 1e-3
+    executed = EXECUTED_MACS[unit_key] * units
+    ref = W_FQMUL[ref_key] * MAC_PER_FQMUL * units if ref_key else None
+    ach = executed / sec / 1e12
+    alg_bytes = ALG_BYTES[alg_key](t) * units
+    prof = PROFILE.get(traffic_key or "", {})
+    r = {"bound": "valu_int32_mac", "kernel": kernel, "kernel_ms": round(kernel_ms, 3), "units_per_launch": units,
+         "achieved": round(ach, 3), "peak": peak["tmacs"], "unit": "TMAC/s", "frac": round(ach / peak["tmacs"], 4),
+         "peak_clock_GHz": peak["clock_ghz"], "peak_source": peak["source"],
+         "executed_macs_per_unit": EXECUTED_MACS[unit_key],
+         "achieved_is": "v_mad the kernel executes per unit (tests/count_ops.py) x units / HIP-event kernel time",
+         "algorithmic_bytes_per_launch": alg_bytes,
+         "hbm_achieved_GBps": round(alg_bytes / sec / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBPS,
+         "hbm_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, 6),
+         "traffic": prof.get("traffic_bytes") if units == prof.get("units") else None,
+         "traffic_is": ("L2<->fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), %s" % prof.get("source")) if prof else None}
+    if ref:
+        r["reference_work_TMACs"] = round(ref / sec / 1e12, 3)
+        r["algorithmic_speedup"] = round(ref / executed, 3)
+    if prof.get("sq_insts_valu") and units == prof.get("units"):
+        lane_instr = prof["sq_insts_valu"] * 64
+        r["executed_cross_check"] = {"sq_insts_valu_wave_instr_per_launch": prof["sq_insts_valu"],
+                                     "executed_v_mad_lane_instr_per_launch": executed,
+                                     "implied_v_mad_share_of_valu": round(executed / lane_instr, 3),
+                                     "static_v_mad_share_of_the_multiplier_bodies": PROFILE.get("static_mad_share")}
+    if extra:
+        r.update(extra)
+    return r
 
 
 def main():
@@ -49,12 +108,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=65536)
-    ap.add_argument("--t", type=int, default=3)
-    ap.add_argument("--signers", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--t", type=int, default=None)
+    ap.add_argument("--signers", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (hashing verify, threshold decryption)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (configs 3 and 4, PCIe-inclusive rate)")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,11 +131,33 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from threshold_crypto_amd.engine import Engine
-    from threshold_crypto_amd.workload import ThresholdSigWorkload
-    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range
-
     eng = Engine(local_rank)
-    t, N, B = args.t, args.signers, args.batch
+    peak = measure_peak() if rank == 0 else dict(PEAK_RECORDED)
+    if args.config == 5:
+        from threshold_crypto_amd import config5
+        result = config5.run_bench(args, eng, dev, rank, world, peak, roofline)
+    else:
+        result = run_config2(args, eng, dev, rank, world, peak)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def run_config2(args, eng, dev, rank, world, peak):
+    import numpy as np
+    import torch
+    from threshold_crypto_amd.workload import ThresholdSigWorkload, ThresholdEncWorkload
+    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range, total_count
+    if world > 1:
+        import torch.distributed as dist
+
+    t = 3 if args.t is None else args.t
+    N = 10 if args.signers is None else args.signers
+    B = 65536 if args.batch is None else args.batch
     start, _ = shard_range(B * world, world, rank)      # weak scaling: B jobs per rank
     wl = ThresholdSigWorkload(eng, t, N, B, start=start)
 
@@ -95,10 +177,6 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
-
-    def local_sync():   # secondary legs: no collective, so a rank-local failure cannot hang the job
-        eng.sync()
-        torch.cuda.synchronize()
 
     eng.set_timing(True)
     # ---- headline: combine_signatures ----------------------------------------------------
@@ -120,16 +198,23 @@ def main():
     value = B * world / (dt / args.steps)
     assert int(st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
 
-    # ---- secondary: verify the combined signatures, re-sign ---------------------------------
-    ok = eng.verify_g2(master_pk, sig, d_hashes)
+    # ---- config 3: verify the combined signatures; every 16th one replaced by its neighbour's ------------
+    bad = sig.clone()
+    expect_ok = torch.ones(B, dtype=torch.uint8, device=dev)
+    if B >= 2:
+        planted = torch.arange(0, B, 16, device=dev)
+        bad[planted] = sig[(planted + 1) % B]
+        expect_ok[planted] = 0
+    ok = eng.verify_g2(master_pk, bad, d_hashes)
     sync()
     v0 = time.perf_counter()
-    ok = eng.verify_g2(master_pk, sig, d_hashes)
+    ok = eng.verify_g2(master_pk, bad, d_hashes)
     verify_kernel_ms = eng.last_kernel_ms()
     sync()
     verify_dt = time.perf_counter() - v0
-    n_ok = int(ok.to(torch.int32).sum().item())
-    assert n_ok == B, "combined signatures failed verification under the master key: %d/%d" % (n_ok, B)
+    assert bool((ok == expect_ok).all().item()), "verify_g2 ok-vector differs from the planted corruption pattern"
+    n_valid = total_count(int(ok.to(torch.int64).sum().item()), world, dev)   # per-rank valid counts, summed over RCCL
+    assert n_valid == int(expect_ok.sum().item()) * world
     s0 = time.perf_counter()
     _sh, _st = eng.g2_mul(d_sk, d_hashes)
     sign_kernel_ms = eng.last_kernel_ms()
@@ -140,128 +225,125 @@ def main():
     sync()
     assert bool((msig[:, 0] == sig).all().item()), "combine != master-key signature"
 
-    # ---- secondary legs: verify incl. hashing (config 3 with hash on device), config 4 ------------
-    extras = {}
+    extras, legs = {}, {}
     if not args.no_extras:
-        try:
-            d_msgs = torch.from_numpy(wl.msg_flat).to(dev)
-            d_off = torch.from_numpy(wl.msg_off.view(np.int64)).to(dev)
-            ok = eng.verify_sig(master_pk, sig, d_msgs, d_off)
-            local_sync()
-            e0 = time.perf_counter()
-            ok = eng.verify_sig(master_pk, sig, d_msgs, d_off)
-            local_sync()
-            extras["verifies_with_hash_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
-            assert int(ok.to(torch.int32).sum().item()) == B
-            e0 = time.perf_counter()
-            hh = eng.hash_g2(d_msgs, d_off)
-            extras["hash_g2_kernel_ms"] = round(eng.last_kernel_ms(), 3)
-            local_sync()
-            extras["hash_g2_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
-            assert bool((hh == d_hashes).all().item())
-            from threshold_crypto_amd.workload import ThresholdEncWorkload
-            we = ThresholdEncWorkload(eng, t, N, B, start=start)
-            du, dv, dw = torch.from_numpy(we.u).to(dev), torch.from_numpy(we.v).to(dev), torch.from_numpy(we.w).to(dev)
-            doff = torch.from_numpy(we.off.view(np.int64)).to(dev)
-            didx, dsh = torch.from_numpy(we.idx.view(np.int64)).to(dev), torch.from_numpy(we.shares).to(dev)
-            okc = eng.ciphertext_verify(du, dv, doff, dw)
-            out, dst = eng.decrypt(t, didx, dsh, dv, doff)
-            local_sync()
-            e0 = time.perf_counter()
-            okc = eng.ciphertext_verify(du, dv, doff, dw)
-            extras["ciphertext_verify_kernel_ms"] = round(eng.last_kernel_ms(), 3)
-            local_sync()
-            e1 = time.perf_counter()
-            out, dst = eng.decrypt(t, didx, dsh, dv, doff)
-            extras["threshold_decrypt_kernel_ms"] = round(eng.last_kernel_ms(), 3)
-            local_sync()
-            e2 = time.perf_counter()
-            extras["ciphertext_verifies_per_s"] = round(B * world / (e1 - e0), 1)
-            extras["threshold_decrypts_per_s"] = round(B * world / (e2 - e1), 1)
-            extras["threshold_decryptions_incl_ciphertext_verify_per_s"] = round(B * world / (e2 - e0), 1)
-            assert int(okc.to(torch.int32).sum().item()) == B and int(dst.to(torch.int32).sum().item()) == 0
-            assert bytes(out.cpu().numpy()[: 32 * 64]) == b"".join(we.plain[:64]), "threshold decryption returned wrong plaintext"
-            assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item())
-        except Exception as exc:  # a failing secondary leg must not hide the headline measurement
-            extras["error"] = "%s: %s" % (type(exc).__name__, exc)
-            local_sync()
+        # ---- verify incl. hashing on the device, hash_g2 alone --------------------------------------------
+        d_msgs = torch.from_numpy(wl.msg_flat).to(dev)
+        d_off = torch.from_numpy(wl.msg_off.view(np.int64)).to(dev)
+        ok2 = eng.verify_sig(master_pk, bad, d_msgs, d_off)
+        sync()
+        e0 = time.perf_counter()
+        ok2 = eng.verify_sig(master_pk, bad, d_msgs, d_off)
+        sync()
+        extras["verifies_with_hash_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
+        assert bool((ok2 == expect_ok).all().item()), "verify (hash on device) ok-vector differs from the pattern"
+        e0 = time.perf_counter()
+        hh = eng.hash_g2(d_msgs, d_off)
+        hash_kernel_ms = eng.last_kernel_ms()
+        sync()
+        extras["hash_g2_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
+        assert bool((hh == d_hashes).all().item())
+        legs["hash_g2"] = roofline("k_hash_g2", "hash_g2", "hash_g2", "hash_g2", t, B, hash_kernel_ms, peak)
+        # ---- config 4: threshold decryption = Ciphertext::verify + G1 combine + keystream -------------------
+        we = ThresholdEncWorkload(eng, t, N, B, start=start)
+        du, dv, dw = torch.from_numpy(we.u).to(dev), torch.from_numpy(we.v).to(dev), torch.from_numpy(we.w).to(dev)
+        doff = torch.from_numpy(we.off.view(np.int64)).to(dev)
+        didx, dsh = torch.from_numpy(we.idx.view(np.int64)).to(dev), torch.from_numpy(we.shares).to(dev)
+        okc = eng.ciphertext_verify(du, dv, doff, dw)
+        out, dst = eng.decrypt(t, didx, dsh, dv, doff)
+        sync()
+        e0 = time.perf_counter()
+        okc = eng.ciphertext_verify(du, dv, doff, dw)
+        extras["ciphertext_verify_kernel_ms"] = round(eng.last_kernel_ms(), 3)
+        sync()
+        e1 = time.perf_counter()
+        out, dst = eng.decrypt(t, didx, dsh, dv, doff)
+        dec_kernel_ms = eng.last_kernel_ms()
+        sync()
+        e2 = time.perf_counter()
+        extras["ciphertext_verifies_per_s"] = round(B * world / (e1 - e0), 1)
+        extras["threshold_decrypts_per_s"] = round(B * world / (e2 - e1), 1)
+        extras["threshold_decryptions_incl_ciphertext_verify_per_s"] = round(B * world / (e2 - e0), 1)
+        assert int(okc.to(torch.int32).sum().item()) == B and int(dst.to(torch.int32).sum().item()) == 0
+        assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item()), "threshold decryption returned wrong plaintext"
+        legs["threshold_decrypt"] = roofline("k_combine_fast<Fq> + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
+                                             "combine_g1", t, B, dec_kernel_ms, peak)
+        # ---- the same combine with HOST buffers at the C ABI (pageable numpy memory): PCIe-inclusive ---------
+        eng.combine_g2(t, wl.idx, wl.shares)
+        best = 1e9
+        for _ in range(2):
+            p0 = time.perf_counter()
+            hsig, hst = eng.combine_g2(t, wl.idx, wl.shares)
+            best = min(best, time.perf_counter() - p0)
+        assert not hst.any() and bool((torch.from_numpy(hsig).to(dev) == sig).all().item())
+        extras["pcie_inclusive_combine_per_s"] = round(B / best, 1)
+        extras["pcie_inclusive_is"] = "tc_combine_g2_batch with host pointers: H2D of %d B + kernels + D2H of %d B, wall clock, one GPU" % (
+            wl.idx.nbytes + wl.shares.nbytes, hsig.nbytes + hst.nbytes)
 
-    result = None
-    if rank == 0:
-        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-        per_launch_mac = W_FQMUL["combine_g2_t3"] * MAC_PER_FQMUL * B if t == 3 else None
-        roofline = None
-        if per_launch_mac:
-            ach = per_launch_mac / (avg_kernel_ms * 1e-3) / 1e12
-            alg_bytes = ((t + 1) * (192 + 8) + 192) * B
-            executed = EXECUTED_MACS["combine_g2_t3_fast"] * B / (avg_kernel_ms * 1e-3) / 1e12
-            roofline = {"bound": "valu_int32_mac", "achieved": round(ach, 3), "peak": P_INT_TMACS, "unit": "TMAC/s",
-                        "frac": round(ach / P_INT_TMACS, 4),
-                        "traffic": PROFILED_TRAFFIC_BYTES.get(B) if world == 1 else None,
-                        "traffic_is": "bytes per launch, L2<->fabric (scratch spills), profiles/r01_h_grouped_combine_rocprofv3_summary.csv",
-                        "achieved_is": "reference-algorithm work (31148 Fq-mul x 300 MAC per combine, SURVEY 8d) / kernel "
-                                       "time; exceeds 1.0 because the kernel needs 4x fewer multiply-adds than the "
-                                       "reference algorithm (SURVEY 8d: a smarter algorithm legitimately raises it); "
-                                       "executed_* is the kernel's own multiply-add count against the same peak",
-                        "executed_TMACs": round(executed, 3), "executed_frac": round(executed / P_INT_TMACS, 4),
-                        "executed_is": "average job (1.06 M v_mad over the 4-of-10 subsets; denominators 1 and 2^a "
-                                       "divide cheaply); one round of 2048 waves lasts as long as its slowest class "
-                                       "(1.53 M v_mad per job), whose waves run at executed_frac_slowest_class",
-                        "executed_frac_slowest_class": round(EXECUTED_MACS["combine_g2_t3_fast_general_denominator"] * B
-                                                             / (avg_kernel_ms * 1e-3) / 1e12 / P_INT_TMACS, 4),
-                        "kernel": "k_lagrange + k_combine<Fq2>", "kernel_ms": round(avg_kernel_ms, 3),
-                        "algorithmic_bytes_per_launch": alg_bytes,
-                        "hbm_achieved_GBps": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9, 3),
-                        "hbm_peak_GBps": HBM_PEAK_GBPS,
-                        "hbm_frac": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
-                        "note": "integer-VALU bound (SURVEY 8d): ~1e4 MAC per byte; HBM shown to prove it is not the bound"}
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
-        result = {
-            "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 limbs (Fq = 14 x 28-bit signed, Montgomery R=2^392; 64-bit column accumulators; one Fq2 coefficient per lane of a lane pair)",
-            "data": "synthetic",
-            "config": {"workload": "t=%d,N=%d,batch=%d threshold signatures (combine_signatures, G2), per GPU" % (t, N, B),
-                       "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world},
-            "pairing_verifies_per_s": round(B * world / verify_dt, 1),
-            "pairing_verify_kernel_ms": round(verify_kernel_ms, 3),
-            "share_signs_per_s": round((t + 1) * B * world / sign_dt, 1),
-            "share_sign_kernel_ms": round(sign_kernel_ms, 3),
-            "verified_all": True,
-            "extras": extras,
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    return result
+    if rank != 0:
+        return None
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    fast = 1 <= t <= 3
+    unit_key = "combine_g2_t3_fast" if t == 3 else None
+    head = None
+    if unit_key:
+        head = roofline("k_lagrange + 3 grouping kernels + k_combine_fast<Fq2> + k_combine_general<Fq2>", unit_key, "combine_g2_t3",
+                        "combine_g2", t, B, avg_kernel_ms, peak, traffic_key="combine_g2_t3",
+                        extra={"frac_slowest_class": round(EXECUTED_MACS["combine_g2_t3_fast_general_denominator"] * B
+                                                           / (avg_kernel_ms * 1e-3) / 1e12 / peak["tmacs"], 4),
+                               "frac_is": "average job over the 4-of-10 subsets; the 65 536-job batch is ONE resident round "
+                                          "of 2048 waves and lasts as long as its slowest denominator class, whose waves run "
+                                          "at frac_slowest_class (DESIGN.md 5.2)"})
+    legs["pairing_check"] = roofline("k_pairing_check", "verify_g2", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
+                                     traffic_key="pairing_check")
+    legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak)
+    cpu = None if args.no_cpu_baseline else cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
+    return {
+        "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32 limbs (Fq = 14 x 28-bit signed, Montgomery R=2^392; 64-bit column accumulators; one Fq2 coefficient per lane of a lane pair)",
+        "data": "synthetic",
+        "config": {"workload": "t=%d,N=%d,batch=%d threshold signatures (combine_signatures, G2), per GPU" % (t, N, B),
+                   "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world,
+                   "fast_path": fast},
+        "pairing_verifies_per_s": round(B * world / verify_dt, 1),
+        "pairing_verify_kernel_ms": round(verify_kernel_ms, 3),
+        "pairing_verify_valid_count_all_ranks": n_valid,
+        "share_signs_per_s": round((t + 1) * B * world / sign_dt, 1),
+        "share_sign_kernel_ms": round(sign_kernel_ms, 3),
+        "verified_all": True,
+        "extras": extras,
+        "roofline": head,
+        "secondary_rooflines": legs,
+        "cpu_baseline": cpu,
+    }
 
 
 def cpu_baseline(wl, gpu_sigs, t, seconds):
-    """Oracle B (plain-C port of the reference algorithm, pthreads over the host cores) on a
-    bounded sample of the SAME jobs; also the bit-exact spot check of the GPU output."""
-    import numpy as np
+    """Oracle B (plain-C port of the reference algorithm, pthreads over the host cores) on a bounded sample
+    of the SAME jobs; also the bit-exact check of the GPU output on that sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     c_oracle.load()
-    cores = os.cpu_count() or 1
+    threads = c_oracle.host_threads()
+    n1 = 8
     t0 = time.perf_counter()
-    c_oracle.combine_g2_batch(t, wl.idx[:1], wl.shares[:1], 1)
-    per = max(time.perf_counter() - t0, 1e-4)
-    n = int(max(cores, min(wl.B, seconds * cores / per)))
+    out1, rc1 = c_oracle.combine_g2_batch(t, wl.idx[:n1], wl.shares[:n1], 1)
+    per = max((time.perf_counter() - t0) / n1, 1e-5)
+    n = int(max(threads, min(wl.B, seconds / per * min(threads, 24))))   # ~seconds of wall clock if ~24 cores are real
     t0 = time.perf_counter()
-    out, rc = c_oracle.combine_g2_batch(t, wl.idx[:n], wl.shares[:n], cores)
+    out, rc = c_oracle.combine_g2_batch(t, wl.idx[:n], wl.shares[:n], threads)
     dt = time.perf_counter() - t0
     mism = int(rc.any()) + int((out != gpu_sigs[:n]).any(axis=1).sum())
     if mism:
         raise AssertionError("GPU combine differs from the CPU oracle on %d of %d sampled jobs" % (mism, n))
-    return {"value": round(n / dt, 2), "unit": "combine_signatures/s", "cores": cores, "kind": "port",
+    return {"value": round(n / dt, 2), "unit": "combine_signatures/s", "cores": threads, "kind": "port",
+            "cores_is": "threads started = len(sched_getaffinity) capped by the cgroup CPU quota (os.cpu_count() = %d)" % (os.cpu_count() or 0),
+            "thread_scaling": round((n / dt) * per, 2),
+            "thread_scaling_is": "all-thread rate / single-thread rate: the number of cores the lease really delivers",
             "sample": "first %d jobs of the timed batch on %d pthreads (oracle/c/tc_oracle.c, gcc -O3 x86-64-v3); "
-                      "every sampled job compared bit-exact with the GPU output" % (n, cores),
+                      "every sampled job compared bit-exact with the GPU output" % (n, threads),
             "single_thread_per_s": round(1.0 / per, 2)}
 
 

@@ -1458,8 +1458,8 @@ EXPORT int or_g2_compress(const uint8_t *in192, uint8_t *out96) {
 /* ---- multi-threaded batch drivers for the timed CPU baseline (bench.py cpu_baseline) ---------- */
 #include <pthread.h>
 typedef struct {
-  int kind; /* 0 = combine_g2, 1 = verify_g2 */
-  size_t t, n, lo, hi;
+  int kind; /* 0 = combine_g2, 1 = verify_g2, 2 = ciphertext_verify, 3 = threshold_decrypt (fixed-length v) */
+  size_t t, n, lo, hi, len;
   const u64 *idx;
   const uint8_t *a, *b, *c;
   uint8_t *out;
@@ -1470,8 +1470,13 @@ static void *batch_worker(void *arg) {
   for (size_t k = j->lo; k < j->hi; k++) {
     if (j->kind == 0)
       j->rc[k] = or_combine_g2(j->t, j->n, j->idx + k * j->n, j->a + k * j->n * 192, j->out + k * 192);
-    else
+    else if (j->kind == 1)
       j->rc[k] = or_verify_g2(j->a, j->b + k * 192, j->c + k * 192);
+    else if (j->kind == 2)
+      j->rc[k] = or_ciphertext_verify(j->a + k * 96, j->b + k * j->len, j->len, j->c + k * 192);
+    else
+      j->rc[k] = or_threshold_decrypt(j->t, j->n, j->idx + k * j->n, j->a + k * j->n * 96, j->b + k * j->len, j->len,
+                                      j->out + k * j->len);
   }
   return NULL;
 }
@@ -1493,12 +1498,24 @@ static void run_batch(batch_job proto, size_t B, int nthreads) {
 /* B combine_signatures jobs (n samples each), nthreads host threads; rc[k] per job */
 EXPORT void or_combine_g2_batch(size_t t, size_t n, const u64 *idx, const uint8_t *shares, size_t B, uint8_t *out, int *rc,
                                 int nthreads) {
-  batch_job p = {0, t, n, 0, 0, idx, shares, NULL, NULL, out, rc};
+  batch_job p = {0, t, n, 0, 0, 0, idx, shares, NULL, NULL, out, rc};
   run_batch(p, B, nthreads);
 }
 /* B verify_g2 checks under one public key; rc[k] = 1 if valid */
 EXPORT void or_verify_g2_batch(const uint8_t *pk, const uint8_t *sigs, const uint8_t *hashes, size_t B, int *rc, int nthreads) {
-  batch_job p = {1, 0, 0, 0, 0, NULL, pk, sigs, hashes, NULL, rc};
+  batch_job p = {1, 0, 0, 0, 0, 0, NULL, pk, sigs, hashes, NULL, rc};
+  run_batch(p, B, nthreads);
+}
+/* B Ciphertext::verify checks (src/lib.rs:508-512), every v of the same length len; rc[k] = 1 if valid */
+EXPORT void or_ciphertext_verify_batch(const uint8_t *u, const uint8_t *v, size_t len, const uint8_t *w, size_t B, int *rc,
+                                       int nthreads) {
+  batch_job p = {2, 0, 0, 0, 0, len, NULL, u, v, w, NULL, rc};
+  run_batch(p, B, nthreads);
+}
+/* B PublicKeySet::decrypt jobs (src/lib.rs:618-626): n decryption shares each, every v of length len */
+EXPORT void or_threshold_decrypt_batch(size_t t, size_t n, const u64 *idx, const uint8_t *shares, const uint8_t *v,
+                                       size_t len, size_t B, uint8_t *out, int *rc, int nthreads) {
+  batch_job p = {3, t, n, 0, 0, len, idx, shares, v, NULL, out, rc};
   run_batch(p, B, nthreads);
 }
 

@@ -53,6 +53,10 @@ def load():
         _lib.or_combine_g2_batch.restype = None
         _lib.or_verify_g2_batch.argtypes = [cp, vp, vp, sz, vp, ctypes.c_int]
         _lib.or_verify_g2_batch.restype = None
+        _lib.or_ciphertext_verify_batch.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_int]
+        _lib.or_ciphertext_verify_batch.restype = None
+        _lib.or_threshold_decrypt_batch.argtypes = [sz, sz, vp, vp, vp, sz, sz, vp, vp, ctypes.c_int]
+        _lib.or_threshold_decrypt_batch.restype = None
     return _lib
 
 
@@ -189,6 +193,42 @@ def verify_g2_batch(pk, sigs, hashes, nthreads):
     hashes = np.ascontiguousarray(hashes)
     load().or_verify_g2_batch(bytes(pk), sigs.ctypes.data, hashes.ctypes.data, B, rc.ctypes.data, nthreads)
     return rc
+
+
+def ciphertext_verify_batch(u, v, length, w, nthreads):
+    """u (B,96), v (B*length,) uint8, w (B,192) -> rc (B,) int32 (1 = valid)"""
+    import numpy as np
+    B = u.shape[0]
+    rc = np.zeros(B, dtype=np.int32)
+    u, v, w = np.ascontiguousarray(u), np.ascontiguousarray(v), np.ascontiguousarray(w)
+    load().or_ciphertext_verify_batch(u.ctypes.data, v.ctypes.data, length, w.ctypes.data, B, rc.ctypes.data, nthreads)
+    return rc
+
+
+def threshold_decrypt_batch(t, idx, shares, v, length, nthreads):
+    """idx (B,n) uint64, shares (B,n,96), v (B*length,) -> (plain (B*length,) uint8, rc (B,) int32)"""
+    import numpy as np
+    B, n = idx.shape
+    out = np.zeros(B * length, dtype=np.uint8)
+    rc = np.zeros(B, dtype=np.int32)
+    idx, shares, v = np.ascontiguousarray(idx), np.ascontiguousarray(shares), np.ascontiguousarray(v)
+    load().or_threshold_decrypt_batch(t, n, idx.ctypes.data, shares.ctypes.data, v.ctypes.data, length, B, out.ctypes.data,
+                                      rc.ctypes.data, nthreads)
+    return out, rc
+
+
+def host_threads():
+    """threads the batch drivers can really use: the CPU affinity mask capped by the cgroup quota"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def g1_decompress(b):

@@ -45,7 +45,7 @@ cnt()
 L.hs_g2_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g2_uncompressed(P2), buf(192)); res["g2_mul"] = (cnt(), 2)
 L.hs_g1_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g1_uncompressed(P1), buf(96)); res["g1_mul"] = (cnt(), 1)
 L.hs_g2_mul_shared(b"".join(o.fr_to_bytes(rnd.randrange(o.R)) for _ in range(4)), 4, o.g2_uncompressed(P2), buf(768), buf(4))
-res["g2_mul_x4_one_point"] = (tuple(x // 4 for x in cnt()), 2)
+res["g2_mul_4_scalars_per_point"] = (tuple(x // 4 for x in cnt()), 2)
 poly = [rnd.randrange(o.R) for _ in range(4)]
 shares_g2 = {i: o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in range(10)}
 shares_g1 = {i: o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in range(10)}
@@ -68,23 +68,81 @@ def avg_combine(g2, general, n=48):
     return tuple(x // n for x in tot)
 
 
+def _denominator(ids):
+    """the common denominator D of the small-index fast path (tc_threshold.h lagrange_small_coeffs)"""
+    from math import gcd
+    xs = [i + 1 for i in ids]
+    den = []
+    for i in range(len(xs)):
+        d = 1
+        for j in range(len(xs)):
+            if j != i:
+                d *= xs[j] - xs[i]
+        den.append(abs(d))
+    D = 1
+    for d in den:
+        D = D * d // gcd(D, d)
+    g = D
+    for i, d in enumerate(den):
+        c = D // d
+        for j in range(len(xs)):
+            if j != i:
+                c *= xs[j]
+        g = gcd(g, c)
+    return D // g
+
+
+def class_combine(pred, n=24):
+    """average over random 4-subsets whose denominator satisfies pred"""
+    tot, done = [0] * 5, 0
+    while done < n:
+        ids = sorted(rnd.sample(range(10), 4))
+        if not pred(_denominator(ids)):
+            continue
+        idx = (ctypes.c_uint64 * 4)(*ids)
+        L.hs_combine_g2(3, idx, b"".join(shares_g2[i] for i in ids), buf(192))
+        tot = [x + y for x, y in zip(tot, cnt())]
+        done += 1
+    return tuple(x // n for x in tot)
+
+
+def all_subsets_combine():
+    """exact average over all C(10, 4) signer subsets (the workload draws them uniformly)"""
+    import itertools
+    tot, n = [0] * 5, 0
+    for ids in itertools.combinations(range(10), 4):
+        idx = (ctypes.c_uint64 * 4)(*ids)
+        L.hs_combine_g2(3, idx, b"".join(shares_g2[i] for i in ids), buf(192))
+        tot = [x + y for x, y in zip(tot, cnt())]
+        n += 1
+    return tuple(x // n for x in tot)
+
+
 cnt()
-res["combine_g2_t3_fast"] = (avg_combine(True, False), 2)
+res["combine_g2_t3_fast"] = (all_subsets_combine(), 2)
+_pow2 = lambda d: d & (d - 1) == 0
+res["combine_g2_t3_fast_general_denominator"] = (class_combine(lambda d: not _pow2(d)), 2)
+res["combine_g2_t3_fast_denominator_1"] = (class_combine(lambda d: d == 1, 8), 2)
+res["combine_g2_t3_fast_denominator_pow2"] = (class_combine(lambda d: d > 1 and _pow2(d), 8), 2)
 res["combine_g2_t3_general"] = (avg_combine(True, True, 8), 2)
 res["combine_g1_t3_fast"] = (avg_combine(False, False), 1)
 res["combine_g1_t3_general"] = (avg_combine(False, True, 8), 1)
 a = rnd.randrange(o.R)
 L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
-                   o.g2_uncompressed(o.E2.mul(P2, a))); res["pairing_check"] = (cnt(), 2)
+                   o.g2_uncompressed(o.E2.mul(P2, a))); res["verify_g2"] = (cnt(), 2)
 tot = [0] * 5
 N = 64
 for j in range(N):
     m = b"tc/msg" + j.to_bytes(8, "little")
     L.hs_hash_g2(m, len(m), buf(192))
     tot = [x + y for x, y in zip(tot, cnt())]
-res["hash_g2_avg%d" % N] = (tuple(x // N for x in tot), 2)
+res["hash_g2"] = (tuple(x // N for x in tot), 2)
 L.hs_decompress_g2(o.g2_compressed(P2), buf(192)); res["g2_decompress"] = (cnt(), 2)
 L.hs_decompress_g1(o.g1_compressed(P1), buf(96)); res["g1_decompress"] = (cnt(), 1)
+if "--json" in sys.argv:
+    import json
+    print(json.dumps({k: macs(c, lanes) for k, (c, lanes) in res.items()}, indent=1))
+    sys.exit(0)
 print("%-26s %8s %8s %8s %8s %8s %12s" % ("job", "mul2", "split_m", "split_s", "all_mul", "all_sqr", "device v_mad"))
 for k, (c, lanes) in res.items():
     print("%-26s %8d %8d %8d %8d %8d %12d" % ((k,) + tuple(c) + (macs(c, lanes),)))

@@ -1,0 +1,301 @@
+"""GPU parity at BASELINE.json's stated sizes, and the committed golden vectors through the HIP path.
+
+  * configs 2, 3, 4 at batch 65 536: EVERY job of the batch compared with Oracle B (plain C, all host
+    threads) -- combine_signatures byte for byte, verify_g2 booleans with every 16th signature replaced
+    by its neighbour's, Ciphertext::verify booleans with planted corruptions, PublicKeySet::decrypt
+    plaintexts byte for byte.  TC_TEST_BASELINE_JOBS=<n> shrinks the batch for quick local iterations
+    (the driver runs the default: the full size);
+  * tests/golden/vectors.json replayed through the C ABI (not only through the two oracles);
+  * reference fixtures (tests/golden/ref_v0.4.0) through the HIP path when present;
+  * the out-of-subgroup divergence: what the default (trusted-operand) mode returns for an on-curve point
+    of E'(Fq2) outside G2, and that checked-input mode / the membership entry reject it.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import c_oracle as c
+import tc_oracle as o
+from threshold_crypto_amd.engine import pack_messages
+
+pytestmark = pytest.mark.gpu
+
+B_FULL = int(os.environ.get("TC_TEST_BASELINE_JOBS", "65536"))
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+bx = bytes.fromhex
+
+
+def u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+@pytest.fixture(scope="module")
+def sig_workload(engine):
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    return ThresholdSigWorkload(engine, 3, 10, B_FULL)
+
+
+@pytest.fixture(scope="module")
+def combined(engine, sig_workload):
+    wl = sig_workload
+    sig, st = engine.combine_g2(3, wl.idx, wl.shares)
+    assert not st.any()
+    return sig
+
+
+def test_config2_every_job_of_the_baseline_batch_vs_oracle(engine, sig_workload, combined):
+    """BASELINE config 2: t=3, N=10, batch=65 536 threshold signatures -- all jobs, bit-exact."""
+    wl = sig_workload
+    c.load()
+    want, rc = c.combine_g2_batch(3, wl.idx, wl.shares, c.host_threads())
+    assert not rc.any()
+    mism = np.flatnonzero((want != combined).any(axis=1))
+    assert mism.size == 0, "GPU combine differs from Oracle B on %d of %d jobs (first: %s)" % (mism.size, wl.B, mism[:8])
+    # ungrouped launch order (batches below 4096 jobs skip the class regrouping): same bytes
+    head = min(wl.B, 1024)
+    sig2, st2 = engine.combine_g2(3, np.ascontiguousarray(wl.idx[:head]), np.ascontiguousarray(wl.shares[:head]))
+    assert not st2.any() and (sig2 == combined[:head]).all()
+
+
+def test_config3_every_verify_of_the_baseline_batch_vs_oracle(engine, sig_workload, combined):
+    """BASELINE config 3: 65 536 signature verifications; every 16th signature is its neighbour's
+    (SURVEY 8d), so the expected ok-vector is known AND recomputed by Oracle B for every job."""
+    wl = sig_workload
+    bad = combined.copy()
+    planted = np.arange(0, wl.B, 16)
+    if wl.B >= 2:
+        bad[planted] = combined[(planted + 1) % wl.B]
+    expect = np.ones(wl.B, dtype=np.uint8)
+    if wl.B >= 2:
+        expect[planted] = 0
+    ok = engine.verify_g2(wl.master_pk, bad, wl.hashes)
+    assert (ok == expect).all()
+    want = c.verify_g2_batch(bytes(wl.master_pk), bad, wl.hashes, c.host_threads())
+    assert (want.astype(np.uint8) == ok).all()
+    # the same verifies with the hash computed on the device (PublicKey::verify, src/lib.rs:115-117)
+    ok2 = engine.verify_sig(wl.master_pk, bad, wl.msg_flat, wl.msg_off)
+    assert (ok2 == expect).all()
+
+
+def test_config4_every_threshold_decryption_of_the_baseline_batch_vs_oracle(engine):
+    """BASELINE config 4: 65 536 threshold decryptions = Ciphertext::verify (pairing) + G1 share combination
+    + keystream, all jobs against Oracle B; every 32nd ciphertext has a flipped byte in v."""
+    from threshold_crypto_amd.workload import ThresholdEncWorkload
+    we = ThresholdEncWorkload(engine, 3, 10, B_FULL)
+    L = 32
+    assert we.v.shape[0] == B_FULL * L
+    v_bad = we.v.copy()
+    planted = np.arange(0, B_FULL, 32)
+    v_bad[planted * L + 5] ^= 0x40
+    expect = np.ones(B_FULL, dtype=np.uint8)
+    expect[planted] = 0
+    okc = engine.ciphertext_verify(we.u, v_bad, we.off, we.w)
+    assert (okc == expect).all()
+    want_ok = c.ciphertext_verify_batch(we.u, v_bad, L, we.w, c.host_threads())
+    assert (want_ok.astype(np.uint8) == okc).all()
+    out, st = engine.decrypt(3, we.idx, we.shares, we.v, we.off)
+    assert not st.any() and (out == we.plain_flat[: out.shape[0]]).all()
+    want_plain, rc = c.threshold_decrypt_batch(3, we.idx, we.shares, we.v, L, c.host_threads())
+    assert not rc.any() and (want_plain == out[: want_plain.shape[0]]).all()
+
+
+# ---- committed golden vectors through the C ABI ---------------------------------------------------------
+def test_golden_vectors_through_hip(engine):
+    """tests/golden/vectors.json (generator tools/gen_golden.py): every entry replayed through libtc_amd.so."""
+    g = GOLD
+    # mul + compress + checked decompress
+    fr = np.stack([u8(bx(m["fr"])) for m in g["mul"]])
+    p1 = np.stack([u8(bx(m["g1"])) for m in g["mul"]])
+    p2 = np.stack([u8(bx(m["g2"])) for m in g["mul"]])
+    o1, s1 = engine.g1_mul(fr, p1)
+    o2, s2 = engine.g2_mul(fr, p2)
+    assert not s1.any() and not s2.any()
+    d1 = np.ascontiguousarray(np.stack([o1[i, i] for i in range(len(fr))]))
+    d2 = np.ascontiguousarray(np.stack([o2[i, i] for i in range(len(fr))]))
+    for i, m in enumerate(g["mul"]):
+        assert bytes(d1[i]).hex() == m["g1_out"] and bytes(d2[i]).hex() == m["g2_out"]
+    c1, _ = engine.g1_compress(d1)
+    c2, _ = engine.g2_compress(d2)
+    for i, m in enumerate(g["mul"]):
+        assert bytes(c1[i]).hex() == m["g1_out_compressed"] and bytes(c2[i]).hex() == m["g2_out_compressed"]
+    b1, st1 = engine.g1_decompress(c1)
+    b2, st2 = engine.g2_decompress(c2)
+    assert not st1.any() and not st2.any() and (b1 == d1).all() and (b2 == d2).all()
+    # combine (G2 and G1)
+    for cb in g["combine"]:
+        t, ids = cb["t"], cb["idx"]
+        idx = np.array([ids], dtype=np.uint64)
+        out, st = engine.combine_g2(t, idx, np.stack([u8(bx(s)) for s in cb["shares_g2"]])[None].copy())
+        assert st[0] == 0 and bytes(out[0]).hex() == cb["combined_g2"]
+        out, st = engine.combine_g1(t, idx, np.stack([u8(bx(s)) for s in cb["shares_g1"]])[None].copy())
+        assert st[0] == 0 and bytes(out[0]).hex() == cb["combined_g1"]
+    # pairing checks
+    pc = g["pairing_check"]
+    ok = engine.pairing_check(np.stack([u8(bx(p["a"])) for p in pc]), np.stack([u8(bx(p["b"])) for p in pc]),
+                              np.stack([u8(bx(p["c"])) for p in pc]), np.stack([u8(bx(p["d"])) for p in pc]))
+    assert [bool(x) for x in ok] == [p["equal"] for p in pc]
+    # hashing, signing, verification, keystream, threshold encryption (H-spec: "compat-unverified")
+    flat, off = pack_messages([bx(h["msg"]) for h in g["hash_g2"]])
+    hh = engine.hash_g2(flat, off)
+    assert [bytes(x).hex() for x in hh] == [h["out"] for h in g["hash_g2"]]
+    for s in g["sign"]:
+        flat, off = pack_messages([bx(s["msg"])])
+        sig, st = engine.sign(u8(bx(s["sk"]))[None], flat, off)
+        assert st[0, 0] == 0 and bytes(sig[0, 0]).hex() == s["sig"]
+        assert engine.verify_sig(u8(bx(s["pk"])), np.ascontiguousarray(sig[:, 0]), flat, off)[0] == 1
+    flat, off = pack_messages([bx(h["msg"]) for h in g["hash_g1_g2"]])
+    out, st = engine.hash_g1_g2(np.stack([u8(bx(h["g1"])) for h in g["hash_g1_g2"]]), flat, off)
+    assert not st.any() and [bytes(x).hex() for x in out] == [h["out"] for h in g["hash_g1_g2"]]
+    for x in g["xor_with_hash"]:
+        flat, off = pack_messages([bx(x["data"])])
+        out, st = engine.xor_with_hash(u8(bx(x["g1"]))[None], flat, off)
+        assert st[0] == 0 and bytes(out[: len(bx(x["data"]))]).hex() == x["out"]
+    te = g["threshold_enc"]
+    flat, off = pack_messages([bx(te["v"])])
+    assert engine.ciphertext_verify(u8(bx(te["u"]))[None], flat, off, u8(bx(te["w"]))[None])[0] == 1
+    n = len(te["dec_shares"])
+    vflat, voff = pack_messages([bx(te["v"])] * n)
+    rep = lambda h, w: np.ascontiguousarray(np.broadcast_to(u8(bx(h))[None], (n, w)))
+    okd = engine.verify_decryption_share(np.stack([u8(bx(p)) for p in te["pk_shares"]]), np.stack([u8(bx(s)) for s in te["dec_shares"]]),
+                                         rep(te["u"], 96), vflat, voff, rep(te["w"], 192))
+    assert okd.all()
+    out, st = engine.decrypt(te["t"], np.array([te["idx"]], dtype=np.uint64), np.stack([u8(bx(s)) for s in te["dec_shares"]])[None].copy(),
+                             flat, off)
+    assert st[0] == 0 and bytes(out[: len(bx(te["plaintext"]))]).hex() == te["plaintext"]
+    pks, st = engine.public_key_shares(np.stack([u8(bx(cc)) for cc in te["commit"]]), np.array(te["idx"], dtype=np.uint64))
+    assert not st.any() and [bytes(x).hex() for x in pks] == te["pk_shares"]
+
+
+def test_reference_fixtures_through_hip_if_present(engine):
+    """The HIP path against vectors of the real crate (tools/ref_fixtures) -- skipped while the file is absent
+    (no Rust toolchain in the build image), and then every H-spec claim of this repository stays
+    "compat-unverified"."""
+    import ref_fixtures as rf
+    if not rf.present():
+        pytest.skip("no reference fixtures (tests/golden/ref_v0.4.0/vectors.hex): parity against the Rust crate unpinned")
+    v = rf.load()
+    hs = v.get("hash_g2", [])
+    if hs:
+        flat, off = pack_messages([h["msg"] for h in hs])
+        comp, st = engine.g2_compress(engine.hash_g2(flat, off))
+        assert not st.any() and [bytes(x) for x in comp] == [h["out"] for h in hs]
+    for s in v.get("sign", []):
+        flat, off = pack_messages([s["msg"]])
+        sig, st = engine.sign(u8(rf.fr_le(s["sk_be"]))[None], flat, off)
+        comp, st2 = engine.g2_compress(np.ascontiguousarray(sig[:, 0]))
+        assert st[0, 0] == 0 and bytes(comp[0]) == s["sig"]
+    for e in v.get("encrypt", []):
+        uc, vv, wc = rf.split_ciphertext(e["ciphertext_bincode"])
+        u, st1 = engine.g1_decompress(u8(uc)[None])
+        w, st2 = engine.g2_decompress(u8(wc)[None])
+        flat, off = pack_messages([vv])
+        assert not st1.any() and not st2.any() and engine.ciphertext_verify(u, flat, off, w)[0] == 1
+        g, st = engine.g1_mul(u8(rf.fr_le(e["sk_be"]))[None], u)
+        out, st = engine.xor_with_hash(np.ascontiguousarray(g[:, 0]), flat, off)
+        assert bytes(out[: len(vv)]) == e["msg"]
+
+
+# ---- operands outside the order-r subgroup ----------------------------------------------------------------
+def _point_outside_g2(rnd):
+    while True:
+        P0 = o.g2_get_point_from_x((rnd.randrange(o.Q), rnd.randrange(o.Q)), False)
+        if P0 is not None and o.E2.mul(P0, o.R) is not None:
+            return P0
+
+
+def test_out_of_subgroup_operands_default_mode_vs_checked_mode(engine):
+    """The reference multiplies bit by bit (CurveAffine::mul, reached from src/lib.rs:372-374), which is
+    correct on all of E'(Fq2); the kernels use psi = [x] and therefore REQUIRE order-r operands -- the
+    reference guarantees that by construction (checked from_bytes, src/lib.rs:246-252).  This test pins the
+    contract: (1) in the default trusted-operand mode an on-curve point outside G2 is accepted (status OK)
+    and the result differs from plain double-and-add -- the documented divergence; (2) the membership entry
+    and checked-input mode reject it exactly like an undecodable encoding; (3) checked-input mode leaves
+    valid operands' results untouched."""
+    rnd = random.Random(77)
+    P0 = _point_outside_g2(rnd)
+    good = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    pts = np.stack([u8(o.g2_uncompressed(P0)), u8(o.g2_uncompressed(good)), u8(o.g2_uncompressed(None))])
+    assert engine.g2_subgroup_check(pts).tolist() == [0, 1, 1]
+    k = rnd.randrange(1, o.R)
+    fr = u8(o.fr_to_bytes(k))[None]
+    out, st = engine.g2_mul(fr, pts)
+    assert st[:, 0].tolist() == [0, 0, 0]
+    assert bytes(out[1, 0]) == o.g2_uncompressed(o.E2.mul(good, k))
+    assert bytes(out[0, 0]) != o.g2_uncompressed(o.E2.mul(P0, k)), "GLS on a non-member happened to agree: pick another point"
+    # G1: a point of E(Fq) outside G1
+    while True:
+        x = rnd.randrange(o.Q)
+        y2 = (x * x * x + 4) % o.Q
+        y = pow(y2, (o.Q + 1) // 4, o.Q)
+        if y * y % o.Q == y2 and o.E1.mul((x, y), o.R) is not None:
+            Q1 = (x, y)
+            break
+    g1pts = np.stack([u8(o.g1_uncompressed(Q1)), u8(o.g1_uncompressed(o.G1_GEN))])
+    assert engine.g1_subgroup_check(g1pts).tolist() == [0, 1]
+    engine.set_input_checks(True)
+    try:
+        out2, st2 = engine.g2_mul(fr, pts)
+        assert st2[:, 0].tolist() == [3, 0, 0]
+        assert bytes(out2[0, 0]) == o.g2_uncompressed(None) and (out2[1:] == out[1:]).all()
+        # combine: a job whose SECOND share is a non-member fails; a non-member beyond the first t+1 samples is ignored
+        t = 1
+        sk = [rnd.randrange(o.R), rnd.randrange(o.R)]
+        h = o.E2.mul(o.G2_GEN, 5)
+        sh = [o.E2.mul(h, o.poly_evaluate(sk, i + 1)) for i in range(3)]
+        enc = lambda ps: np.stack([u8(o.g2_uncompressed(p)) for p in ps])
+        idx = np.array([[0, 1, 2], [0, 1, 2], [0, 1, 2]], dtype=np.uint64)
+        shares = np.stack([enc(sh), enc([sh[0], P0, sh[2]]), enc([sh[0], sh[1], P0])])
+        res, stc = engine.combine_g2(t, idx, shares)
+        assert stc.tolist() == [0, 3, 0]
+        assert bytes(res[0]) == bytes(res[2]) == o.g2_uncompressed(o.E2.mul(h, sk[0])) and bytes(res[1]) == o.g2_uncompressed(None)
+        # verify: a non-member signature is rejected
+        pk = u8(o.g1_uncompressed(o.E1.mul(o.G1_GEN, sk[0])))
+        sig_ok = o.E2.mul(h, sk[0])
+        okv = engine.verify_g2(pk, enc([sig_ok, P0]), enc([h, h]))
+        assert okv.tolist() == [1, 0]
+        okp = engine.pairing_check(g1pts, enc([h, h]), g1pts, enc([h, h]))
+        assert okp.tolist() == [0, 1]
+    finally:
+        engine.set_input_checks(False)
+    # the API mirror validates raw uncompressed bytes by default (threshold_crypto_amd/api.py)
+    from threshold_crypto_amd import api
+    api.set_default_engine(engine)
+    with pytest.raises(api.FromBytesError):
+        api.Signature(o.g2_uncompressed(P0))
+    with pytest.raises(api.FromBytesError):
+        api.DecryptionShare(o.g1_uncompressed(Q1))
+    assert api.Signature(o.g2_uncompressed(good)).raw == o.g2_uncompressed(good)
+
+
+def test_failed_jobs_never_return_stale_plaintext(engine):
+    """the host-mode staging slot of tc_decrypt_batch / tc_xor_with_hash_batch is reused across
+    calls; a failing job must come back as zeros, not as an earlier call's bytes at the same offset."""
+    rnd = random.Random(5)
+    g = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    data = bytes(range(40))
+    flat, off = pack_messages([data, data])
+    good = np.stack([u8(o.g1_uncompressed(g)), u8(o.g1_uncompressed(g))])
+    out, st = engine.xor_with_hash(good, flat, off)
+    assert not st.any() and bytes(out[:40]) == bytes(out[40:80]) != bytes(40)
+    bad = good.copy()
+    bad[1, 95] ^= 1  # off the curve
+    out2, st2 = engine.xor_with_hash(bad, flat, off)
+    assert st2.tolist() == [0, 3] and bytes(out2[:40]) == bytes(out[:40]) and bytes(out2[40:80]) == bytes(40)
+
+
+def test_malformed_offsets_are_rejected(engine):
+    from threshold_crypto_amd.engine import TcError
+    flat = np.zeros(16, dtype=np.uint8)
+    with pytest.raises(TcError):
+        engine.hash_g2(flat, np.array([0, 9, 4], dtype=np.uint64))
+    with pytest.raises(TcError):
+        engine.hash_g2(flat, np.array([2, 9, 12], dtype=np.uint64))
+    with pytest.raises(TypeError):
+        engine.combine_g2(1, np.zeros((1, 2), dtype=np.int32), np.zeros((1, 2, 192), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        engine.combine_g2(1, np.zeros((1, 2), dtype=np.uint64), np.zeros((1, 3, 192), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        engine.verify_g2(np.zeros(96, np.uint8), np.zeros((4, 192), np.uint8)[:, ::-1], np.zeros((4, 192), np.uint8))

@@ -196,3 +196,31 @@ def test_checked_decompress_both_oracles(rnd):
     bad = bytearray(o.g1_compressed(o.G1_GEN))
     bad[0] &= 0x7f
     assert c.g1_decompress(bytes(bad))[0] == 3
+
+
+def test_reference_fixtures_if_present():
+    """Pins BOTH oracles to vectors printed by the real threshold_crypto 0.4.0 crate (tools/ref_fixtures)
+    when tests/golden/ref_v0.4.0/vectors.hex exists.  It does not in this repository (no Rust toolchain in
+    the build image: SURVEY.md 8c), so the H-spec consumers stay "compat-unverified" and this test skips --
+    the day the file is committed it becomes the known-answer test of hash_g2 / sign / encrypt."""
+    import ref_fixtures as rf
+    assert rf.source() == ("self-oracle" if not rf.present() else rf.source())
+    if not rf.present():
+        pytest.skip("no reference fixtures (tests/golden/ref_v0.4.0/vectors.hex): parity against the Rust crate unpinned")
+    v = rf.load()
+    for h in v.get("hash_g2", []):
+        want = h["out"]
+        assert c.g2_compress(c.hash_g2(h["msg"])) == (0, want)
+        assert o.g2_compressed(o.hash_g2(h["msg"])) == want
+    for s in v.get("sign", []):
+        rc, sig = c.sign(rf.fr_le(s["sk_be"]), s["msg"])
+        assert rc == 0 and c.g2_compress(sig) == (0, s["sig"])
+    for k in v.get("key", []):
+        rng = o.ChaChaRng(k["seed"])
+        assert o.fr_random(rng) == int.from_bytes(k["sk_be"], "big")
+        assert o.g1_compressed(o.public_key(int.from_bytes(k["sk_be"], "big"))) == k["pk"]
+    for e in v.get("encrypt", []):
+        u, vv, w = rf.split_ciphertext(e["ciphertext_bincode"])
+        sk = int.from_bytes(e["sk_be"], "big")
+        ct = (o.g1_from_compressed(u), vv, o.g2_from_compressed(w))
+        assert o.ciphertext_verify(ct) and o.decrypt(sk, ct) == e["msg"]

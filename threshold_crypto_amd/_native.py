@@ -44,6 +44,8 @@ PROTOTYPES = {
     "tc_verify_decryption_share_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p],
     "tc_encrypt_batch": [_u8p, _sz, _u8p, _u8p, _u64p, _sz, _u8p, _u8p, _u8p, _u8p],
     "tc_public_key_share_batch": [_u8p, _sz, _u64p, _sz, _u8p, _u8p],
+    "tc_g1_subgroup_check_batch": [_u8p, _sz, _u8p],
+    "tc_g2_subgroup_check_batch": [_u8p, _sz, _u8p],
     "tc_g1_compress_batch": [_u8p, _sz, _u8p, _u8p],
     "tc_g2_compress_batch": [_u8p, _sz, _u8p, _u8p],
     "tc_g1_decompress_batch": [_u8p, _sz, _u8p, _u8p],
@@ -51,7 +53,7 @@ PROTOTYPES = {
 }
 
 CONTEXT_SYMBOLS = ["tc_ctx_create", "tc_ctx_destroy", "tc_ctx_set_device_io", "tc_ctx_set_stream", "tc_sync",
-                   "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version"]
+                   "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version", "tc_ctx_set_input_checks"]
 
 ALL_SYMBOLS = CONTEXT_SYMBOLS + sorted(PROTOTYPES)
 
@@ -89,6 +91,8 @@ def load():
     lib.tc_ctx_set_stream.restype = ctypes.c_int
     lib.tc_ctx_set_timing.argtypes = [_ctx, ctypes.c_int]
     lib.tc_ctx_set_timing.restype = ctypes.c_int
+    lib.tc_ctx_set_input_checks.argtypes = [_ctx, ctypes.c_int]
+    lib.tc_ctx_set_input_checks.restype = ctypes.c_int
     lib.tc_last_kernel_ms.argtypes = [_ctx]
     lib.tc_last_kernel_ms.restype = ctypes.c_double
     lib.tc_sync.argtypes = [_ctx]

@@ -82,14 +82,29 @@ def into_fr_plus_1(i):
     return (int(i) + 1) % _R
 
 
+def _require_members(engine, g2, rows):
+    """The reference only holds G1/G2 values that passed the checked decode (on the curve AND in the
+    order-r subgroup, src/lib.rs:140-146, 246-252); the kernels rely on it.  Raw uncompressed bytes that
+    did not come out of this library are therefore tested on the device before they become a value."""
+    e = engine or default_engine()
+    ok = (e.g2_subgroup_check if g2 else e.g1_subgroup_check)(rows)
+    if not ok.all():
+        raise FromBytesError("point is not a valid member of the order-r subgroup")
+
+
 class _G1Value:
+    """A group element in its uncompressed encoding.  `_trusted=True` is for values this library produced
+    itself (kernel outputs); anything else is validated like from_bytes validates (see _require_members)."""
     __slots__ = ("raw",)
     SIZE = 96
+    _G2 = False
 
-    def __init__(self, raw):
+    def __init__(self, raw, _trusted=False):
         raw = bytes(raw)
         if len(raw) != self.SIZE:
             raise ValueError("expected %d bytes" % self.SIZE)
+        if not _trusted:
+            _require_members(None, self._G2, _u8(raw)[None])
         self.raw = raw
 
     def __eq__(self, other):
@@ -107,6 +122,7 @@ class _G1Value:
 
 class _G2Value(_G1Value):
     SIZE = 192
+    _G2 = True
 
     def to_bytes(self):
         """Compressed form (to_bytes, src/lib.rs:255-259)."""
@@ -122,7 +138,7 @@ def _from_bytes(cls, data, size, fn_name):
     out, st = getattr(default_engine(), fn_name)(_u8(data)[None])
     if int(st[0]):
         raise FromBytesError("invalid encoding")
-    return cls(out[0])
+    return cls(out[0], _trusted=True)  # the checked decode ran on the device
 
 
 class Signature(_G2Value):
@@ -152,8 +168,13 @@ class DecryptionShare(_G1Value):
 class Ciphertext:
     """struct Ciphertext(G1, Vec<u8>, G2) (src/lib.rs:473-478)."""
 
-    def __init__(self, u, v, w):
+    def __init__(self, u, v, w, _trusted=False):
         self.u, self.v, self.w = bytes(u), bytes(v), bytes(w)
+        if len(self.u) != 96 or len(self.w) != 192:
+            raise ValueError("Ciphertext(u: 96 bytes, v, w: 192 bytes)")
+        if not _trusted:
+            _require_members(None, False, _u8(self.u)[None])
+            _require_members(None, True, _u8(self.w)[None])
 
     def verify(self):
         """Ciphertext::verify (src/lib.rs:508-512)."""
@@ -185,7 +206,7 @@ class PublicKey(_G1Value):
         u, v, w, st = e.encrypt(_u8(self.raw), rr, flat, off)
         for s_ in st:
             _raise_status(s_)
-        return [Ciphertext(u[j], bytes(v[int(off[j]): int(off[j + 1])]), w[j]) for j in range(len(msgs))]
+        return [Ciphertext(u[j], bytes(v[int(off[j]): int(off[j + 1])]), w[j], _trusted=True) for j in range(len(msgs))]
 
     def verify_g2(self, sig, hash_g2_point):
         """PublicKey::verify_g2 (src/lib.rs:108-110)."""
@@ -197,10 +218,14 @@ class PublicKey(_G1Value):
 
     def verify_g2_batch(self, sigs, hashes, engine=None):
         e = engine or default_engine()
+        if len(sigs) != len(hashes):
+            raise ValueError("one hash point per signature")
         return e.verify_g2(_u8(self.raw), _stack([s.raw for s in sigs], 192), _stack(hashes, 192)).astype(bool)
 
     def verify_batch(self, sigs, msgs, engine=None):
         e = engine or default_engine()
+        if len(sigs) != len(msgs):
+            raise ValueError("one message per signature")
         flat, off = pack_messages([bytes(m) for m in msgs])
         return e.verify_sig(_u8(self.raw), _stack([s.raw for s in sigs], 192), flat, off).astype(bool)
 
@@ -215,6 +240,8 @@ class PublicKeyShare(PublicKey):
     @staticmethod
     def verify_decryption_share_batch(pk_shares, shares, cts, engine=None):
         e = engine or default_engine()
+        if not (len(pk_shares) == len(shares) == len(cts)):
+            raise ValueError("one key share, one decryption share and one ciphertext per job")
         v, off = pack_messages([c.v for c in cts])
         return e.verify_decryption_share(_stack([p.raw for p in pk_shares], 96), _stack([s.raw for s in shares], 96),
                                          _stack([c.u for c in cts], 96), v, off,
@@ -224,6 +251,8 @@ class PublicKeyShare(PublicKey):
     def verify_batch_shares(pk_shares, sig_shares, msgs, engine=None):
         """PublicKeyShare::verify (src/lib.rs:177-179) for many (share key, share, msg) triples."""
         e = engine or default_engine()
+        if not (len(pk_shares) == len(sig_shares) == len(msgs)):
+            raise ValueError("one key share, one signature share and one message per job")
         flat, off = pack_messages([bytes(m) for m in msgs])
         return e.verify_sig(_stack([p.raw for p in pk_shares], 96), _stack([s.raw for s in sig_shares], 192), flat,
                             off).astype(bool)
@@ -253,13 +282,13 @@ class SecretKey:
         """SecretKey::public_key (src/lib.rs:367-369)."""
         out, st = default_engine().g1_mul(_u8(self._bytes())[None], _u8(_G1_GEN)[None])
         _raise_status(st[0, 0])
-        return PublicKey(out[0, 0])
+        return PublicKey(out[0, 0], _trusted=True)
 
     def sign_g2(self, hash_g2_point):
         """SecretKey::sign_g2 (src/lib.rs:372-374)."""
         out, st = default_engine().g2_mul(_u8(self._bytes())[None], _u8(hash_g2_point)[None])
         _raise_status(st[0, 0])
-        return Signature(out[0, 0])
+        return Signature(out[0, 0], _trusted=True)
 
     def sign(self, msg):
         """SecretKey::sign (src/lib.rs:379-381)."""
@@ -271,7 +300,7 @@ class SecretKey:
         out, st = e.sign(_u8(self._bytes())[None], flat, off)
         for s_ in st.reshape(-1):
             _raise_status(s_)
-        return [cls(out[j, 0]) for j in range(len(msgs))]
+        return [cls(out[j, 0], _trusted=True) for j in range(len(msgs))]
 
     def decrypt(self, ct):
         """SecretKey::decrypt (src/lib.rs:384-391): None if the ciphertext is invalid."""
@@ -290,11 +319,11 @@ class SecretKeyShare(SecretKey):
 
     def public_key_share(self):
         """SecretKeyShare::public_key_share (src/lib.rs:437-439)."""
-        return PublicKeyShare(self.public_key().raw)
+        return PublicKeyShare(self.public_key().raw, _trusted=True)
 
     def sign_g2(self, hash_g2_point):
         """SecretKeyShare::sign_g2 (src/lib.rs:442-444)."""
-        return SignatureShare(SecretKey.sign_g2(self, hash_g2_point).raw)
+        return SignatureShare(SecretKey.sign_g2(self, hash_g2_point).raw, _trusted=True)
 
     def sign(self, msg):
         """SecretKeyShare::sign (src/lib.rs:447-449)."""
@@ -310,7 +339,7 @@ class SecretKeyShare(SecretKey):
         """SecretKeyShare::decrypt_share_no_verify (src/lib.rs:460-462)."""
         out, st = default_engine().g1_mul(_u8(self._bytes())[None], _u8(ct.u)[None])
         _raise_status(st[0, 0])
-        return DecryptionShare(out[0, 0])
+        return DecryptionShare(out[0, 0], _trusted=True)
 
 
 def sign_shares_batch(secret_key_shares, msgs, engine=None):
@@ -321,7 +350,7 @@ def sign_shares_batch(secret_key_shares, msgs, engine=None):
     out, st = e.sign(fr, flat, off)
     for s_ in st.reshape(-1):
         _raise_status(s_)
-    return [[SignatureShare(out[j, s]) for s in range(len(secret_key_shares))] for j in range(len(msgs))]
+    return [[SignatureShare(out[j, s], _trusted=True) for s in range(len(secret_key_shares))] for j in range(len(msgs))]
 
 
 def _ordered(shares):
@@ -335,8 +364,12 @@ def _ordered(shares):
 class PublicKeySet:
     """struct PublicKeySet { commit: Commitment } (src/lib.rs:539-543); commit = list of G1 (96 B)."""
 
-    def __init__(self, commit):
+    def __init__(self, commit, _trusted=False):
         self.commit = [bytes(c) for c in commit]
+        if any(len(c) != 96 for c in self.commit) or not self.commit:
+            raise ValueError("commit: a non-empty list of 96-byte G1 points")
+        if not _trusted:
+            _require_members(None, False, _stack(self.commit, 96))
 
     def threshold(self):
         """PublicKeySet::threshold (src/lib.rs:560-562) = commit.degree()."""
@@ -344,7 +377,7 @@ class PublicKeySet:
 
     def public_key(self):
         """PublicKeySet::public_key (src/lib.rs:565-567)."""
-        return PublicKey(self.commit[0])
+        return PublicKey(self.commit[0], _trusted=True)
 
     def public_key_share(self, i):
         """PublicKeySet::public_key_share (src/lib.rs:570-573) = Commitment::evaluate(i + 1)
@@ -357,7 +390,7 @@ class PublicKeySet:
             out, st = e.public_key_shares(_stack(self.commit, 96), np.array([int(i) for i in indices], dtype=np.uint64))
             for s_ in st:
                 _raise_status(s_)
-            return [PublicKeyShare(out[j]) for j in range(len(indices))]
+            return [PublicKeyShare(out[j], _trusted=True) for j in range(len(indices))]
         n = len(self.commit)
         B = len(indices)
         scal = np.zeros((B, n, 32), dtype=np.uint8)
@@ -371,7 +404,7 @@ class PublicKeySet:
         out, st = e.lincomb_g1(scal, pts)
         for s in st:
             _raise_status(s)
-        return [PublicKeyShare(out[j]) for j in range(B)]
+        return [PublicKeyShare(out[j], _trusted=True) for j in range(B)]
 
     def combine_signatures(self, shares):
         """PublicKeySet::combine_signatures (src/lib.rs:608-615)."""
@@ -394,7 +427,7 @@ class PublicKeySet:
             for k, (_, s) in enumerate(o):
                 sh[j, k] = np.frombuffer(s.raw, dtype=np.uint8)
         out, st = e.combine_g2(t, idx, sh[:, :n].copy() if n else sh[:, :0].copy())
-        return [Signature(out[j]) for j in range(len(jobs))], st
+        return [Signature(out[j], _trusted=True) for j in range(len(jobs))], st
 
     def decrypt(self, shares, ct):
         """PublicKeySet::decrypt (src/lib.rs:618-626)."""
@@ -405,8 +438,12 @@ class PublicKeySet:
     def decrypt_batch(self, jobs, cts, engine=None):
         e = engine or default_engine()
         t = self.threshold()
+        if len(jobs) != len(cts):
+            raise ValueError("one ciphertext per share set")
         ordered = [_ordered(j) for j in jobs]
         n = len(ordered[0])
+        if any(len(o) != n for o in ordered):
+            raise ValueError("all jobs of one batch must supply the same number of shares")
         idx = np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(jobs), n)
         sh = np.empty((len(jobs), n, 96), dtype=np.uint8)
         for j, o in enumerate(ordered):
@@ -442,4 +479,4 @@ class SecretKeySet:
         e = engine or default_engine()
         fr = _stack([c.to_bytes(32, "little") for c in self.poly], 32)
         out, st = e.g1_mul(fr, _u8(_G1_GEN)[None])
-        return PublicKeySet([bytes(out[0, k]) for k in range(len(self.poly))])
+        return PublicKeySet([bytes(out[0, k]) for k in range(len(self.poly))], _trusted=True)

@@ -4,16 +4,20 @@
 
 namespace tc {
 
-// one lane per (job, sample position): lambda_i of job j
+// one lane per (job, sample position): lambda_i of job j.  Jobs the small-index fast path owns are
+// skipped; the others are counted in *need_general (one atomic per wave) so that k_combine_general can
+// leave at once when there is nothing for it to do.
 __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t,
                                                      size_t B, uint32_t* __restrict__ lam,
-                                                     uint8_t* __restrict__ status, int g2) {
+                                                     uint8_t* __restrict__ status, uint32_t* __restrict__ need_general) {
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t k = t + 1;
-  if (tid >= B * k) return;
-  const size_t j = tid / k, i = tid % k;
-  (void)g2;
-  if (combine_small_applies(idx + j * n_per_job, (int)t)) return;  // the fast path owns the job
+  const bool live = tid < B * k;
+  const size_t j = live ? tid / k : 0, i = live ? tid % k : 0;
+  const bool general = live && !combine_small_applies(idx + j * n_per_job, (int)t);
+  const uint64_t m = __builtin_amdgcn_ballot_w64(general && i == 0);
+  if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(need_general, (uint32_t)__builtin_popcountll(m));
+  if (!general) return;  // the fast path owns the job (or the lane is past the end)
   uint8_t st = job_lagrange(idx + j * n_per_job, (int)t, (int)i, lam + tid * 8);
   if (st && status) status[j] = st;
 }
@@ -69,11 +73,15 @@ TC_D bool combine_fast(size_t t, const uint64_t* idx, const uint8_t* shares, uin
   return false;
 }
 
-// one lane per job: sum_i lambda_i * share_i
+// The combination runs as TWO kernels so that each carries only its own private segment (the general
+// path's 4-share psi tables are 15 KB per lane, the fast path needs a fraction of that):
+//   k_combine_fast     t in {1, 2, 3}, small distinct indices: short joint ladder + ONE division by the
+//                      common denominator (tc_threshold.h lagrange_small_coeffs); leaves other jobs alone
+//   k_combine_general  everything else (t = 0, t > 3, large or repeated indices): Lagrange coefficients
+//                      from k_lagrange + Straus / GLS chunks; leaves at once when *need_general == 0
 template <class F>
-__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
-                                                    const uint8_t* __restrict__ shares,
-                                                    const uint32_t* __restrict__ lam, size_t B,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine_fast(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
+                                                    const uint8_t* __restrict__ shares, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status,
                                                     const uint32_t* __restrict__ perm, size_t slots) {
   constexpr int PB = PointIO<F>::BYTES;
@@ -82,13 +90,28 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   if (slot >= slots) return;
   const size_t j = perm ? (size_t)perm[slot] : slot;  // grouped by denominator class, or the identity
   if (j >= B) return;                                 // padding between two classes
+  uint8_t st = TC_JOB_OK;
+  if (!combine_fast<F>(t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st)) return;
+  if (status && (L == 1 || pair_leader())) status[j] = st;
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine_general(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
+                                                    const uint8_t* __restrict__ shares,
+                                                    const uint32_t* __restrict__ lam, size_t B,
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status,
+                                                    const uint32_t* __restrict__ need_general) {
+  constexpr int PB = PointIO<F>::BYTES;
+  constexpr int L = JobLanes<F>::N;
+  if (need_general && *need_general == 0) return;  // every job went through the fast path
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
+  if (j >= B) return;
+  if (t >= 1 && t <= 3 && combine_small_applies(idx + j * n_per_job, (int)t)) return;  // done by k_combine_fast
   if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
     PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
     return;
   }
-  uint8_t st = TC_JOB_OK;
-  if (!combine_fast<F>(t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st))
-    st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
+  const uint8_t st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
@@ -116,31 +139,39 @@ void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const u
 }
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
-                     uint8_t* status, bool g2) {
+                     uint8_t* status, uint32_t* need_general) {
   const size_t n = B * (t + 1);
-  if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status, g2 ? 1 : 0);
+  if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status, need_general);
 }
+// need_general: one zeroed word the Lagrange stage counts non-fast jobs in (nullptr when t == 0: no
+// Lagrange stage, the general kernel takes every job)
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_combine<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, (const uint32_t*)nullptr, B);
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general) {
+  if (!B) return;
+  if (t >= 1 && t <= 3)
+    hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B);
+  hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general);
 }
 size_t combine_group_slots(size_t B) { return B + (size_t)kCombineClasses * kCombinePad; }
 // cls: B bytes, counters: 8 words, perm: combine_group_slots(B) words (scratch of the caller); pass
 // perm = nullptr to run the jobs in their own order
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
-                       uint32_t* perm) {
+                       uint32_t* perm, const uint32_t* need_general) {
   if (!B) return;
-  size_t slots = B;
-  if (perm) {
-    slots = combine_group_slots(B);
-    (void)hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st);
-    (void)hipMemsetAsync(perm, 0xff, slots * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_combine_classify, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, cls, counters);
-    hipLaunchKernelGGL(k_combine_offsets, dim3(1), dim3(64), 0, st, counters);
-    hipLaunchKernelGGL(k_combine_scatter, dim3(grid_for(B)), dim3(kBlock), 0, st, cls, B, counters, perm);
+  if (t >= 1 && t <= 3) {
+    size_t slots = B;
+    if (perm) {
+      slots = combine_group_slots(B);
+      (void)hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st);
+      (void)hipMemsetAsync(perm, 0xff, slots * sizeof(uint32_t), st);
+      hipLaunchKernelGGL(k_combine_classify, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, cls, counters);
+      hipLaunchKernelGGL(k_combine_offsets, dim3(1), dim3(64), 0, st, counters);
+      hipLaunchKernelGGL(k_combine_scatter, dim3(grid_for(B)), dim3(kBlock), 0, st, cls, B, counters, perm);
+    }
+    hipLaunchKernelGGL(k_combine_fast<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots);
   }
-  hipLaunchKernelGGL(k_combine<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, (const uint32_t*)perm, slots);
+  hipLaunchKernelGGL(k_combine_general<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general);
 }
 
 }  // namespace tc

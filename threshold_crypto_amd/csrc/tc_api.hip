@@ -24,6 +24,7 @@ struct tc_ctx {
   hipStream_t stream = nullptr;
   bool device_io = false;
   bool timing = false;
+  bool input_checks = false;  // validate uncompressed operands (order-r subgroup) before using them
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
   std::string err;
@@ -41,6 +42,7 @@ namespace {
 struct Call {
   tc_ctx* c;
   bool failed = false;
+  bool arg_error = false;
   struct CopyBack {
     void* host;
     const void* dev;
@@ -48,6 +50,11 @@ struct Call {
   };
   std::vector<CopyBack> outs;
   std::vector<std::pair<void*, size_t>> wipe;
+  struct Pending {
+    const uint8_t* valid;
+    size_t per_job, group;
+  };
+  std::vector<Pending> checks;  // checked-input mode: validity bytes waiting to be applied to the jobs
 
   explicit Call(tc_ctx* ctx) : c(ctx) {
     c->next_slot = 0;
@@ -111,6 +118,30 @@ struct Call {
     if (d && zero && n) check(hipMemsetAsync(d, 0, n, c->stream), "memset");
     return d;
   }
+  // Checked-input mode (tc_ctx_set_input_checks): validate the first `take` points of `records` records of
+  // n_per_job points each (stride 0 = ONE point shared by every job); job j owns record j / group.
+  void check_points(bool g2, const uint8_t* d_pts, size_t stride, size_t n_per_job, size_t take, size_t records, size_t group) {
+    if (!c->input_checks || failed || !d_pts || !records || !take) return;
+    const size_t PB = g2 ? 192 : 96;
+    if (stride == 0) {
+      stride = PB;
+      records = 1;
+      n_per_job = take = 1;
+      group = (size_t)-1;
+    }
+    const size_t n = records * take;
+    uint8_t* v = temp<uint8_t>(n);
+    if (!v) return;
+    if (g2) tc::launch_subgroup_check_g2(c->stream, d_pts, stride, n_per_job, take, n, v);
+    else tc::launch_subgroup_check_g1(c->stream, d_pts, stride, n_per_job, take, n, v);
+    checks.push_back({v, take, group});
+  }
+  // after the main kernels: jobs that own an invalid point fail like undecodable ones
+  void apply_checks(size_t B, uint8_t* status, uint8_t* out, size_t out_bytes, uint8_t* ok) {
+    if (!failed)
+      for (auto& p : checks) tc::launch_invalidate_jobs(c->stream, p.valid, p.per_job, p.group, B, status, out, out_bytes, ok);
+    checks.clear();
+  }
   void begin_timing() {
     if (c->timing && !failed) check(hipEventRecord(c->ev0, c->stream), "event record");
   }
@@ -131,13 +162,22 @@ struct Call {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     }
-    return failed ? TC_ERR_HIP : TC_OK;
+    return failed ? (arg_error ? TC_ERR_INVALID_ARG : TC_ERR_HIP) : TC_OK;
   }
 };
 
 // total message bytes = off[B]; in device-io mode read it back (8 bytes)
 bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
   if (!k.c->device_io) {
+    // host offsets are validated here (O(B)); in device-io mode the caller guarantees off[0] = 0 and a
+    // non-decreasing array (the kernels read msgs + off[j] .. off[j+1] as they are)
+    bool good = off[0] == 0;
+    for (size_t j = 0; j < B && good; j++) good = off[j + 1] >= off[j];
+    if (!good) {
+      k.fail("invalid argument: offsets must start at 0 and be non-decreasing");
+      k.arg_error = true;
+      return false;
+    }
     *total = off[B];
     return true;
   }
@@ -210,6 +250,12 @@ int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream) {
   return TC_OK;
 }
 
+int tc_ctx_set_input_checks(tc_ctx* ctx, int enabled) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  ctx->input_checks = enabled != 0;
+  return TC_OK;
+}
+
 int tc_ctx_set_timing(tc_ctx* ctx, int enabled) {
   if (!ctx) return TC_ERR_INVALID_ARG;
   ctx->timing = enabled != 0;
@@ -259,7 +305,9 @@ int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, con
   uint8_t* d_out = k.out(out_g2, B * 192);
   uint8_t* d_st = k.out(status, B);
   k.begin_timing();
+  k.check_points(false, d_g1, 96, 1, 1, B, 1);
   if (!k.failed) tc::launch_hash_g1_g2(ctx->stream, d_g1, d_msgs, d_off, B, d_out, d_st);
+  k.apply_checks(B, d_st, d_out, 192, nullptr);
   k.end_timing();
   return k.finish();
 }
@@ -277,10 +325,12 @@ static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts
   uint8_t* d_out = k.out(out, S * B * PB);
   uint8_t* d_st = k.out(status, S * B);
   k.begin_timing();
+  k.check_points(g2, d_pts, PB, 1, 1, B, S);
   if (!k.failed) {
     if (g2) tc::launch_g2_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
     else tc::launch_g1_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
   }
+  k.apply_checks(S * B, d_st, d_out, PB, nullptr);
   k.end_timing();
   return k.finish();
 }
@@ -362,19 +412,22 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
   uint8_t* d_cls = group ? k.temp<uint8_t>(B) : nullptr;
   uint32_t* d_counters = group ? k.temp<uint32_t>(8) : nullptr;
   uint32_t* d_perm = group ? k.temp<uint32_t>(tc::combine_group_slots(B)) : nullptr;
+  uint32_t* d_need = t > 0 ? k.temp<uint32_t>(1, /*zero=*/true) : nullptr;
   const uint8_t* d_v = nullptr;
   const uint64_t* d_off = nullptr;
   uint8_t* d_plain = nullptr;
   if (plain) {
     d_v = k.in(v, (size_t)total);
     d_off = k.in(off, B + 1);
-    d_plain = k.out(plain, (size_t)total);
+    d_plain = k.out(plain, (size_t)total, /*zero=*/true);  // failed jobs leave zeros, never stale staging bytes
   }
   k.begin_timing();
+  k.check_points(g2, d_sh, PB, n, t + 1, B, 1);  // exactly the first t+1 samples interpolate() takes
   if (!k.failed) {
-    if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, g2);
-    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm);
-    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st);
+    if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
+    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need);
+    k.apply_checks(B, d_st, d_pt, PB, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
   }
   k.end_timing();
@@ -416,10 +469,12 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
   uint8_t* d_out = k.out(out, B * PB);
   uint8_t* d_st = k.out(status, B);
   k.begin_timing();
+  k.check_points(g2, d_pt, PB, n, n, B, 1);
   if (!k.failed) {
     if (g2) tc::launch_lincomb_g2(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
     else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
   }
+  k.apply_checks(B, d_st, d_out, PB, nullptr);
   k.end_timing();
   return k.finish();
 }
@@ -446,10 +501,14 @@ int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, 
   const uint8_t* d_g1 = k.in(g1, B * 96);
   const uint8_t* d_data = k.in(data, (size_t)total);
   const uint64_t* d_off = k.in(off, B + 1);
-  uint8_t* d_out = k.out(out, (size_t)total);
+  uint8_t* d_out = k.out(out, (size_t)total, /*zero=*/true);
   uint8_t* d_st = k.out(status, B, /*zero=*/true);
   k.begin_timing();
-  if (!k.failed) tc::launch_xor_with_hash(ctx->stream, d_g1, d_data, d_off, B, d_out, d_st);
+  k.check_points(false, d_g1, 96, 1, 1, B, 1);
+  if (!k.failed) {
+    k.apply_checks(B, d_st, nullptr, 0, nullptr);  // the keystream kernel skips jobs already flagged
+    tc::launch_xor_with_hash(ctx->stream, d_g1, d_data, d_off, B, d_out, d_st);
+  }
   k.end_timing();
   return k.finish();
 }
@@ -469,7 +528,12 @@ int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8
   const uint8_t* dd = k.in(d, span(sd, 192));
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
+  k.check_points(false, da, sa, 1, 1, B, 1);
+  k.check_points(true, db, sb, 1, 1, B, 1);
+  k.check_points(false, dc, sc, 1, 1, B, 1);
+  k.check_points(true, dd, sd, 1, 1, B, 1);
   if (!k.failed) tc::launch_pairing_check(ctx->stream, da, sa, db, sb, dc, sc, dd, sd, B, d_ok);
+  k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
 }
@@ -486,8 +550,12 @@ int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const u
   const uint8_t* d_hash = k.in(hash, B * 192);
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
+  k.check_points(false, d_pk, pk_stride, 1, 1, B, 1);
+  k.check_points(true, d_sig, 192, 1, 1, B, 1);
+  k.check_points(true, d_hash, 192, 1, 1, B, 1);
   // e(pk, hash) == e(g1, sig)                                           (src/lib.rs:109)
   if (!k.failed) tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen, 0, d_sig, 192, B, d_ok);
+  k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
 }
@@ -509,12 +577,15 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
   uint8_t* d_hash = k.temp<uint8_t>(B * 192);
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
+  k.check_points(false, d_pk, pk_stride, 1, 1, B, 1);
+  k.check_points(true, d_sig, 192, 1, 1, B, 1);
   if (!k.failed) {
     // e(pk, [c] Q') == e(g1, sig)  <=>  e(pk, Q') == e([1/c] g1, sig): the hash skips its last constant
     // multiplication and the generator side uses the context's pre-scaled generator
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen_unfix, 0, d_sig, 192, B, d_ok);
   }
+  k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
 }
@@ -535,12 +606,15 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
   uint8_t* d_hash = k.temp<uint8_t>(B * 192);
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
+  k.check_points(false, d_u, 96, 1, 1, B, 1);
+  k.check_points(true, d_w, 192, 1, 1, B, 1);
   if (!k.failed) {
     // an undecodable u leaves an infinity hash; the pairing kernel then rejects u itself
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
     // e(g1, w) == e(u, [c] Q')  <=>  e([1/c] g1, w) == e(u, Q')         (src/lib.rs:511)
     tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok);
   }
+  k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
 }
@@ -567,14 +641,43 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
   uint8_t* d_sharec = k.temp<uint8_t>(B * 96);
   uint8_t* d_ok = k.out(ok, B);
   k.begin_timing();
+  k.check_points(false, d_pk, pk_stride, 1, 1, B, 1);
+  k.check_points(false, d_share, 96, 1, 1, B, 1);
+  k.check_points(false, d_u, 96, 1, 1, B, 1);
+  k.check_points(true, d_w, 192, 1, 1, B, 1);
   if (!k.failed) {
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st, /*fix=*/false);
     tc::launch_g1_scale_cofactor_fix(ctx->stream, d_share, 96, B, d_sharec);
     // e(share, hash) = e([c] share, Q') == e(pk_share, w)               (src/lib.rs:185)
     tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok);
   }
+  k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
+}
+
+// ---- membership tests ---------------------------------------------------------------------------
+static int subgroup_check(tc_ctx* ctx, bool g2, const uint8_t* pts, size_t B, uint8_t* ok) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && pts && ok);
+  const size_t PB = g2 ? 192 : 96;
+  Call k(ctx);
+  const uint8_t* d_pts = k.in(pts, B * PB);
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  if (!k.failed) {
+    if (g2) tc::launch_subgroup_check_g2(ctx->stream, d_pts, PB, 1, 1, B, d_ok);
+    else tc::launch_subgroup_check_g1(ctx->stream, d_pts, PB, 1, 1, B, d_ok);
+  }
+  k.end_timing();
+  return k.finish();
+}
+int tc_g1_subgroup_check_batch(tc_ctx* ctx, const uint8_t* pts96, size_t B, uint8_t* ok) {
+  return subgroup_check(ctx, false, pts96, B, ok);
+}
+int tc_g2_subgroup_check_batch(tc_ctx* ctx, const uint8_t* pts192, size_t B, uint8_t* ok) {
+  return subgroup_check(ctx, true, pts192, B, ok);
 }
 
 // ---- wire formats ------------------------------------------------------------------------------
@@ -625,7 +728,15 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uin
   uint8_t* d_w = k.out(out_w, B * 192);
   uint8_t* d_st = k.out(status, B);
   k.begin_timing();
+  k.check_points(false, d_pk, pk_stride, 1, 1, B, 1);
   if (!k.failed) tc::launch_encrypt(ctx->stream, d_pk, pk_stride, d_r, d_msgs, d_off, B, d_u, d_v, d_w, d_st);
+  if (!k.checks.empty()) {
+    // an invalid key fails the job: status + identity u and w (v keeps the kernel's bytes and must be ignored)
+    auto pending = k.checks;
+    k.apply_checks(B, d_st, d_u, 96, nullptr);
+    k.checks = pending;
+    k.apply_checks(B, nullptr, d_w, 192, nullptr);
+  }
   k.end_timing();
   return k.finish();
 }
@@ -642,7 +753,9 @@ int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, cons
   uint8_t* d_out = k.out(out, M * 96);
   uint8_t* d_st = k.out(status, M);
   k.begin_timing();
+  k.check_points(false, d_c, 96, t + 1, t + 1, 1, (size_t)-1);  // the t+1 coefficients, shared by every index
   if (!k.failed) tc::launch_commitment_evaluate(ctx->stream, d_c, t, d_idx, M, d_out, d_st);
+  k.apply_checks(M, d_st, d_out, 96, nullptr);
   k.end_timing();
   return k.finish();
 }

@@ -48,6 +48,10 @@ TC_HD Jac<Fq2> point_mul_scalar(const Affine<Fq2>& p, const uint32_t* k) {
   return g2_mul_gls(p, k);
 }
 
+// order-r membership (tc_sqrt.h: Scott's endomorphism tests, one / two 64-bit ladders)
+TC_HD bool point_in_subgroup(const Affine<Fq>& p) { return g1_in_subgroup(p); }
+TC_HD bool point_in_subgroup(const Affine<Fq2>& p) { return g2_in_subgroup(p); }
+
 // out = fr * pt           (CurveAffine::mul: sign_g2 src/lib.rs:373, decrypt_share :461)
 // The scalar is shared by all lanes of a wave (one secret key share per wave), so the
 // bit-serial double-and-add below has wave-uniform control flow.

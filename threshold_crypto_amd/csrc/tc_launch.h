@@ -29,18 +29,30 @@ void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* ou
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 
+// need_general: one zeroed device word; the Lagrange stage counts the jobs the small-index fast path
+// does not take, the general combine kernel leaves at once when it stays zero (k_combine.hip)
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
-                     uint8_t* status, bool g2);
+                     uint8_t* status, uint32_t* need_general);
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status);
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general);
 size_t combine_group_slots(size_t B);
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
-                       uint32_t* perm);
+                       uint32_t* perm, const uint32_t* need_general);
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status);
 void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status);
+
+// opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
+// records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an
+// invalid point (status INVALID_ENCODING + identity output, or ok = 0); job j owns record j / group
+void launch_subgroup_check_g1(hipStream_t st, const uint8_t* pts, size_t stride, size_t n_per_job, size_t take, size_t n,
+                              uint8_t* valid);
+void launch_subgroup_check_g2(hipStream_t st, const uint8_t* pts, size_t stride, size_t n_per_job, size_t take, size_t n,
+                              uint8_t* valid);
+void launch_invalidate_jobs(hipStream_t st, const uint8_t* valid, size_t per_job, size_t group, size_t B, uint8_t* status,
+                            uint8_t* out, size_t out_bytes, uint8_t* ok);
 
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok);

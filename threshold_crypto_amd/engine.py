@@ -73,6 +73,10 @@ class Engine:
     def set_timing(self, on):
         self._lib.tc_ctx_set_timing(self._ctx, 1 if on else 0)
 
+    def set_input_checks(self, on):
+        """checked-input mode: every point operand is tested for order-r membership on the device first"""
+        self._lib.tc_ctx_set_input_checks(self._ctx, 1 if on else 0)
+
     def last_kernel_ms(self):
         return float(self._lib.tc_last_kernel_ms(self._ctx))
 
@@ -108,24 +112,53 @@ class Engine:
             raise TcError(rc, self._lib.tc_last_error(self._ctx).decode())
 
     @staticmethod
-    def _check(a, shape_tail, name):
-        if tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail):
-            raise ValueError("%s: expected trailing shape %s, got %s" % (name, shape_tail, tuple(a.shape)))
-        if not (a.is_contiguous() if _is_torch(a) else a.flags["C_CONTIGUOUS"]):
-            raise ValueError("%s must be contiguous" % name)
+    def _arg(a, shape, kind, name):
+        """Every operand is validated before its raw pointer crosses the C ABI: dtype (`kind` "u8" or
+        "u64"), C-contiguity and the FULL expected shape (None = any extent).  A wrong dtype or a sliced
+        view would otherwise be misread, or read out of bounds, by the library."""
+        if a is None:
+            raise ValueError("%s is required" % name)
+        torch_arr = _is_torch(a)
+        dt = str(a.dtype)
+        good = {"u8": ("uint8", "torch.uint8"), "u64": ("uint64", "int64", "torch.int64", "torch.uint64")}[kind]
+        if dt not in good:
+            raise TypeError("%s: expected dtype %s, got %s" % (name, good[0], dt))
+        if len(a.shape) != len(shape) or any(w is not None and int(g) != int(w) for g, w in zip(a.shape, shape)):
+            raise ValueError("%s: expected shape %s, got %s" % (name, tuple(shape), tuple(a.shape)))
+        if not (a.is_contiguous() if torch_arr else a.flags["C_CONTIGUOUS"]):
+            raise ValueError("%s must be C-contiguous" % name)
+        return a
+
+    def _msgs(self, msgs, off, B=None):
+        """a message blob + its offsets[B+1]; returns B"""
+        self._arg(off, (None,), "u64", "off")
+        if off.shape[0] < 1:
+            raise ValueError("off must hold B+1 entries")
+        if B is not None and off.shape[0] != B + 1:
+            raise ValueError("off holds %d entries for %d jobs (expected B+1)" % (off.shape[0], B))
+        self._arg(msgs, (None,), "u8", "msgs")
+        return off.shape[0] - 1
+
+    def _point(self, a, nbytes, B, name):
+        """a per-job (B, nbytes) operand or ONE (nbytes,) operand broadcast to every job; returns the stride"""
+        if len(a.shape) == 1:
+            self._arg(a, (nbytes,), "u8", name)
+            return 0
+        self._arg(a, (B, nbytes), "u8", name)
+        return nbytes
 
     # -- hashing ------------------------------------------------------------------------------
     def hash_g2(self, msgs, off):
         dev = self._mode(msgs, off)
-        B = off.shape[0] - 1
+        B = self._msgs(msgs, off)
         out = self._empty(dev, (B, G2_BYTES), ref=msgs)
         self._call("tc_hash_g2_batch", _ptr(msgs), _ptr(off), B, _ptr(out))
         return out
 
     def hash_g1_g2(self, g1, msgs, off):
         dev = self._mode(g1, msgs, off)
-        B = off.shape[0] - 1
-        self._check(g1, (G1_BYTES,), "g1")
+        B = self._msgs(msgs, off)
+        self._arg(g1, (B, G1_BYTES), "u8", "g1")
         out = self._empty(dev, (B, G2_BYTES), ref=g1)
         st = self._empty(dev, (B,), ref=g1)
         self._call("tc_hash_g1_g2_batch", _ptr(g1), _ptr(msgs), _ptr(off), B, _ptr(out), _ptr(st))
@@ -134,8 +167,8 @@ class Engine:
     # -- scalar multiplication -------------------------------------------------------------------
     def _mul(self, name, pb, fr, pts):
         dev = self._mode(fr, pts)
-        self._check(fr, (FR_BYTES,), "fr")
-        self._check(pts, (pb,), "pts")
+        self._arg(fr, (None, FR_BYTES), "u8", "fr")
+        self._arg(pts, (None, pb), "u8", "pts")
         S, B = fr.shape[0], pts.shape[0]
         out = self._empty(dev, (B, S, pb), ref=pts)
         st = self._empty(dev, (B, S), ref=pts)
@@ -151,7 +184,8 @@ class Engine:
 
     def sign(self, fr, msgs, off):
         dev = self._mode(fr, msgs, off)
-        S, B = fr.shape[0], off.shape[0] - 1
+        self._arg(fr, (None, FR_BYTES), "u8", "fr")
+        S, B = fr.shape[0], self._msgs(msgs, off)
         out = self._empty(dev, (B, S, G2_BYTES), ref=fr)
         st = self._empty(dev, (B, S), ref=fr)
         self._call("tc_sign_batch", _ptr(fr), _ptr(msgs), _ptr(off), S, B, _ptr(out), _ptr(st))
@@ -160,8 +194,9 @@ class Engine:
     # -- combination --------------------------------------------------------------------------------
     def _combine(self, name, pb, t, idx, shares):
         dev = self._mode(idx, shares)
+        self._arg(idx, (None, None), "u64", "idx")
         B, n = idx.shape
-        self._check(shares, (n, pb), "shares")
+        self._arg(shares, (B, n, pb), "u8", "shares")
         out = self._empty(dev, (B, pb), ref=shares)
         st = self._empty(dev, (B,), ref=shares)
         self._call(name, int(t), int(n), _ptr(idx), _ptr(shares), B, _ptr(out), _ptr(st))
@@ -175,9 +210,9 @@ class Engine:
 
     def _lincomb(self, name, pb, scalars, points):
         dev = self._mode(scalars, points)
+        self._arg(scalars, (None, None, FR_BYTES), "u8", "scalars")
         B, n = scalars.shape[0], scalars.shape[1]
-        self._check(scalars, (n, FR_BYTES), "scalars")
-        self._check(points, (n, pb), "points")
+        self._arg(points, (B, n, pb), "u8", "points")
         out = self._empty(dev, (B, pb), ref=points)
         st = self._empty(dev, (B,), ref=points)
         self._call(name, int(n), _ptr(scalars), _ptr(points), B, _ptr(out), _ptr(st))
@@ -192,8 +227,10 @@ class Engine:
 
     def decrypt(self, t, idx, shares_g1, v, off):
         dev = self._mode(idx, shares_g1, v, off)
+        self._arg(idx, (None, None), "u64", "idx")
         B, n = idx.shape
-        self._check(shares_g1, (n, G1_BYTES), "shares")
+        self._arg(shares_g1, (B, n, G1_BYTES), "u8", "shares")
+        self._msgs(v, off, B)
         out = self._empty(dev, tuple(v.shape), ref=v)
         st = self._empty(dev, (B,), ref=v)
         self._call("tc_decrypt_batch", int(t), int(n), _ptr(idx), _ptr(shares_g1), _ptr(v), _ptr(off), B,
@@ -202,107 +239,123 @@ class Engine:
 
     def xor_with_hash(self, g1, data, off):
         dev = self._mode(g1, data, off)
-        B = off.shape[0] - 1
+        B = self._msgs(data, off)
+        self._arg(g1, (B, G1_BYTES), "u8", "g1")
         out = self._empty(dev, tuple(data.shape), ref=data)
         st = self._empty(dev, (B,), ref=data)
         self._call("tc_xor_with_hash_batch", _ptr(g1), _ptr(data), _ptr(off), B, _ptr(out), _ptr(st))
         return out, st
 
     # -- pairing checks -------------------------------------------------------------------------------
-    @staticmethod
-    def _stride(a, nbytes):
-        return 0 if a.ndim == 1 else nbytes
-
     def pairing_check(self, a, b, c, d, B=None):
         """ok[j] = e(a[j], b[j]) == e(c[j], d[j]); 1-D operands are broadcast to every job."""
         dev = self._mode(a, b, c, d)
         if B is None:
-            B = max(x.shape[0] if x.ndim == 2 else 1 for x in (a, b, c, d))
+            B = max(x.shape[0] if len(x.shape) == 2 else 1 for x in (a, b, c, d))
+        sa, sb = self._point(a, G1_BYTES, B, "a"), self._point(b, G2_BYTES, B, "b")
+        sc, sd = self._point(c, G1_BYTES, B, "c"), self._point(d, G2_BYTES, B, "d")
         ok = self._empty(dev, (B,), ref=a)
-        self._call("tc_pairing_check_batch", _ptr(a), self._stride(a, G1_BYTES), _ptr(b), self._stride(b, G2_BYTES),
-                   _ptr(c), self._stride(c, G1_BYTES), _ptr(d), self._stride(d, G2_BYTES), B, _ptr(ok))
+        self._call("tc_pairing_check_batch", _ptr(a), sa, _ptr(b), sb, _ptr(c), sc, _ptr(d), sd, B, _ptr(ok))
         return ok
 
     def verify_g2(self, pk, sig, hash_):
         dev = self._mode(pk, sig, hash_)
+        self._arg(sig, (None, G2_BYTES), "u8", "sig")
         B = sig.shape[0]
+        self._arg(hash_, (B, G2_BYTES), "u8", "hash")
         ok = self._empty(dev, (B,), ref=sig)
-        self._call("tc_verify_g2_batch", _ptr(pk), self._stride(pk, G1_BYTES), _ptr(sig), _ptr(hash_), B, _ptr(ok))
+        self._call("tc_verify_g2_batch", _ptr(pk), self._point(pk, G1_BYTES, B, "pk"), _ptr(sig), _ptr(hash_), B, _ptr(ok))
         return ok
 
     def verify_sig(self, pk, sig, msgs, off):
         dev = self._mode(pk, sig, msgs, off)
+        self._arg(sig, (None, G2_BYTES), "u8", "sig")
         B = sig.shape[0]
+        self._msgs(msgs, off, B)
         ok = self._empty(dev, (B,), ref=sig)
-        self._call("tc_verify_sig_batch", _ptr(pk), self._stride(pk, G1_BYTES), _ptr(sig), _ptr(msgs), _ptr(off), B,
+        self._call("tc_verify_sig_batch", _ptr(pk), self._point(pk, G1_BYTES, B, "pk"), _ptr(sig), _ptr(msgs), _ptr(off), B,
                    _ptr(ok))
         return ok
 
     def ciphertext_verify(self, u, v, off, w):
         dev = self._mode(u, v, off, w)
+        self._arg(u, (None, G1_BYTES), "u8", "u")
         B = u.shape[0]
+        self._msgs(v, off, B)
+        self._arg(w, (B, G2_BYTES), "u8", "w")
         ok = self._empty(dev, (B,), ref=u)
         self._call("tc_ciphertext_verify_batch", _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(ok))
         return ok
 
     def verify_decryption_share(self, pk_share, share, u, v, off, w):
         dev = self._mode(pk_share, share, u, v, off, w)
+        self._arg(share, (None, G1_BYTES), "u8", "share")
         B = share.shape[0]
+        self._arg(u, (B, G1_BYTES), "u8", "u")
+        self._arg(w, (B, G2_BYTES), "u8", "w")
+        self._msgs(v, off, B)
         ok = self._empty(dev, (B,), ref=share)
-        self._call("tc_verify_decryption_share_batch", _ptr(pk_share), self._stride(pk_share, G1_BYTES), _ptr(share),
-                   _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(ok))
+        self._call("tc_verify_decryption_share_batch", _ptr(pk_share), self._point(pk_share, G1_BYTES, B, "pk_share"),
+                   _ptr(share), _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(ok))
+        return ok
+
+    # -- membership tests -----------------------------------------------------------------------------
+    def g1_subgroup_check(self, pts):
+        """ok[j] = pts[j] is a valid encoding of a point of G1 (on the curve, order r)"""
+        dev = self._mode(pts)
+        self._arg(pts, (None, G1_BYTES), "u8", "pts")
+        ok = self._empty(dev, (pts.shape[0],), ref=pts)
+        self._call("tc_g1_subgroup_check_batch", _ptr(pts), pts.shape[0], _ptr(ok))
+        return ok
+
+    def g2_subgroup_check(self, pts):
+        dev = self._mode(pts)
+        self._arg(pts, (None, G2_BYTES), "u8", "pts")
+        ok = self._empty(dev, (pts.shape[0],), ref=pts)
+        self._call("tc_g2_subgroup_check_batch", _ptr(pts), pts.shape[0], _ptr(ok))
         return ok
 
     # -- wire formats ------------------------------------------------------------------------------------
-    def g1_compress(self, pts):
-        dev = self._mode(pts)
-        B = pts.shape[0]
-        out = self._empty(dev, (B, 48), ref=pts)
-        st = self._empty(dev, (B,), ref=pts)
-        self._call("tc_g1_compress_batch", _ptr(pts), B, _ptr(out), _ptr(st))
+    def _recode(self, name, a, nin, nout):
+        dev = self._mode(a)
+        self._arg(a, (None, nin), "u8", "points")
+        B = a.shape[0]
+        out = self._empty(dev, (B, nout), ref=a)
+        st = self._empty(dev, (B,), ref=a)
+        self._call(name, _ptr(a), B, _ptr(out), _ptr(st))
         return out, st
 
+    def g1_compress(self, pts):
+        return self._recode("tc_g1_compress_batch", pts, G1_BYTES, 48)
+
     def g2_compress(self, pts):
-        dev = self._mode(pts)
-        B = pts.shape[0]
-        out = self._empty(dev, (B, 96), ref=pts)
-        st = self._empty(dev, (B,), ref=pts)
-        self._call("tc_g2_compress_batch", _ptr(pts), B, _ptr(out), _ptr(st))
-        return out, st
+        return self._recode("tc_g2_compress_batch", pts, G2_BYTES, 96)
 
     def g1_decompress(self, comp):
         """checked decode of 48-byte compressed G1 (from_bytes): status 3 = invalid"""
-        dev = self._mode(comp)
-        B = comp.shape[0]
-        out = self._empty(dev, (B, G1_BYTES), ref=comp)
-        st = self._empty(dev, (B,), ref=comp)
-        self._call("tc_g1_decompress_batch", _ptr(comp), B, _ptr(out), _ptr(st))
-        return out, st
+        return self._recode("tc_g1_decompress_batch", comp, 48, G1_BYTES)
 
     def g2_decompress(self, comp):
-        dev = self._mode(comp)
-        B = comp.shape[0]
-        out = self._empty(dev, (B, G2_BYTES), ref=comp)
-        st = self._empty(dev, (B,), ref=comp)
-        self._call("tc_g2_decompress_batch", _ptr(comp), B, _ptr(out), _ptr(st))
-        return out, st
+        return self._recode("tc_g2_decompress_batch", comp, 96, G2_BYTES)
 
     def encrypt(self, pk, r, msgs, off):
         """PublicKey::encrypt_with_rng with the Fr draws supplied: returns (u, v, w, status)."""
         dev = self._mode(pk, r, msgs, off)
-        B = off.shape[0] - 1
-        self._check(r, (FR_BYTES,), "r")
+        B = self._msgs(msgs, off)
+        self._arg(r, (B, FR_BYTES), "u8", "r")
         u = self._empty(dev, (B, G1_BYTES), ref=r)
         v = self._empty(dev, tuple(msgs.shape), ref=r)
         w = self._empty(dev, (B, G2_BYTES), ref=r)
         st = self._empty(dev, (B,), ref=r)
-        self._call("tc_encrypt_batch", _ptr(pk), self._stride(pk, G1_BYTES), _ptr(r), _ptr(msgs), _ptr(off), B, _ptr(u),
+        self._call("tc_encrypt_batch", _ptr(pk), self._point(pk, G1_BYTES, B, "pk"), _ptr(r), _ptr(msgs), _ptr(off), B, _ptr(u),
                    _ptr(v), _ptr(w), _ptr(st))
         return u, v, w, st
 
     def public_key_shares(self, commit, idx):
         """Commitment::evaluate(idx + 1) for every index: (M, 96)."""
         dev = self._mode(commit, idx)
+        self._arg(commit, (None, G1_BYTES), "u8", "commit")
+        self._arg(idx, (None,), "u64", "idx")
         M = idx.shape[0]
         t = commit.shape[0] - 1
         out = self._empty(dev, (M, G1_BYTES), ref=commit)

@@ -6,14 +6,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string>
 #include <vector>
 #include <algorithm>
 
-#define ITERS 8192
 #define NACC 8
 
 template <int OP>
-__global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t* ticks, uint32_t seed) {
+__global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t* ticks, uint32_t seed, int iters) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t acc[NACC];
   int64_t sacc[NACC];
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t* ticks, uint32_
   const uint64_t t0 = __builtin_readcyclecounter();   // s_memtime
   const uint64_t r0 = wall_clock64();                 // s_memrealtime (100 MHz)
 #pragma unroll 1
-  for (int it = 0; it < ITERS; it++) {
+  for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int kx = 0; kx < NACC; kx++) {
       if (OP == 0) acc[kx] = (uint64_t)(uint32_t)acc[(kx + 1) & (NACC - 1)] * b + acc[kx];        // v_mad_u64_u32
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t* ticks, uint32_
 }
 
 template <int OP>
-void run(const char* name, uint64_t* d_out, uint64_t* d_ticks, int blocks, int waves_per_simd) {
+void run(const char* name, uint64_t* d_out, uint64_t* d_ticks, int blocks, int waves_per_simd, int iters = 8192) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -57,7 +57,7 @@ void run(const char* name, uint64_t* d_out, uint64_t* d_ticks, int blocks, int w
   float best = 1e30f;
   for (int r = 0; r < 4; r++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, 777u + r);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, 777u + r, iters);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -69,17 +69,18 @@ void run(const char* name, uint64_t* d_out, uint64_t* d_ticks, int blocks, int w
   for (int w = 0; w < nw; w++) {
     const double cycles = (double)h[2 * w], real = (double)h[2 * w + 1];
     if (real > 0) clk.push_back(cycles / (real / 100e6) / 1e9);
-    cyc.push_back(cycles / ((double)ITERS * NACC));
+    cyc.push_back(cycles / ((double)iters * NACC));
   }
   std::sort(clk.begin(), clk.end());
   std::sort(cyc.begin(), cyc.end());
-  const double ops = (double)blocks * 256 * ITERS * NACC;
-  printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"kernel_ms\": %.4f, \"lane_ops_per_s\": %.4e, \"effective_clock_GHz_median\": %.3f, "
+  const double ops = (double)blocks * 256 * iters * NACC;
+  printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"iters\": %d, \"kernel_ms\": %.4f, \"lane_ops_per_s\": %.4e, \"effective_clock_GHz_median\": %.3f, "
          "\"shader_cycles_per_instr_per_wave_median\": %.3f, \"cycles_per_instr_per_simd\": %.3f}\n",
-         name, waves_per_simd, best, ops / (best * 1e-3), clk[clk.size() / 2], cyc[cyc.size() / 2], cyc[cyc.size() / 2] / waves_per_simd);
+         name, waves_per_simd, iters, best, ops / (best * 1e-3), clk[clk.size() / 2], cyc[cyc.size() / 2], cyc[cyc.size() / 2] / waves_per_simd);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool peak_only = argc > 1 && std::string(argv[1]) == "--peak";  // bench.py: the sustained roofline peak only
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fprintf(stderr, "no HIP device\n"); return 1; }
   hipDeviceProp_t p;
@@ -89,6 +90,11 @@ int main() {
   uint64_t *d_out, *d_ticks;
   hipMalloc(&d_out, (size_t)cus * 8 * 256 * 8);
   hipMalloc(&d_ticks, (size_t)cus * 8 * 4 * 16);
+  // the roofline denominator: the multiplier's own instruction, every SIMD full (8 waves), ~25 ms per
+  // launch so that the clock is the one the chip SUSTAINS under this load
+  run<1>("v_mad_i64_i32", d_out, d_ticks, cus * 8, 8, 8192 * 20);
+  if (peak_only) return 0;
+  run<0>("v_mad_u64_u32", d_out, d_ticks, cus * 8, 8, 8192 * 20);
   for (int wps : {1, 2, 8}) {
     run<0>("v_mad_u64_u32", d_out, d_ticks, cus * wps, wps);
     run<1>("v_mad_i64_i32", d_out, d_ticks, cus * wps, wps);
