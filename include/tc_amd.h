@@ -169,6 +169,25 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk_g1, size_t pk_stride, const 
 int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                               uint8_t* status);
 
+/* ---- DKG algebra (src/poly.rs) ----------------------------------------------------------------- */
+/* out[i] = coeff_fr[i] * g1: Poly::commitment src/poly.rs:372-377 and BivarPoly::commitment :625-632 (every
+ * coefficient times the G1 generator).  Fixed base: a signed 4-bit window table of g1, built once per context
+ * and staged in LDS by every workgroup -- 64 mixed additions and no doubling per coefficient. */
+int tc_g1_commitment_batch(tc_ctx* ctx, const uint8_t* coeff_fr, size_t M, uint8_t* out, uint8_t* status);
+/* BivarCommitment::row src/poly.rs:713-727 for M abscissae: out[m*(degree+1) + i] = sum_j commit[pos(i,j)] * xs[m]^j
+ * with commit the (degree+1)(degree+2)/2 coefficients of a symmetric bivariate commitment in coeff_pos order
+ * (src/poly.rs:746-750) and xs[m] the u64 `IntoFr` value itself (rows are requested as row(m), m = 0..N).
+ * BivarCommitment::evaluate(x, y) :694-710 is row(x) followed by tc_public_key_share_batch-style Horner in y;
+ * status[m*(degree+1) + i]. */
+int tc_bivar_commitment_row_batch(tc_ctx* ctx, const uint8_t* commit, size_t degree, const uint64_t* xs, size_t M, uint8_t* out,
+                                  uint8_t* status);
+/* Poly::interpolate src/poly.rs:341-350, 388-417 in Fr: for each of B jobs the n coefficients (low degree first,
+ * 32 B LE each; the reference's Poly drops trailing zeros) of the unique polynomial through the n samples
+ * (xs[j][k], ys[j][k]) (32 B LE canonical each, abscissae taken as given).  A repeated abscissa -- where the
+ * reference panics "sample points must be distinct" -- gives TC_JOB_DUPLICATE_ENTRY and zero coefficients. */
+int tc_fr_interpolate_batch(tc_ctx* ctx, size_t n, const uint8_t* xs, const uint8_t* ys, size_t B, uint8_t* out_coeff,
+                            uint8_t* status);
+
 /* ---- membership tests ------------------------------------------------------------------------ */
 /* ok[j] = 1 iff pts[j] decodes (range, flags, curve equation) and lies in the order-r subgroup: the
  * CHECKED half of `into_affine` (from_bytes, src/lib.rs:140-146, 246-252) for values that arrive

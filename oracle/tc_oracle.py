@@ -1059,3 +1059,85 @@ def signature_parity(sig):
     for b in g2_uncompressed(sig):
         x ^= b
     return bin(x).count('1') % 2 != 0
+
+
+# ---- DKG algebra (src/poly.rs), SURVEY.md 8f rank 4 ------------------------------------------------
+def coeff_pos(i, j):
+    """coeff_pos (src/poly.rs:746-750): position of coefficient (i, j) of a SYMMETRIC bivariate polynomial."""
+    if j < i:
+        i, j = j, i
+    return i + j * (j + 1) // 2
+
+
+def powers(x, degree):
+    """powers (src/poly.rs:734-743): x^0 .. x^degree in Fr."""
+    out, p = [], 1
+    for _ in range(degree + 1):
+        out.append(p)
+        p = p * x % R
+    return out
+
+
+def bivar_poly_row(degree, coeff, x):
+    """BivarPoly::row (src/poly.rs:606-622): the univariate polynomial f(x, .) as Fr coefficients."""
+    xp = powers(x % R, degree)
+    return [sum(coeff[coeff_pos(i, j)] * xp[j] for j in range(degree + 1)) % R for i in range(degree + 1)]
+
+
+def bivar_poly_evaluate(degree, coeff, x, y):
+    """BivarPoly::evaluate (src/poly.rs:587-603)."""
+    xp, yp = powers(x % R, degree), powers(y % R, degree)
+    return sum(coeff[coeff_pos(i, j)] * xp[i] * yp[j] for i in range(degree + 1) for j in range(degree + 1)) % R
+
+
+def bivar_commitment(coeff):
+    """BivarPoly::commitment (src/poly.rs:625-632): every coefficient times the G1 generator."""
+    return [E1.mul(G1_GEN, c % R) for c in coeff]
+
+
+def bivar_commitment_row(degree, commit, x):
+    """BivarCommitment::row (src/poly.rs:713-727): row[i] = sum_j commit[pos(i, j)] * x^j."""
+    xp = powers(x % R, degree)
+    row = []
+    for i in range(degree + 1):
+        acc = None
+        for j in range(degree + 1):
+            acc = E1.add(acc, E1.mul(commit[coeff_pos(i, j)], xp[j]))
+        row.append(acc)
+    return row
+
+
+def bivar_commitment_evaluate(degree, commit, x, y):
+    """BivarCommitment::evaluate (src/poly.rs:694-710)."""
+    xp, yp = powers(x % R, degree), powers(y % R, degree)
+    acc = None
+    for i in range(degree + 1):
+        for j in range(degree + 1):
+            acc = E1.add(acc, E1.mul(commit[coeff_pos(i, j)], xp[i] * yp[j] % R))
+    return acc
+
+
+def poly_interpolate(samples):
+    """Poly::interpolate / compute_interpolation (src/poly.rs:341-350, 388-417): the unique polynomial of
+    degree len(samples) - 1 through the (x, y) pairs (x taken as given, NOT + 1), built sample by sample
+    exactly as the reference does.  Raises ZeroDivisionError where the reference panics ("sample points must
+    be distinct")."""
+    if not samples:
+        return []
+    samples = [(x % R, y % R) for x, y in samples]
+    poly = [samples[0][1]]
+    base = [(-samples[0][0]) % R, 1]
+    for x, y in samples[1:]:
+        diff = (y - poly_evaluate(poly, x)) % R
+        base_val = poly_evaluate(base, x)
+        if base_val == 0:
+            raise ZeroDivisionError("sample points must be distinct")
+        diff = diff * pow(base_val, R - 2, R) % R
+        scaled = [c * diff % R for c in base]
+        poly = [((poly[k] if k < len(poly) else 0) + scaled[k]) % R for k in range(len(scaled))]
+        nb = [0] * (len(base) + 1)            # base *= (X - x)
+        for k, c in enumerate(base):
+            nb[k] = (nb[k] - c * x) % R
+            nb[k + 1] = (nb[k + 1] + c) % R
+        base = nb
+    return poly

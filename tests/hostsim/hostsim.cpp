@@ -2,6 +2,8 @@
 // the per-lane job bodies can be differential-tested against the oracle in a container
 // without a GPU.  Never linked into, loaded by, or used as a fallback for libtc_amd.so.
 #include "tc_jobs.h"
+#include "tc_dkg.h"
+#include <vector>
 #include <string.h>
 using namespace tc;
 
@@ -245,4 +247,24 @@ int hs_decompress_g1(const uint8_t* in, uint8_t* out) { return job_decompress<Fq
 int hs_decompress_g2(const uint8_t* in, uint8_t* out) { return job_decompress<Fq2>(in, out); }
 int hs_compress_g1(const uint8_t* in, uint8_t* out) { return job_compress<Fq>(in, out); }
 int hs_compress_g2(const uint8_t* in, uint8_t* out) { return job_compress<Fq2>(in, out); }
+
+// ---- DKG algebra (tc_dkg.h) ----------------------------------------------------------------------
+static std::vector<int32_t>& hs_fb_table() {
+  static std::vector<int32_t> t;
+  if (t.empty()) {
+    t.resize(kFbTableWords);
+    for (int e = 0; e < kFbWindows * kFbEntries; e++) fixed_base_table_entry(e, t.data() + (size_t)e * kFbPointWords);
+  }
+  return t;
+}
+int hs_g1_fixed_base_mul(const uint8_t* fr, uint8_t* out96) {
+  return job_g1_fixed_base_mul((const int32_t*)hs_fb_table().data(), fr, out96);
+}
+int hs_bivar_commitment_row(const uint8_t* commit, size_t degree, size_t i, uint64_t x, uint8_t* out96) {
+  return job_bivar_commitment_row(commit, degree, i, x, out96);
+}
+int hs_fr_interpolate(size_t n, const uint32_t* xs, const uint32_t* ys, uint32_t* out) {
+  std::vector<uint32_t> ws(2 * (n + 1) * 8);
+  return job_fr_interpolate(n, xs, ys, out, ws.data());
+}
 }

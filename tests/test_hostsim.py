@@ -525,3 +525,46 @@ def test_whole_suite_under_the_bound_analysis():
                         "-k", "not under_the_bound_analysis and not bound_check_build"],
                        capture_output=True, text=True, timeout=1800, env=env, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+# ---- DKG algebra (tc_dkg.h; src/poly.rs) ---------------------------------------------------------------
+def test_fixed_base_mul_matches_oracle(L, rnd):
+    """Poly::commitment (src/poly.rs:372-377): coefficient * g1 through the signed 4-bit window table."""
+    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88888888, o.R - 1, o.R - 2, (1 << 254) + 12345, int("8" * 63, 16) % o.R,
+          int("f" * 63, 16) % o.R] + [rnd.randrange(o.R) for _ in range(6)]
+    for k in ks:
+        out = buf(96)
+        assert L.hs_g1_fixed_base_mul(o.fr_to_bytes(k), out) == 0
+        assert out.raw == o.g1_uncompressed(o.E1.mul(o.G1_GEN, k)), hex(k)
+    assert L.hs_g1_fixed_base_mul(o.R.to_bytes(32, "little"), buf(96)) == 3   # non-canonical scalar
+
+
+def test_bivar_commitment_row_matches_oracle(L, rnd):
+    """BivarCommitment::row (src/poly.rs:713-727)."""
+    d = 2
+    coeff = [rnd.randrange(o.R) for _ in range((d + 1) * (d + 2) // 2)]
+    commit = o.bivar_commitment(coeff)
+    blob = b"".join(o.g1_uncompressed(c) for c in commit)
+    for x in (0, 1, 2, 5, 2 ** 63 + 5):
+        want = o.bivar_commitment_row(d, commit, x)
+        assert want == o.commitment(o.bivar_poly_row(d, coeff, x))          # row_poly.commitment() == row_commit (:847)
+        for i in range(d + 1):
+            out = buf(96)
+            assert L.hs_bivar_commitment_row(blob, d, i, ctypes.c_uint64(x), out) == 0
+            assert out.raw == o.g1_uncompressed(want[i]), (x, i)
+
+
+def test_fr_interpolate_matches_oracle(L, rnd):
+    """Poly::interpolate (src/poly.rs:341-350, 388-417)."""
+    def words(vals):
+        return (ctypes.c_uint32 * (8 * len(vals)))(*[(v >> (32 * i)) & 0xffffffff for v in vals for i in range(8)])
+    for n in (1, 2, 3, 6):
+        f = [rnd.randrange(o.R) for _ in range(n)]
+        xs = rnd.sample(range(1, 50), n)
+        ys = [o.poly_evaluate(f, x) for x in xs]
+        out = (ctypes.c_uint32 * (8 * n))()
+        assert L.hs_fr_interpolate(n, words(xs), words(ys), out) == 0
+        got = [sum(out[8 * k + i] << (32 * i) for i in range(8)) for k in range(n)]
+        assert got == f == o.poly_interpolate(list(zip(xs, ys)))
+    out = (ctypes.c_uint32 * 24)()
+    assert L.hs_fr_interpolate(3, words([4, 9, 4]), words([1, 2, 3]), out) == 2   # repeated abscissa

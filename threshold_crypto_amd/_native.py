@@ -44,6 +44,9 @@ PROTOTYPES = {
     "tc_verify_decryption_share_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p],
     "tc_encrypt_batch": [_u8p, _sz, _u8p, _u8p, _u64p, _sz, _u8p, _u8p, _u8p, _u8p],
     "tc_public_key_share_batch": [_u8p, _sz, _u64p, _sz, _u8p, _u8p],
+    "tc_g1_commitment_batch": [_u8p, _sz, _u8p, _u8p],
+    "tc_bivar_commitment_row_batch": [_u8p, _sz, _u64p, _sz, _u8p, _u8p],
+    "tc_fr_interpolate_batch": [_sz, _u8p, _u8p, _sz, _u8p, _u8p],
     "tc_g1_subgroup_check_batch": [_u8p, _sz, _u8p],
     "tc_g2_subgroup_check_batch": [_u8p, _sz, _u8p],
     "tc_g1_compress_batch": [_u8p, _sz, _u8p, _u8p],

@@ -35,6 +35,8 @@ struct tc_ctx {
   // its last constant multiplication (tc_gls.h g2_clear_cofactor): e(pk, [c] Q') == e(g1, sig)  <=>
   // e(pk, Q') == e([1/c] g1, sig)
   uint8_t* g1_gen_unfix = nullptr;
+  int32_t* fb_table = nullptr;  // signed 4-bit window table of the G1 generator (tc_dkg.h), built on first use
+  int cus = 0;
 };
 
 namespace {
@@ -215,6 +217,10 @@ int tc_ctx_create(tc_ctx** out, int device) {
     return TC_ERR_HIP;
   }
   c->stream = c->own_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount;
+  }
   tc::launch_fill_g1_generator(c->stream, c->g1_gen, c->g1_gen_unfix);
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
     // typically: no gfx950 code object for this device
@@ -232,6 +238,7 @@ void tc_ctx_destroy(tc_ctx* c) {
     if (s.p) (void)hipFree(s.p);
   if (c->g1_gen) (void)hipFree(c->g1_gen);
   if (c->g1_gen_unfix) (void)hipFree(c->g1_gen_unfix);
+  if (c->fb_table) (void)hipFree(c->fb_table);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -652,6 +659,64 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
     tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok);
   }
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
+  k.end_timing();
+  return k.finish();
+}
+
+// ---- DKG algebra -----------------------------------------------------------------------------------
+int tc_g1_commitment_batch(tc_ctx* ctx, const uint8_t* coeff_fr, size_t M, uint8_t* out, uint8_t* status) {
+  TC_REQUIRE(ctx);
+  if (M == 0) return TC_OK;
+  TC_REQUIRE(ctx && coeff_fr && out);
+  Call k(ctx);
+  if (!ctx->fb_table && !k.failed) {
+    if (k.check(hipMalloc((void**)&ctx->fb_table, tc::fixed_base_table_bytes()), "hipMalloc"))
+      tc::launch_fixed_base_table(ctx->stream, ctx->fb_table);
+  }
+  const uint8_t* d_fr = k.in(coeff_fr, M * 32, /*secret=*/true);
+  uint8_t* d_out = k.out(out, M * 96);
+  uint8_t* d_st = k.out(status, M);
+  k.begin_timing();
+  if (!k.failed) tc::launch_g1_fixed_base(ctx->stream, ctx->fb_table, d_fr, M, d_out, d_st, ctx->cus);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_bivar_commitment_row_batch(tc_ctx* ctx, const uint8_t* commit, size_t degree, const uint64_t* xs, size_t M, uint8_t* out,
+                                  uint8_t* status) {
+  TC_REQUIRE(ctx);
+  if (M == 0) return TC_OK;
+  TC_REQUIRE(ctx && commit && xs && out);
+  TC_REQUIRE(degree < (1u << 16));
+  const size_t ncoeff = (degree + 1) * (degree + 2) / 2;
+  Call k(ctx);
+  const uint8_t* d_c = k.in(commit, ncoeff * 96);
+  const uint64_t* d_x = k.in(xs, M);
+  uint8_t* d_out = k.out(out, M * (degree + 1) * 96);
+  uint8_t* d_st = k.out(status, M * (degree + 1));
+  k.begin_timing();
+  k.check_points(false, d_c, 96, ncoeff, ncoeff, 1, (size_t)-1);
+  if (!k.failed) tc::launch_bivar_commitment_row(ctx->stream, d_c, degree, d_x, M, d_out, d_st);
+  k.apply_checks(M * (degree + 1), d_st, d_out, 96, nullptr);
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_fr_interpolate_batch(tc_ctx* ctx, size_t n, const uint8_t* xs, const uint8_t* ys, size_t B, uint8_t* out_coeff, uint8_t* status) {
+  TC_REQUIRE(ctx);
+  if (B == 0 || n == 0) return TC_OK;
+  TC_REQUIRE(ctx && xs && ys && out_coeff);
+  TC_REQUIRE(n < (1u << 16));
+  Call k(ctx);
+  const uint8_t* d_x = k.in(xs, B * n * 32);
+  const uint8_t* d_y = k.in(ys, B * n * 32, /*secret=*/true);
+  uint8_t* d_out = k.out(out_coeff, B * n * 32);
+  uint32_t* d_ws = k.temp<uint32_t>(B * 2 * (n + 1) * 8);
+  if (d_ws) k.wipe.emplace_back(d_ws, B * 2 * (n + 1) * 8 * sizeof(uint32_t));
+  uint8_t* d_st = k.out(status, B);
+  k.begin_timing();
+  if (!k.failed)
+    tc::launch_fr_interpolate(ctx->stream, n, (const uint32_t*)d_x, (const uint32_t*)d_y, B, (uint32_t*)d_out, d_ws, d_st);
   k.end_timing();
   return k.finish();
 }

@@ -71,6 +71,14 @@ void launch_encrypt(hipStream_t st, const uint8_t* pk, size_t pk_stride, const u
                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status);
 void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                                 uint8_t* status);
+// DKG algebra (k_dkg.hip): the fixed-base window table of the G1 generator is built once per context
+size_t fixed_base_table_bytes();
+void launch_fixed_base_table(hipStream_t st, int32_t* tbl);
+void launch_g1_fixed_base(hipStream_t st, const int32_t* tbl, const uint8_t* fr, size_t M, uint8_t* out, uint8_t* status, int cus);
+void launch_bivar_commitment_row(hipStream_t st, const uint8_t* commit, size_t degree, const uint64_t* xs, size_t M, uint8_t* out,
+                                 uint8_t* status);
+void launch_fr_interpolate(hipStream_t st, size_t n, const uint32_t* xs, const uint32_t* ys, size_t B, uint32_t* out, uint32_t* ws,
+                           uint8_t* status);
 void launch_fill_g1_generator(hipStream_t st, uint8_t* out96, uint8_t* out96_unfix);
 
 }  // namespace tc

@@ -362,3 +362,37 @@ class Engine:
         st = self._empty(dev, (M,), ref=commit)
         self._call("tc_public_key_share_batch", _ptr(commit), int(t), _ptr(idx), M, _ptr(out), _ptr(st))
         return out, st
+
+    # -- DKG algebra (src/poly.rs) ------------------------------------------------------------------------
+    def g1_commitment(self, coeff_fr):
+        """out[i] = coeff_fr[i] * g1 (Poly::commitment / BivarPoly::commitment): fixed-base, LDS window table"""
+        dev = self._mode(coeff_fr)
+        self._arg(coeff_fr, (None, FR_BYTES), "u8", "coeff_fr")
+        M = coeff_fr.shape[0]
+        out = self._empty(dev, (M, G1_BYTES), ref=coeff_fr)
+        st = self._empty(dev, (M,), ref=coeff_fr)
+        self._call("tc_g1_commitment_batch", _ptr(coeff_fr), M, _ptr(out), _ptr(st))
+        return out, st
+
+    def bivar_commitment_rows(self, commit, degree, xs):
+        """BivarCommitment::row(xs[m]) for every m: (M, degree+1, 96)"""
+        dev = self._mode(commit, xs)
+        n = (degree + 1) * (degree + 2) // 2
+        self._arg(commit, (n, G1_BYTES), "u8", "commit")
+        self._arg(xs, (None,), "u64", "xs")
+        M = xs.shape[0]
+        out = self._empty(dev, (M, degree + 1, G1_BYTES), ref=commit)
+        st = self._empty(dev, (M, degree + 1), ref=commit)
+        self._call("tc_bivar_commitment_row_batch", _ptr(commit), int(degree), _ptr(xs), M, _ptr(out), _ptr(st))
+        return out, st
+
+    def fr_interpolate(self, xs, ys):
+        """Poly::interpolate for B jobs of n samples: xs, ys (B, n, 32) -> coefficients (B, n, 32), status (B,)"""
+        dev = self._mode(xs, ys)
+        self._arg(xs, (None, None, FR_BYTES), "u8", "xs")
+        B, n = xs.shape[0], xs.shape[1]
+        self._arg(ys, (B, n, FR_BYTES), "u8", "ys")
+        out = self._empty(dev, (B, n, FR_BYTES), ref=xs)
+        st = self._empty(dev, (B,), ref=xs)
+        self._call("tc_fr_interpolate_batch", int(n), _ptr(xs), _ptr(ys), B, _ptr(out), _ptr(st))
+        return out, st
