@@ -299,3 +299,42 @@ def test_malformed_offsets_are_rejected(engine):
         engine.combine_g2(1, np.zeros((1, 2), dtype=np.uint64), np.zeros((1, 3, 192), dtype=np.uint8))
     with pytest.raises(ValueError):
         engine.verify_g2(np.zeros(96, np.uint8), np.zeros((4, 192), np.uint8)[:, ::-1], np.zeros((4, 192), np.uint8))
+
+
+def test_rlc_share_validation_equals_per_share_path(engine):
+    """tc_verify_shares_rlc_batch (opt-in): the ok-matrix of a batch with planted bad shares -- a wrong signer's
+    share, a share of another message, an off-curve encoding, the identity -- equals the per-share
+    PublicKeyShare::verify path's (src/lib.rs:177-179; the loop of examples/threshold_sig.rs:115-131), and only
+    the affected messages take the per-share fallback."""
+    from threshold_crypto_amd.workload import key_set, messages
+    t, N, B = 3, 10, 96
+    sks = key_set(t)
+    shares_sk = [sks.secret_key_share(i) for i in range(N)]
+    fr = np.stack([u8(s._bytes()) for s in shares_sk])
+    msgs = messages(B)
+    flat, off = pack_messages(msgs)
+    sig, st = engine.sign(fr, flat, off)                      # (B, N, 192)
+    assert not st.any()
+    commit = np.stack([u8(c) for c in sks.public_keys(engine).commit])
+    pks, st = engine.public_key_shares(commit, np.arange(N, dtype=np.uint64))
+    assert not st.any()
+    bad = sig.copy()
+    bad[5, 3] = sig[5, 4]            # node 3 sends node 4's share
+    bad[17, 0] = sig[18, 0]          # a share of another message
+    bad[40, 9, 100] ^= 1             # not on the curve
+    bad[41, 2] = u8(o.g2_uncompressed(None))   # the identity
+    bad[95, 7] = sig[95, 6]
+    expect = np.ones((B, N), dtype=np.uint8)
+    for j, i in ((5, 3), (17, 0), (40, 9), (41, 2), (95, 7)):
+        expect[j, i] = 0
+    # per-share path: N*B pairing checks with hashing
+    rep_flat, rep_off = pack_messages([m for m in msgs for _ in range(N)])
+    per_share = engine.verify_sig(np.ascontiguousarray(np.broadcast_to(pks[None], (B, N, 96)).reshape(B * N, 96)),
+                                  np.ascontiguousarray(bad.reshape(B * N, 192)), rep_flat, rep_off).reshape(B, N)
+    assert (per_share == expect).all()
+    ok, nfb = engine.verify_shares_rlc(pks, bad, flat, off, seed=bytes(range(32)))
+    assert (ok == expect).all() and nfb == 5
+    ok, nfb = engine.verify_shares_rlc(pks, sig, flat, off)   # all valid: no fallback at all
+    assert ok.all() and nfb == 0
+    # one of the oracle's own checks on a sampled share
+    assert c.verify(bytes(pks[3]), bytes(bad[5, 3]), msgs[5]) == 0 and c.verify(bytes(pks[4]), bytes(bad[5, 3]), msgs[5]) == 1

@@ -45,6 +45,46 @@ __global__ void k_invalidate_jobs(const uint8_t* __restrict__ valid, size_t per_
   }
 }
 
+// r[i] = a non-zero 64-bit scalar (32 B LE, upper bytes zero) from ChaCha20(key = seed, block counter = i):
+// unpredictable to whoever produced the shares as long as the seed is drawn after they were received
+__global__ void k_rlc_scalars(const uint8_t* __restrict__ seed32, size_t n, uint8_t* __restrict__ out_fr) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t key[8];
+  for (int w = 0; w < 8; w++)
+    key[w] = (uint32_t)seed32[4 * w] | ((uint32_t)seed32[4 * w + 1] << 8) | ((uint32_t)seed32[4 * w + 2] << 16) | ((uint32_t)seed32[4 * w + 3] << 24);
+  ChaChaRng rng;
+  rng.init(key);
+  rng.counter = i;
+  const uint32_t lo = rng.next_u32() | 1u, hi = rng.next_u32();
+  for (int b = 0; b < 32; b++) out_fr[i * 32 + b] = 0;
+  for (int b = 0; b < 4; b++) {
+    out_fr[i * 32 + b] = (uint8_t)(lo >> (8 * b));
+    out_fr[i * 32 + 4 + b] = (uint8_t)(hi >> (8 * b));
+  }
+}
+__global__ void k_gather_rows(const uint8_t* __restrict__ src, size_t row_words, const uint32_t* __restrict__ map, size_t rows,
+                              uint8_t* __restrict__ dst) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;  // one 8-byte word per lane: coalesced within a row
+  if (t >= rows * row_words) return;
+  const size_t r = t / row_words, w = t % row_words;
+  reinterpret_cast<uint64_t*>(dst)[t] = reinterpret_cast<const uint64_t*>(src)[(size_t)map[r] * row_words + w];
+}
+__global__ void k_scatter_bytes(const uint8_t* __restrict__ src, const uint32_t* __restrict__ map, size_t rows, uint8_t* __restrict__ dst) {
+  const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < rows) dst[map[r]] = src[r];
+}
+void launch_rlc_scalars(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr) {
+  if (n) hipLaunchKernelGGL(k_rlc_scalars, dim3(grid_for(n)), dim3(kBlock), 0, st, seed32, n, out_fr);
+}
+void launch_gather_rows(hipStream_t st, const uint8_t* src, size_t row_bytes, const uint32_t* map, size_t rows, uint8_t* dst) {
+  const size_t words = rows * (row_bytes / 8);
+  if (words) hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(words)), dim3(kBlock), 0, st, src, row_bytes / 8, map, rows, dst);
+}
+void launch_scatter_bytes(hipStream_t st, const uint8_t* src, const uint32_t* map, size_t rows, uint8_t* dst) {
+  if (rows) hipLaunchKernelGGL(k_scatter_bytes, dim3(grid_for(rows)), dim3(kBlock), 0, st, src, map, rows, dst);
+}
+
 void launch_subgroup_check_g1(hipStream_t st, const uint8_t* pts, size_t stride, size_t n_per_job, size_t take, size_t n,
                               uint8_t* valid) {
   if (n) hipLaunchKernelGGL(k_subgroup_check<Fq>, dim3(grid_for(n)), dim3(kBlock), 0, st, pts, stride, n_per_job, take, n, valid);

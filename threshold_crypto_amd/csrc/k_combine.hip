@@ -115,27 +115,28 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
-// one lane per job: sum_i scalar_i * point_i with caller-supplied scalars (32 B LE each)
+// one lane per job: sum_i scalar_i * point_i with caller-supplied scalars (32 B LE each); the points of job
+// j start at points + j * pts_stride (n * PB for per-job points, 0 for ONE point set shared by every job)
 template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
-                                                    const uint8_t* __restrict__ points, size_t B,
+                                                    const uint8_t* __restrict__ points, size_t pts_stride, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   if (j >= B) return;
-  uint8_t st = job_lincomb<F>((int)n, points + j * n * PB, reinterpret_cast<const uint32_t*>(scalars + j * n * 32),
+  uint8_t st = job_lincomb<F>((int)n, points + j * pts_stride, reinterpret_cast<const uint32_t*>(scalars + j * n * 32),
                               out + j * PB);
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                       uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_lincomb<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, B, out, status);
+                       uint8_t* status, bool shared_points) {
+  if (B) hipLaunchKernelGGL(k_lincomb<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 96, B, out, status);
 }
 void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                       uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, scalars, points, B, out, status);
+                       uint8_t* status, bool shared_points) {
+  if (B) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 192, B, out, status);
 }
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,

@@ -597,6 +597,103 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
   return k.finish();
 }
 
+// Share validation by ONE random linear combination per message (opt-in fast path of the loop at
+// examples/threshold_sig.rs:115-131): instead of N pairing checks  e(pk_i, H(m)) == e(g1, sig_i)  the device
+// checks  e(sum_i r_i pk_i, H(m)) == e(g1, sum_i r_i sig_i)  with secret 64-bit r_i, which holds whenever all N
+// do and fails with probability >= 1 - 2^-64 otherwise; messages whose combined check fails are re-checked
+// share by share, so ok[] equals the per-share path's (up to that 2^-64).
+int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* sig_shares, const uint8_t* msgs,
+                               const uint64_t* off, size_t B, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+  TC_REQUIRE(ctx);
+  if (n_fallback) *n_fallback = 0;
+  if (B == 0 || N == 0) return TC_OK;
+  TC_REQUIRE(ctx && pk_shares && sig_shares && off && seed32 && ok);
+  TC_REQUIRE(B * N < (1ull << 32));
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || msgs);
+  const uint8_t* d_pk = k.in(pk_shares, N * 96);
+  const uint8_t* d_sig = k.in(sig_shares, B * N * 192);
+  const uint8_t* d_msgs = k.in(msgs, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  // the seed is host memory in both I/O modes (32 bytes; it must stay secret until the call returns)
+  uint8_t* d_seed = k.temp<uint8_t>(32);
+  if (d_seed) {
+    k.check(hipMemcpyAsync(d_seed, seed32, 32, hipMemcpyHostToDevice, ctx->stream), "seed copy");
+    k.wipe.emplace_back(d_seed, 32);
+  }
+  uint8_t* d_r = k.temp<uint8_t>(B * N * 32);
+  if (d_r) k.wipe.emplace_back(d_r, B * N * 32);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_S = k.temp<uint8_t>(B * 192);
+  uint8_t* d_P = k.temp<uint8_t>(B * 96);
+  uint8_t* d_stS = k.temp<uint8_t>(B);
+  uint8_t* d_okmsg = k.temp<uint8_t>(B);
+  uint8_t* d_ok = k.out(ok, B * N);
+  k.begin_timing();
+  k.check_points(false, d_pk, 96, N, N, 1, (size_t)-1);
+  k.check_points(true, d_sig, 192, N, N, B, 1);
+  std::vector<uint8_t> h_okmsg(B);
+  if (!k.failed) {
+    tc::launch_rlc_scalars(ctx->stream, d_seed, B * N, d_r);
+    tc::launch_lincomb_g2(ctx->stream, N, d_r, d_sig, B, d_S, d_stS);
+    tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
+    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
+    // e(P, [c] Q') == e(g1, S)  <=>  e(P, Q') == e([1/c] g1, S)   (the folded hash constant of tc_verify_sig_batch)
+    tc::launch_pairing_check(ctx->stream, d_P, 96, d_hash, 192, ctx->g1_gen_unfix, 0, d_S, 192, B, d_okmsg);
+    // a share that does not decode (status below) or, in checked-input mode, is no group member sends its
+    // message to the per-share fallback
+    k.apply_checks(B, nullptr, nullptr, 0, d_okmsg);
+    k.check(hipMemsetAsync(d_ok, 1, B * N, ctx->stream), "memset");
+    k.check(hipMemcpyAsync(h_okmsg.data(), d_okmsg, B, hipMemcpyDeviceToHost, ctx->stream), "ok readback");
+    std::vector<uint8_t> h_stS(B);
+    k.check(hipMemcpyAsync(h_stS.data(), d_stS, B, hipMemcpyDeviceToHost, ctx->stream), "status readback");
+    k.check(hipStreamSynchronize(ctx->stream), "stream sync");
+    std::vector<uint32_t> failed;
+    if (!k.failed)
+      for (size_t j = 0; j < B; j++)
+        if (!h_okmsg[j] || h_stS[j] != TC_JOB_OK) failed.push_back((uint32_t)j);
+    if (!k.failed && !failed.empty()) {
+      // per-share pairing checks for every share of the failed messages, on compacted operands
+      const size_t F = failed.size(), R = F * N;
+      std::vector<uint32_t> m_sig(R), m_hash(R), m_pk(R);
+      for (size_t f = 0; f < F; f++)
+        for (size_t i = 0; i < N; i++) {
+          m_sig[f * N + i] = (uint32_t)(failed[f] * N + i);
+          m_hash[f * N + i] = failed[f];
+          m_pk[f * N + i] = (uint32_t)i;
+        }
+      uint32_t* d_maps = k.temp<uint32_t>(3 * R);
+      uint8_t* c_sig = k.temp<uint8_t>(R * 192);
+      uint8_t* c_hash = k.temp<uint8_t>(R * 192);
+      uint8_t* c_pk = k.temp<uint8_t>(R * 96);
+      uint8_t* c_ok = k.temp<uint8_t>(R);
+      if (!k.failed) {
+        k.check(hipMemcpyAsync(d_maps, m_sig.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        k.check(hipMemcpyAsync(d_maps + R, m_hash.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        k.check(hipMemcpyAsync(d_maps + 2 * R, m_pk.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        tc::launch_gather_rows(ctx->stream, d_sig, 192, d_maps, R, c_sig);
+        tc::launch_gather_rows(ctx->stream, d_hash, 192, d_maps + R, R, c_hash);
+        tc::launch_gather_rows(ctx->stream, d_pk, 96, d_maps + 2 * R, R, c_pk);
+        tc::launch_pairing_check(ctx->stream, c_pk, 96, c_hash, 192, ctx->g1_gen_unfix, 0, c_sig, 192, R, c_ok);
+        if (ctx->input_checks) {  // members only, as the per-share path would require
+          uint8_t* v = k.temp<uint8_t>(R);
+          tc::launch_subgroup_check_g2(ctx->stream, c_sig, 192, 1, 1, R, v);
+          tc::launch_invalidate_jobs(ctx->stream, v, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          tc::launch_subgroup_check_g1(ctx->stream, c_pk, 96, 1, 1, R, v);
+          tc::launch_invalidate_jobs(ctx->stream, v, 1, 1, R, nullptr, nullptr, 0, c_ok);
+        }
+        tc::launch_scatter_bytes(ctx->stream, c_ok, d_maps, R, d_ok);
+        k.check(hipStreamSynchronize(ctx->stream), "stream sync");  // the host maps go out of scope
+      }
+      if (n_fallback) *n_fallback = F;
+    }
+  }
+  k.end_timing();
+  return k.finish();
+}
+
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, const uint64_t* off,
                                const uint8_t* w, size_t B, uint8_t* ok) {
   TC_REQUIRE(ctx);

@@ -39,10 +39,16 @@ size_t combine_group_slots(size_t B);
 void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
                        uint32_t* perm, const uint32_t* need_general);
+// shared_points: every job combines the SAME n points (points holds n of them) with its own n scalars
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                       uint8_t* status);
+                       uint8_t* status, bool shared_points = false);
 void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                       uint8_t* status);
+                       uint8_t* status, bool shared_points = false);
+// random-linear-combination share validation (k_check.hip): 64-bit scalars from a ChaCha20 stream keyed
+// by the caller's seed; row gather / byte scatter for the per-share fallback of failed messages
+void launch_rlc_scalars(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr);
+void launch_gather_rows(hipStream_t st, const uint8_t* src, size_t row_bytes, const uint32_t* map, size_t rows, uint8_t* dst);
+void launch_scatter_bytes(hipStream_t st, const uint8_t* src, const uint32_t* map, size_t rows, uint8_t* dst);
 
 // opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
 // records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an

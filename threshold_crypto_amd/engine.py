@@ -277,6 +277,25 @@ class Engine:
                    _ptr(ok))
         return ok
 
+    def verify_shares_rlc(self, pk_shares, sig_shares, msgs, off, seed=None):
+        """Share validation by one random linear combination per message (opt-in; see tc_amd.h): returns
+        (ok (B, N), number of messages that fell back to per-share checks).  `seed`: 32 secret random bytes
+        (os.urandom when omitted)."""
+        import os
+        dev = self._mode(pk_shares, sig_shares, msgs, off)
+        self._arg(pk_shares, (None, G1_BYTES), "u8", "pk_shares")
+        N = pk_shares.shape[0]
+        B = self._msgs(msgs, off)
+        self._arg(sig_shares, (B, N, G2_BYTES), "u8", "sig_shares")
+        seed = bytes(seed) if seed is not None else os.urandom(32)
+        if len(seed) != 32:
+            raise ValueError("seed: 32 bytes")
+        ok = self._empty(dev, (B, N), ref=sig_shares)
+        nfb = ctypes.c_uint64(0)
+        self._call("tc_verify_shares_rlc_batch", _ptr(pk_shares), N, _ptr(sig_shares), _ptr(msgs), _ptr(off), B, seed, _ptr(ok),
+                   ctypes.byref(nfb))
+        return ok, int(nfb.value)
+
     def ciphertext_verify(self, u, v, off, w):
         dev = self._mode(u, v, off, w)
         self._arg(u, (None, G1_BYTES), "u8", "u")
