@@ -102,6 +102,12 @@ int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, con
  * SecretKey::sign_g2 src/lib.rs:372-374, SecretKeyShare::sign_g2 :442-444 */
 int tc_g2_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                     uint8_t* status);
+/* out[j*n + k] = sk_table[idx[j*n + k]] * hashes[j]: the signature shares of message j by the n signers of its
+ * subset, out of a table of N secret key shares (SecretKeyShare::sign_g2 src/lib.rs:442-444 for each selected
+ * signer) -- the on-device share generation of the (t, N, batch) workloads, so that nothing larger than the key
+ * set crosses PCIe.  An index >= N fails its own output (TC_JOB_INVALID_ENCODING). */
+int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, const uint64_t* idx, const uint8_t* hashes, size_t n,
+                            size_t B, uint8_t* out, uint8_t* status);
 /* SecretKeyShare::decrypt_share_no_verify src/lib.rs:460-462, SecretKey::public_key :367-369 */
 int tc_g1_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                     uint8_t* status);

@@ -127,6 +127,20 @@ res["combine_g2_t3_fast_denominator_pow2"] = (class_combine(lambda d: d > 1 and 
 res["combine_g2_t3_general"] = (avg_combine(True, True, 8), 2)
 res["combine_g1_t3_fast"] = (avg_combine(False, False), 1)
 res["combine_g1_t3_general"] = (avg_combine(False, True, 8), 1)
+# BASELINE config 5 shape: one t = 67 combination through the two-stage path (k_lagrange_all's Fr work is not
+# v_mad_i64_i32 work and is not counted: the saturated 8 x 32 Fr multiplier issues v_mad_u64_u32)
+poly67 = [rnd.randrange(o.R) for _ in range(68)]
+ids67 = sorted(rnd.sample(range(200), 68))
+_sh = []
+for i in ids67:
+    b_ = buf(192)
+    L.hs_g2_mul(o.fr_to_bytes(o.secret_key_share(poly67, i)), o.g2_uncompressed(P2), b_)
+    _sh.append(b_.raw)
+cnt()
+_out = buf(192)
+assert L.hs_combine_g2(67, (ctypes.c_uint64 * 68)(*ids67), b"".join(_sh), _out) == 0
+res["combine_g2_t67_msm"] = (cnt(), 2)
+assert _out.raw == o.g2_uncompressed(o.E2.mul(P2, poly67[0]))
 a = rnd.randrange(o.R)
 L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
                    o.g2_uncompressed(o.E2.mul(P2, a))); res["verify_g2"] = (cnt(), 2)

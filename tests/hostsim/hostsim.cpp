@@ -3,6 +3,7 @@
 // without a GPU.  Never linked into, loaded by, or used as a fallback for libtc_amd.so.
 #include "tc_jobs.h"
 #include "tc_dkg.h"
+#include "tc_msm.h"
 #include <vector>
 #include <string.h>
 using namespace tc;
@@ -96,6 +97,7 @@ void hs_fr_inverse_of_small(uint64_t d_abs, int d_neg, uint8_t* out32le) {
   fr_inverse_of_small(d_abs, d_neg != 0, w);
   memcpy(out32le, w, 32);
 }
+static int hs_combine_g2_large(int t, const uint64_t* idx, const uint8_t* shares, uint32_t* lam, uint8_t* out);
 static int g_force_general = 0;
 void hs_force_general_combine(int on) { g_force_general = on; }
 static int combine(int g2, int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) {
@@ -114,6 +116,9 @@ static int combine(int g2, int t, const uint64_t* idx, const uint8_t* shares, ui
       if (t == 3) done = job_combine_small<Fq, 4>(idx, shares, out, &st);
     }
     if (done) return st;
+  }
+  if (g2 && (size_t)(t + 1) >= 8 && !g_force_general) {  // the large-threshold dispatch of tc_api.hip: k_lagrange_all + k_msm_*
+    return hs_combine_g2_large(t, idx, shares, lam, out);
   }
   for (int i = 0; i <= t; i++) {
     int st = job_lagrange(idx, t, i, lam + 8 * i);
@@ -267,4 +272,36 @@ int hs_fr_interpolate(size_t n, const uint32_t* xs, const uint32_t* ys, uint32_t
   std::vector<uint32_t> ws(2 * (n + 1) * 8);
   return job_fr_interpolate(n, xs, ys, out, ws.data());
 }
+
+// ---- two-stage G2 linear combination (tc_msm.h): stage T for every chunk, then stage L ----------------------
+int hs_msm_g2(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out192) {
+  const size_t chunks = msm_chunks(n), shares4 = chunks * kMsmChunk;
+  std::vector<int32_t> tbl(shares4 * 8 * kMsmEntryWords);
+  std::vector<uint8_t> codes(kMsmColumns * shares4);
+  bool ok = true;
+  for (size_t c = 0; c < chunks; c++) ok &= job_msm_tables(n, c, points, scalars, tbl.data(), codes.data(), true);
+  if (!ok) {
+    g2_encode_uncompressed(G2Affine::infinity(), out192);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  g2_encode_uncompressed(jac_to_affine(job_msm_ladder(n, tbl.data(), codes.data())), out192);
+  return TC_JOB_OK;
+}
+
+int hs_lagrange_all(const uint64_t* idx, int t, uint32_t* out) {
+  std::vector<uint32_t> ws(4 * (size_t)(t + 1) * 8);
+  return lagrange_all_at_zero(idx, t, out, ws.data());
+}
+
+}  // extern "C"
+static int hs_combine_g2_large(int t, const uint64_t* idx, const uint8_t* shares, uint32_t* lam, uint8_t* out) {
+  std::vector<uint32_t> ws(4 * (size_t)(t + 1) * 8);
+  int st = lagrange_all_at_zero(idx, t, lam, ws.data());
+  if (st) {
+    g2_encode_uncompressed(G2Affine::infinity(), out);
+    return st;
+  }
+  return hs_msm_g2((size_t)t + 1, shares, lam, out);
+}
+extern "C" {
 }

@@ -568,3 +568,36 @@ def test_fr_interpolate_matches_oracle(L, rnd):
         assert got == f == o.poly_interpolate(list(zip(xs, ys)))
     out = (ctypes.c_uint32 * 24)()
     assert L.hs_fr_interpolate(3, words([4, 9, 4]), words([1, 2, 3]), out) == 2   # repeated abscissa
+
+
+def test_two_stage_msm_matches_oracle(L, rnd):
+    """tc_msm.h (large-threshold share combination): n = 9 and 13 points incl. the identity, zero / even / odd /
+    maximal scalars -- tables + digit codes + one ladder == sum_i s_i P_i."""
+    for n in (9, 13):
+        pts = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(n)]
+        pts[2] = None
+        sc = [rnd.randrange(o.R) for _ in range(n)]
+        sc[0], sc[1], sc[3], sc[4] = 0, o.R - 1, 2, 1
+        want = None
+        for p, s in zip(pts, sc):
+            want = o.E2.add(want, o.E2.mul(p, s))
+        words = (ctypes.c_uint32 * (8 * n))(*[(s >> (32 * i)) & 0xffffffff for s in sc for i in range(8)])
+        out = buf(192)
+        assert L.hs_msm_g2(n, b"".join(o.g2_uncompressed(p) for p in pts), words, out) == 0
+        assert out.raw == o.g2_uncompressed(want), n
+    bad = bytearray(b"".join(o.g2_uncompressed(p) for p in pts))
+    bad[192 * 5 + 100] ^= 1
+    assert L.hs_msm_g2(n, bytes(bad), words, buf(192)) == 3
+
+
+def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
+    """tc_threshold.h lagrange_all_at_zero == the reference's per-coefficient construction (src/lib.rs:739-763),
+    including repeated indices (filtered by VALUE out of the denominator, :758) and u64 edge values."""
+    cases = [sorted(rnd.sample(range(200), 68)), [5, 9, 5, 7, 9, 11, 2, 40, 41], [0, 2 ** 64 - 1, 2 ** 63, 1, 3, 9, 27, 81, 243],
+             list(range(10))]
+    for ids in cases:
+        t = len(ids) - 1
+        out = (ctypes.c_uint32 * (8 * (t + 1)))()
+        assert L.hs_lagrange_all((ctypes.c_uint64 * len(ids))(*ids), t, out) == 0
+        got = [sum(out[8 * k + i] << (32 * i) for i in range(8)) for k in range(t + 1)]
+        assert got == o.lagrange_coeffs(t, [o.into_fr_plus_1(i) for i in ids]), ids

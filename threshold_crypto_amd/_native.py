@@ -30,6 +30,7 @@ PROTOTYPES = {
     "tc_hash_g1_g2_batch": [_u8p, _u8p, _u64p, _sz, _u8p, _u8p],
     "tc_g2_mul_batch": [_u8p, _u8p, _sz, _sz, _u8p, _u8p],
     "tc_g1_mul_batch": [_u8p, _u8p, _sz, _sz, _u8p, _u8p],
+    "tc_sign_shares_g2_batch": [_u8p, _sz, _u64p, _u8p, _sz, _sz, _u8p, _u8p],
     "tc_sign_batch": [_u8p, _u8p, _u64p, _sz, _sz, _u8p, _u8p],
     "tc_combine_g2_batch": [_sz, _sz, _u64p, _u8p, _sz, _u8p, _u8p],
     "tc_combine_g1_batch": [_sz, _sz, _u64p, _u8p, _sz, _u8p, _u8p],

@@ -22,6 +22,17 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t
   if (st && status) status[j] = st;
 }
 
+// one lane per JOB: all t+1 coefficients with one inversion (tc_threshold.h lagrange_all_at_zero); used for the
+// large thresholds, where no job takes the small-index fast path
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange_all(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
+                                                                    uint32_t* __restrict__ lam, uint32_t* __restrict__ ws,
+                                                                    uint8_t* __restrict__ status) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  const uint8_t st = lagrange_all_at_zero(idx + j * n_per_job, (int)t, lam + j * (t + 1) * 8, ws + j * 4 * (t + 1) * 8);
+  if (st && status) status[j] = st;
+}
+
 // ---- grouping jobs by denominator class (tc_jobs.h combine_divide) -----------------------------------
 // Three tiny kernels turn the batch into a permutation in which every class occupies a run of whole
 // waves (runs padded to kCombinePad jobs with the marker 0xffffffff), so that the lanes of a wave take
@@ -143,6 +154,11 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
                      uint8_t* status, uint32_t* need_general) {
   const size_t n = B * (t + 1);
   if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status, need_general);
+}
+size_t lagrange_all_ws_words(size_t t, size_t B) { return B * 4 * (t + 1) * 8; }
+void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
+                         uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_lagrange_all, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, ws, status);
 }
 // need_general: one zeroed word the Lagrange stage counts non-fast jobs in (nullptr when t == 0: no
 // Lagrange stage, the general kernel takes every job)

@@ -1,0 +1,50 @@
+// gfx950 kernels: large G2 linear combinations in two stages (tc_msm.h) -- the share combiner of the
+// general path for t + 1 >= 8 samples (BASELINE config "t=67, N=200") and tc_g2_lincomb_batch for n >= 8.
+#include "tc_msm.h"
+#include "tc_launch.h"
+
+namespace tc {
+
+// stage T: one lane pair per (job, chunk of 4 shares)
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_tables(size_t n, size_t pts_stride, const uint8_t* __restrict__ points,
+                                                                  const uint32_t* __restrict__ scalars, size_t B,
+                                                                  int32_t* __restrict__ tbl, uint8_t* __restrict__ codes,
+                                                                  uint8_t* __restrict__ status) {
+  const size_t chunks = msm_chunks(n);
+  const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  if (tid >= B * chunks) return;
+  const size_t j = tid / chunks, c = tid % chunks;
+  const size_t shares4 = chunks * kMsmChunk;
+  const bool ok = job_msm_tables(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + j * shares4 * 8 * kMsmEntryWords,
+                                 codes + j * kMsmColumns * shares4, pair_leader());
+  if (!ok && pair_leader() && status[j] == TC_JOB_OK) status[j] = TC_JOB_INVALID_ENCODING;
+}
+
+// stage L: one lane pair per job
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder(size_t n, size_t B, const int32_t* __restrict__ tbl,
+                                                                  const uint8_t* __restrict__ codes, uint8_t* __restrict__ out,
+                                                                  const uint8_t* __restrict__ status) {
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  if (j >= B) return;
+  if (status[j] != TC_JOB_OK) {
+    g2_encode_uncompressed(G2Affine::infinity(), out + j * 192);
+    return;
+  }
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  const G2Jac r = job_msm_ladder(n, tbl + j * shares4 * 8 * kMsmEntryWords, codes + j * kMsmColumns * shares4);
+  g2_encode_uncompressed(jac_to_affine(r), out + j * 192);
+}
+
+size_t msm_table_bytes(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWords * sizeof(int32_t); }
+size_t msm_code_bytes(size_t n, size_t B) { return B * kMsmColumns * msm_chunks(n) * kMsmChunk; }
+// status: B bytes, TC_JOB_OK for the jobs to run (others get the identity and keep their status)
+void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
+                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status) {
+  if (!B || !n) return;
+  const size_t lanes = B * msm_chunks(n) * kG2Lanes;
+  hipLaunchKernelGGL(k_msm_tables, dim3(grid_for(lanes)), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status);
+  hipLaunchKernelGGL(k_msm_ladder, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
+                     (const uint8_t*)status);
+}
+
+}  // namespace tc

@@ -187,6 +187,15 @@ bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
   return k.check(hipStreamSynchronize(k.c->stream), "stream sync");
 }
 
+// sum_i scalars[j][i] * points[j][i] in G2 for n >= kMsmMinPoints through the two-stage kernels (k_msm.hip);
+// d_st must hold B zeroed-or-flagged status bytes
+void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
+            uint8_t* d_st) {
+  int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes(n, B) / sizeof(int32_t));
+  uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, B));
+  if (!k.failed) tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts, d_scalars, B, d_tbl, d_codes, d_out, d_st);
+}
+
 #define TC_REQUIRE(cond)            \
   do {                              \
     if (!(cond)) {                  \
@@ -352,6 +361,25 @@ int tc_g1_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S
   return point_mul(ctx, false, fr, pts, S, B, out, status);
 }
 
+int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, const uint64_t* idx, const uint8_t* hashes, size_t n,
+                            size_t B, uint8_t* out, uint8_t* status) {
+  TC_REQUIRE(ctx);
+  if (n == 0 || B == 0) return TC_OK;
+  TC_REQUIRE(ctx && sk_table && idx && hashes && out && N > 0);
+  Call k(ctx);
+  const uint8_t* d_sk = k.in(sk_table, N * 32, /*secret=*/true);
+  const uint64_t* d_idx = k.in(idx, B * n);
+  const uint8_t* d_h = k.in(hashes, B * 192);
+  uint8_t* d_out = k.out(out, B * n * 192);
+  uint8_t* d_st = k.out(status, B * n);
+  k.begin_timing();
+  k.check_points(true, d_h, 192, 1, 1, B, n);
+  if (!k.failed) tc::launch_g2_mul_gather(ctx->stream, d_sk, N, d_idx, d_h, n, B, d_out, d_st);
+  k.apply_checks(B * n, d_st, d_out, 192, nullptr);
+  k.end_timing();
+  return k.finish();
+}
+
 int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uint64_t* off, size_t S, size_t B,
                   uint8_t* out_g2, uint8_t* status) {
   TC_REQUIRE(ctx);
@@ -431,8 +459,14 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
   k.begin_timing();
   k.check_points(g2, d_sh, PB, n, t + 1, B, 1);  // exactly the first t+1 samples interpolate() takes
   if (!k.failed) {
-    if (t > 0) tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
-    if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+    if (t + 1 >= tc::kMsmMinPoints) {
+      uint32_t* d_ws = k.temp<uint32_t>(tc::lagrange_all_ws_words(t, B));
+      if (!k.failed) tc::launch_lagrange_all(ctx->stream, d_idx, n, t, B, d_lam, d_ws, d_st);
+    } else if (t > 0) {
+      tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
+    }
+    if (g2 && t + 1 >= tc::kMsmMinPoints) msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds
+    else if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
     else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need);
     k.apply_checks(B, d_st, d_pt, PB, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
@@ -478,7 +512,11 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
   k.begin_timing();
   k.check_points(g2, d_pt, PB, n, n, B, 1);
   if (!k.failed) {
-    if (g2) tc::launch_lincomb_g2(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
+    if (g2 && n >= tc::kMsmMinPoints) {
+      uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
+      if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
+      msm_g2(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
+    } else if (g2) tc::launch_lincomb_g2(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
     else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
   }
   k.apply_checks(B, d_st, d_out, PB, nullptr);
@@ -637,7 +675,12 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
   std::vector<uint8_t> h_okmsg(B);
   if (!k.failed) {
     tc::launch_rlc_scalars(ctx->stream, d_seed, B * N, d_r);
-    tc::launch_lincomb_g2(ctx->stream, N, d_r, d_sig, B, d_S, d_stS);
+    if (N >= tc::kMsmMinPoints) {
+      k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
+      msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS);
+    } else {
+      tc::launch_lincomb_g2(ctx->stream, N, d_r, d_sig, B, d_S, d_stS);
+    }
     tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     // e(P, [c] Q') == e(g1, S)  <=>  e(P, Q') == e([1/c] g1, S)   (the folded hash constant of tc_verify_sig_batch)

@@ -100,6 +100,40 @@ TC_HD void job_g2_mul_shared(const uint8_t* fr_le32, int n, const uint8_t* pt, u
   }
 }
 
+// out[s] = sk[idx[s]] * pt for n <= kMulShare signer indices into a table of N secret key shares: the shares of
+// ONE message by the signers of its subset (SecretKeyShare::sign_g2, src/lib.rs:442-444, for every selected
+// signer), generated on the device so that a (t, N, batch) workload needs only the key set and the hash points.
+// An index >= N fails its own output.
+TC_HD void job_g2_mul_gather(const uint8_t* sk_table, size_t N, const uint64_t* idx, int n, const uint8_t* pt, uint8_t* out,
+                             uint8_t* status, bool leader) {
+  G2Affine p;
+  const bool pok = g2_decode_uncompressed(pt, p);
+  if (!pok) p = G2Affine::infinity();
+  G2Affine base[4];
+  g2_gls_bases(p, base);
+  G2SacTable tb;
+  g2_sac_table_call(base, tb);
+  G2Jac res[kMulShare];
+  bool ok[kMulShare];
+  TC_NOUNROLL for (int s = 0; s < n; s++) {
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t i = idx[s];
+    ok[s] = pok && i < N;
+    if (i < N) ok[s] = fr_from_le32(sk_table + 32 * i, k) && ok[s];
+    uint64_t d[4];
+    const bool flip = gls_decompose_odd(k, d);
+    G2Jac r = g2_sac_ladder_call(tb, d);
+    r.y = Fq2::select(flip, -r.y, r.y);
+    res[s] = G2Jac::select(ok[s], r, G2Jac::infinity());
+  }
+  G2Affine aff[kMulShare];
+  jac_batch_to_affine<Fq2, kMulShare>(res, aff, n);
+  TC_NOUNROLL for (int s = 0; s < n; s++) {
+    g2_encode_uncompressed(aff[s], out + (size_t)s * 192);
+    if (status && leader) status[s] = ok[s] ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+  }
+}
+
 // k * c mod r for c = FR_COFACTOR_FIX (canonical words in and out)
 TC_HD void fr_mul_cofactor_fix(const uint32_t* k, uint32_t* out) {
   (Fr::from_canonical(k) * Fr::from_canonical(FR_COFACTOR_FIX)).to_canonical(out);

@@ -24,6 +24,9 @@ void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t
                    uint8_t* status);
 void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status);
+// out[j*n + k] = sk[idx[j*n + k]] * pts[j]: the shares of message j by its n selected signers out of N
+void launch_g2_mul_gather(hipStream_t st, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
+                          uint8_t* out, uint8_t* status);
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
@@ -33,6 +36,10 @@ void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* 
 // does not take, the general combine kernel leaves at once when it stays zero (k_combine.hip)
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
                      uint8_t* status, uint32_t* need_general);
+// every coefficient of a job from ONE lane with one inversion (large thresholds); ws: lagrange_all_ws_words
+size_t lagrange_all_ws_words(size_t t, size_t B);
+void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
+                         uint8_t* status);
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general);
 size_t combine_group_slots(size_t B);
@@ -49,6 +56,15 @@ void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const u
 void launch_rlc_scalars(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr);
 void launch_gather_rows(hipStream_t st, const uint8_t* src, size_t row_bytes, const uint32_t* map, size_t rows, uint8_t* dst);
 void launch_scatter_bytes(hipStream_t st, const uint8_t* src, const uint32_t* map, size_t rows, uint8_t* dst);
+
+// large G2 linear combinations in two stages (k_msm.hip): per-share affine psi tables + digit codes in HBM
+// (tbl: msm_table_bytes, codes: msm_code_bytes), then one 64-step ladder per job.  status: B bytes, jobs with
+// status != TC_JOB_OK are skipped (identity out); undecodable operands set TC_JOB_INVALID_ENCODING.
+constexpr size_t kMsmMinPoints = 8;
+size_t msm_table_bytes(size_t n, size_t B);
+size_t msm_code_bytes(size_t n, size_t B);
+void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
+                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status);
 
 // opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
 // records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an

@@ -1,0 +1,147 @@
+// Large linear combinations in G2 (t+1 >= 8 shares per job: BASELINE config "t=67, N=200"), two stages:
+//
+//   stage T  one lane pair per (job, chunk of 4 shares): every scalar is split into its four base-|x| digits
+//            (tc_gls.h), each share gets its 8-entry sign-aligned table  B0 + {subset sums of B1, B2, B3}  of
+//            psi-images, and the 4 x 7 proper sums of the chunk are brought to AFFINE form with one shared
+//            inversion.  Tables (256 B per entry) and per-column digit codes go to HBM.
+//   stage L  one lane pair per job: ONE chain of 64 doublings for all t+1 shares; per column and share one
+//            table look-up (a single coalesced 64-byte row per coordinate and lane) and one MIXED addition.
+//
+// Per share that is 64 mixed additions + 7 table additions + 1/4 inversion, against 64 + 7 + 16 doublings + the
+// chunk sums for the 4-share ladders of tc_threshold.h straus_chunk_gls4 (whose tables live in per-lane
+// scratch and share one Z only inside a chunk).  Same group element, same bytes as interpolate's
+// sum_i lambda_i S_i (/root/reference/src/lib.rs:764).
+#pragma once
+#include "tc_jobs.h"
+
+namespace tc {
+
+constexpr int kMsmChunk = 4;          // shares per stage-T lane pair
+constexpr int kMsmEntryWords = 64;    // one table entry: x (2 x 16 words), y (2 x 16 words); word 15 of x[0] = flags
+constexpr int kMsmCoordWords = 16;    // 14 limbs + 2 words of padding: one 64-byte row per coordinate and lane
+constexpr int kMsmColumns = 65;       // digit columns 0 .. 64 (column 64: the leading +1 of the sign-aligned form)
+
+TC_HD size_t msm_chunks(size_t n) { return (n + kMsmChunk - 1) / kMsmChunk; }
+
+// this lane's half of an affine G2 point -> its two 64-byte rows of a table entry (hipcc: one coefficient per
+// lane of the pair; g++ test build: both coefficients)
+TC_HD void msm_store_entry(int32_t* e, const G2Affine& p) {
+#if TC_PAIR
+  const int o = pair_odd() * kMsmCoordWords;
+  const Fq x = p.x.m.norm(), y = p.y.m.norm();
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    e[o + i] = x.l[i];
+    e[2 * kMsmCoordWords + o + i] = y.l[i];
+  }
+  e[o + 14] = 0;
+  e[o + 15] = p.inf ? 1 : 0;
+  e[2 * kMsmCoordWords + o + 14] = 0;
+  e[2 * kMsmCoordWords + o + 15] = 0;
+#else
+  const Fq xs[2] = {p.x.c0.norm(), p.x.c1.norm()}, ys[2] = {p.y.c0.norm(), p.y.c1.norm()};
+  for (int h = 0; h < 2; h++) {
+    for (int i = 0; i < FQ_LIMBS; i++) {
+      e[h * kMsmCoordWords + i] = xs[h].l[i];
+      e[2 * kMsmCoordWords + h * kMsmCoordWords + i] = ys[h].l[i];
+    }
+    e[h * kMsmCoordWords + 14] = 0;
+    e[h * kMsmCoordWords + 15] = p.inf ? 1 : 0;
+    e[2 * kMsmCoordWords + h * kMsmCoordWords + 14] = 0;
+    e[2 * kMsmCoordWords + h * kMsmCoordWords + 15] = 0;
+  }
+#endif
+}
+TC_HD Fq msm_load_fq(const int32_t* w) {
+  Fq r;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = w[i];
+  r.set_range(-0.001f, 1.001f);
+  r.set_val(2.1f);
+  return r;
+}
+TC_HD G2Affine msm_load_entry(const int32_t* e) {
+  G2Affine p;
+#if TC_PAIR
+  const int o = pair_odd() * kMsmCoordWords;
+  p.x = Fq2{msm_load_fq(e + o)};
+  p.y = Fq2{msm_load_fq(e + 2 * kMsmCoordWords + o)};
+  p.inf = e[o + 15] != 0;
+#else
+  p.x = Fq2::make(msm_load_fq(e), msm_load_fq(e + kMsmCoordWords));
+  p.y = Fq2::make(msm_load_fq(e + 2 * kMsmCoordWords), msm_load_fq(e + 3 * kMsmCoordWords));
+  p.inf = e[15] != 0;
+#endif
+  return p;
+}
+
+// Stage T for the chunk `c` of job data: points (n x 192 B), scalars (n x 8 canonical words).
+//   tbl    this job's tables: (4 * chunks) shares x 8 entries x 64 words
+//   codes  this job's digit codes: 65 columns x (4 * chunks) shares, one byte each: bits 0..2 table index,
+//          bit 3 = subtract
+// Returns false when a point or scalar of the chunk does not decode (the job then fails as a whole).
+TC_HD bool job_msm_tables(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes,
+                          bool leader) {
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  G2Jac sums[7 * kMsmChunk];
+  G2Affine b0[kMsmChunk];
+  SacDigits sd[kMsmChunk];
+  bool ok = true;
+  TC_NOUNROLL for (int k = 0; k < kMsmChunk; k++) {
+    const size_t s = c * kMsmChunk + k;
+    G2Affine p = G2Affine::infinity();
+    uint32_t sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < n) {
+      ok &= g2_decode_uncompressed(points + s * 192, p);
+      for (int w = 0; w < 8; w++) sc[w] = scalars[s * 8 + w];
+      ok &= limbs_lt_p<FrParams>(sc);
+    }
+    if (!ok) p = G2Affine::infinity();
+    uint64_t d[4];
+    const bool flip = gls_decompose_odd(sc, d);
+    sd[k] = sac_recode4(d);
+    G2Affine base[4];
+    g2_gls_bases(p, base);
+    TC_NOUNROLL for (int j = 0; j < 4; j++) base[j].y = Fq2::select(flip, -base[j].y, base[j].y).norm();
+    b0[k] = base[0];
+    TC_NOUNROLL for (int m = 1; m < 8; m++) {
+      const int low = __builtin_ctz((unsigned)m);
+      const int rest = m & (m - 1);
+      sums[7 * k + m - 1] = rest ? jac_add_mixed(sums[7 * k + rest - 1], base[low + 1]) : jac_add_affine(base[0], base[low + 1]);
+    }
+  }
+  G2Affine aff[7 * kMsmChunk];
+  jac_batch_to_affine<Fq2, 7 * kMsmChunk>(sums, aff, 7 * kMsmChunk);
+  TC_NOUNROLL for (int k = 0; k < kMsmChunk; k++) {
+    const size_t s = c * kMsmChunk + k;
+    int32_t* t = tbl + s * 8 * kMsmEntryWords;
+    msm_store_entry(t, b0[k]);
+    TC_NOUNROLL for (int m = 1; m < 8; m++) msm_store_entry(t + m * kMsmEntryWords, aff[7 * k + m - 1]);
+    if (leader) {
+      TC_NOUNROLL for (int col = 0; col < 64; col++) {
+        const uint32_t m = (uint32_t)((sd[k].u[0] >> col) & 1) | ((uint32_t)((sd[k].u[1] >> col) & 1) << 1) |
+                           ((uint32_t)((sd[k].u[2] >> col) & 1) << 2);
+        codes[(size_t)col * shares4 + s] = (uint8_t)(m | (((sd[k].neg >> col) & 1) << 3));
+      }
+      codes[(size_t)64 * shares4 + s] = (uint8_t)sd[k].top;  // column 64: every share adds +tbl[top]
+    }
+  }
+  return ok;
+}
+
+// Stage L: sum over the (4 * chunks) shares of one job from its tables and digit codes
+TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes) {
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  G2Jac acc = G2Jac::infinity();
+  TC_NOUNROLL for (int col = kMsmColumns - 1; col >= 0; col--) {
+    if (col != kMsmColumns - 1) acc = jac_dbl(acc);
+    const uint8_t* cc = codes + (size_t)col * shares4;
+    TC_NOUNROLL for (size_t s = 0; s < shares4; s++) {
+      const uint32_t code = cc[s];
+      G2Affine e = msm_load_entry(tbl + (s * 8 + (code & 7)) * kMsmEntryWords);
+      e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
+      acc = jac_add_mixed(acc, e);
+    }
+  }
+  return acc;
+}
+
+}  // namespace tc

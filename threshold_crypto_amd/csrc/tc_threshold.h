@@ -26,6 +26,57 @@ TC_HD bool lagrange_coeff_at_zero(const uint64_t* idx, int t, int i, Fr& out) {
   return true;
 }
 
+// All t+1 coefficients of one job with ONE field inversion (Montgomery's trick) instead of one Fermat power
+// per coefficient -- what the reference does at src/lib.rs:763 costs ~320 Fr multiplications each, more than
+// the t multiplications of the denominator itself; at t = 67 the per-coefficient kernel was 15 % of the whole
+// combination.  Same values: lambda_i = (prod_{j != i by position} x_j) * (prod_{j: x_j != x_i} (x_j - x_i))^-1.
+// ws: 4 (t+1) x 8 words of scratch (x, denominators, their prefix products, prefix products of x), Montgomery form.
+// out: (t+1) x 8 canonical words.  Equal abscissae are filtered BY VALUE (src/lib.rs:758), so a denominator is
+// never zero and DuplicateEntry stays unreachable, as in the reference.
+TC_HD uint8_t lagrange_all_at_zero(const uint64_t* idx, int t, uint32_t* out, uint32_t* ws) {
+  const int n = t + 1;
+  uint32_t* xm = ws;
+  uint32_t* den = ws + (size_t)n * 8;
+  uint32_t* pre = ws + (size_t)2 * n * 8;
+  uint32_t* px = ws + (size_t)3 * n * 8;
+  auto put = [](uint32_t* dst, const Fr& v) { TC_UNROLL for (int i = 0; i < 8; i++) dst[i] = v.v.l[i]; };
+  auto get = [](const uint32_t* src) { Fr v; TC_UNROLL for (int i = 0; i < 8; i++) v.v.l[i] = src[i]; return v; };
+  const Fr one = Fr::one();
+  Fr accx = one;
+  TC_NOUNROLL for (int i = 0; i < n; i++) {
+    const Fr x = fr_from_u64(idx[i]) + one;
+    put(xm + (size_t)i * 8, x);
+    put(px + (size_t)i * 8, accx);  // prod_{k < i} x_k
+    accx = accx * x;
+  }
+  Fr accd = one;
+  TC_NOUNROLL for (int i = 0; i < n; i++) {
+    const Fr xi = get(xm + (size_t)i * 8);
+    const uint64_t vi = idx[i];
+    Fr d = one;
+    TC_NOUNROLL for (int j = 0; j < n; j++) {
+      if (idx[j] != vi) d = d * (get(xm + (size_t)j * 8) - xi);  // x_j != x_i  <=>  idx_j != idx_i  (u64 + 1 is injective mod r)
+    }
+    put(den + (size_t)i * 8, d);
+    put(pre + (size_t)i * 8, accd);  // prod_{k < i} den_k
+    accd = accd * d;
+  }
+  if (accd.is_zero()) {  // unreachable (see above); kept so that a zero can never be inverted silently
+    TC_NOUNROLL for (int k = 0; k < n * 8; k++) out[k] = 0;
+    return TC_JOB_DUPLICATE_ENTRY;
+  }
+  Fr inv = accd.inv();
+  Fr sufx = one;  // prod_{k > i} x_k
+  TC_NOUNROLL for (int i = n - 1; i >= 0; i--) {
+    const Fr dinv = inv * get(pre + (size_t)i * 8);
+    inv = inv * get(den + (size_t)i * 8);
+    const Fr lam = get(px + (size_t)i * 8) * sufx * dinv;
+    sufx = sufx * get(xm + (size_t)i * 8);
+    lam.to_canonical(out + (size_t)i * 8);
+  }
+  return TC_JOB_OK;
+}
+
 // sum_{k < K} s_k * P_k for K <= 4 points with per-lane 255-bit scalars: joint (Straus)
 // double-and-add over a (2^K - 1)-entry subset-sum table held in the lane's scratch.
 // One shared doubling chain for the K points; control flow is lane-uniform except the

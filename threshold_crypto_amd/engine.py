@@ -182,6 +182,18 @@ class Engine:
     def g1_mul(self, fr, pts):
         return self._mul("tc_g1_mul_batch", G1_BYTES, fr, pts)
 
+    def sign_shares_g2(self, sk_table, idx, hashes):
+        """out[j, k] = sk_table[idx[j, k]] * hashes[j]: the shares of each message by its selected signers"""
+        dev = self._mode(sk_table, idx, hashes)
+        self._arg(sk_table, (None, FR_BYTES), "u8", "sk_table")
+        self._arg(idx, (None, None), "u64", "idx")
+        B, n = idx.shape
+        self._arg(hashes, (B, G2_BYTES), "u8", "hashes")
+        out = self._empty(dev, (B, n, G2_BYTES), ref=hashes)
+        st = self._empty(dev, (B, n), ref=hashes)
+        self._call("tc_sign_shares_g2_batch", _ptr(sk_table), sk_table.shape[0], _ptr(idx), _ptr(hashes), n, B, _ptr(out), _ptr(st))
+        return out, st
+
     def sign(self, fr, msgs, off):
         dev = self._mode(fr, msgs, off)
         self._arg(fr, (None, FR_BYTES), "u8", "fr")
