@@ -222,6 +222,36 @@ int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* o
 int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status);
 int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out192, uint8_t* status);
 
+/* ---- several GPUs of one node from ONE host process ------------------------------ */
+/* A group owns one tc_ctx and one worker thread per GPU.  Jobs are independent, so a batch in host memory is
+ * split into contiguous ranges, one per GPU, and there is no data-path collective; the two exchange steps of the
+ * path run on RCCL (bound with dlopen at tc_group_create): the BROADCAST of the key-set parameters from rank 0 to
+ * every GPU's HBM over xGMI (tc_group_set_keyset) and the ALL-REDUCE of the per-GPU valid counts
+ * (tc_group_verify_g2).  Processes that prefer one process per GPU use a plain tc_ctx each and do the broadcast
+ * themselves (torch.distributed / RCCL: threshold_crypto_amd/parallel.py, bench.py --gpus N).
+ * devices: ndev HIP device ids; duplicate ids put several ranks on one GPU (no RCCL then: a test configuration). */
+typedef struct tc_group tc_group;
+int tc_group_create(tc_group** out, const int* devices, int ndev);
+void tc_group_destroy(tc_group* g);
+int tc_group_size(const tc_group* g);
+int tc_group_uses_rccl(const tc_group* g);
+tc_ctx* tc_group_ctx(tc_group* g, int rank);             /* the rank's context, for direct tc_*_batch calls */
+const char* tc_group_last_error(const tc_group* g);
+/* contiguous range [start, start + count) of a B-job batch that rank `rank` works on */
+int tc_group_shard(const tc_group* g, size_t B, int rank, size_t* start, size_t* count);
+/* PublicKeySet { commit } src/lib.rs:539-543: (t+1) x 96 B from host memory to rank 0, then RCCL broadcast */
+int tc_group_set_keyset(tc_group* g, size_t t, const uint8_t* commit);
+int tc_group_get_keyset(tc_group* g, int rank, uint8_t* out_commit);
+/* PublicKeySet::combine_signatures src/lib.rs:608-615 for B jobs (host buffers), threshold = the key set's */
+int tc_group_combine_signatures(tc_group* g, size_t n_per_job, const uint64_t* idx, const uint8_t* shares, size_t B, uint8_t* out,
+                                uint8_t* status);
+/* PublicKeySet::public_key().verify_g2 src/lib.rs:565-567, 108-110 for B jobs; n_valid (optional): all-reduced count */
+int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, size_t B, uint8_t* ok, uint64_t* n_valid);
+/* BASELINE config 5 in one call: hash each message, sign the n shares of its signer subset ON the device from the
+ * N x 32 B table of secret key shares, combine, verify under the master key.  idx: B x n ascending signer indices. */
+int tc_group_sign_combine_verify(tc_group* g, const uint8_t* sk_table, size_t N, const uint64_t* idx, size_t n, const uint8_t* msgs,
+                                 const uint64_t* off, size_t B, uint8_t* sig, uint8_t* ok, uint64_t* n_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,60 @@
+"""tc_group_* (the C ABI's multi-GPU surface) on the one GPU this box has: a 1-rank group runs its key-set
+broadcast and its valid-count all-reduce on RCCL (ncclCommInitAll over one device); a group with device 0 listed
+twice exercises the two-worker sharding (no RCCL there -- RCCL refuses duplicate devices -- documented test
+configuration).  Results must equal direct single-context calls byte for byte."""
+import numpy as np
+import pytest
+
+from threshold_crypto_amd.engine import Group, pack_messages
+from threshold_crypto_amd.workload import ThresholdSigWorkload, key_set, messages
+from threshold_crypto_amd.config5 import signer_subsets_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wl(engine):
+    return ThresholdSigWorkload(engine, 3, 10, 300)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def test_group_matches_single_context(engine, wl, devices):
+    g = Group(devices)
+    try:
+        assert g.size() == len(devices) and g.uses_rccl() == (len(devices) == 1)
+        spans = [g.shard(wl.B, r) for r in range(g.size())]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == wl.B and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        commit = np.stack([np.frombuffer(c, dtype=np.uint8) for c in wl.sks.public_keys(engine).commit])
+        g.set_keyset(commit)
+        for r in range(g.size()):
+            assert (g.get_keyset(r) == commit).all()            # every rank's HBM holds rank 0's commitment
+        sig, st = g.combine_signatures(wl.idx, wl.shares)
+        want, wst = engine.combine_g2(3, wl.idx, wl.shares)
+        assert not st.any() and (sig == want).all()
+        bad = sig.copy()
+        bad[7] = sig[8]
+        bad[299] = sig[0]
+        ok, nvalid = g.verify_g2(bad, wl.hashes)
+        assert nvalid == wl.B - 2 and ok.sum() == wl.B - 2 and ok[7] == 0 and ok[299] == 0
+    finally:
+        g.close()
+
+
+def test_group_config5_pipeline(engine):
+    """tc_group_sign_combine_verify: BASELINE config 5's flow (t = 8 here: the large-threshold path) from one call."""
+    t, N, B = 8, 12, 70
+    sks = key_set(t)
+    commit = np.stack([np.frombuffer(c, dtype=np.uint8) for c in sks.public_keys(engine).commit])
+    sk_table = np.stack([np.frombuffer(sks.secret_key_share(i)._bytes(), dtype=np.uint8) for i in range(N)])
+    idx = signer_subsets_np(B, N, t)
+    flat, off = pack_messages(messages(B))
+    g = Group([0, 0])
+    try:
+        g.set_keyset(commit)
+        sig, ok, nvalid = g.sign_combine_verify(sk_table, idx, flat, off)
+    finally:
+        g.close()
+    assert ok.all() and nvalid == B
+    h = engine.hash_g2(flat, off)
+    msig, st = engine.g2_mul(np.frombuffer(sks.poly[0].to_bytes(32, "little"), dtype=np.uint8)[None].copy(), h)
+    assert (msig[:, 0] == sig).all()

@@ -60,7 +60,26 @@ PROTOTYPES = {
 CONTEXT_SYMBOLS = ["tc_ctx_create", "tc_ctx_destroy", "tc_ctx_set_device_io", "tc_ctx_set_stream", "tc_sync",
                    "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version", "tc_ctx_set_input_checks"]
 
-ALL_SYMBOLS = CONTEXT_SYMBOLS + sorted(PROTOTYPES)
+# the multi-GPU surface (tc_group_*): name -> (restype, argtypes); the group handle is an opaque pointer
+_grp = ctypes.c_void_p
+_szp = ctypes.POINTER(ctypes.c_size_t)
+_u64out = ctypes.POINTER(ctypes.c_uint64)
+GROUP_PROTOTYPES = {
+    "tc_group_create": (ctypes.c_int, [ctypes.POINTER(_grp), ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "tc_group_destroy": (None, [_grp]),
+    "tc_group_size": (ctypes.c_int, [_grp]),
+    "tc_group_uses_rccl": (ctypes.c_int, [_grp]),
+    "tc_group_ctx": (ctypes.c_void_p, [_grp, ctypes.c_int]),
+    "tc_group_last_error": (ctypes.c_char_p, [_grp]),
+    "tc_group_shard": (ctypes.c_int, [_grp, _sz, ctypes.c_int, _szp, _szp]),
+    "tc_group_set_keyset": (ctypes.c_int, [_grp, _sz, _u8p]),
+    "tc_group_get_keyset": (ctypes.c_int, [_grp, ctypes.c_int, _u8p]),
+    "tc_group_combine_signatures": (ctypes.c_int, [_grp, _sz, _u64p, _u8p, _sz, _u8p, _u8p]),
+    "tc_group_verify_g2": (ctypes.c_int, [_grp, _u8p, _u8p, _sz, _u8p, _u64out]),
+    "tc_group_sign_combine_verify": (ctypes.c_int, [_grp, _u8p, _sz, _u64p, _sz, _u8p, _u64p, _sz, _u8p, _u8p, _u64out]),
+}
+
+ALL_SYMBOLS = CONTEXT_SYMBOLS + sorted(PROTOTYPES) + sorted(GROUP_PROTOTYPES)
 
 _lib = None
 
@@ -110,5 +129,9 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = [_ctx] + args
         fn.restype = ctypes.c_int
+    for name, (res, args) in GROUP_PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
     _lib = lib
     return lib

@@ -22,7 +22,7 @@ BUILD = os.path.join(HERE, "_build")
 EXTRA_FLAGS = os.environ.get("TC_BUILD_FLAGS", "").split()
 SUFFIX = os.environ.get("TC_BUILD_SUFFIX", "")
 LIB = os.path.join(HERE, "libtc_amd%s.so" % SUFFIX)
-UNITS = ["tc_api", "k_mul", "k_combine", "k_pairing", "k_hash", "k_check", "k_dkg", "k_msm"]
+UNITS = ["tc_api", "tc_group", "k_mul", "k_combine", "k_pairing", "k_hash", "k_check", "k_dkg", "k_msm"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wno-unused-result"] + EXTRA_FLAGS
 
@@ -81,7 +81,7 @@ def build(force=False, jobs=None, timeout=1500, verbose=True):
             objs[unit] = obj
             if verbose:
                 print("[tc build] %-10s %s" % (unit, "cached" if cached else "%.1fs" % dt), flush=True)
-    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + [objs[u] for u in UNITS]
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + [objs[u] for u in UNITS] + ["-ldl", "-lpthread"]
     subprocess.run(cmd, check=True, timeout=600)
     os.replace(LIB + ".tmp", LIB)
     with open(stamp, "w") as f:

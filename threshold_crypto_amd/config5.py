@@ -125,8 +125,9 @@ def run_pipeline(engine, t, N, B, rank, world, device=None, steps=1, warmup=0, s
             "sig": sig_np, "hashes": hashes, "idx": idx_np, "key_material": km, "secret_key_set": sks, "master_pk": master_pk}
 
 
-def run_bench(args, eng, dev, rank, world, peak, roofline):
-    """bench.py --config 5: 131 072 jobs per GPU by default (x 8 GPUs = the BASELINE batch)."""
+def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
+    """bench.py --config 5: 131 072 jobs per GPU by default (x 8 GPUs = the BASELINE batch).  cpu_baseline: the
+    caller's oracle leg (bench.py owns every use of oracle/; this package never imports it)."""
     import torch
     t = 67 if args.t is None else args.t
     N = 200 if args.signers is None else args.signers
@@ -160,9 +161,7 @@ def run_bench(args, eng, dev, rank, world, peak, roofline):
         "share_sign": roofline("k_g2_mul_gather", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, float(ms[0]), peak),
         "pairing_check": roofline("k_pairing_check", "verify_g2", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
     }
-    cpu = None
-    if not args.no_cpu_baseline:
-        cpu = cpu_baseline(res, t, args.cpu_seconds)
+    cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline) else None
     return {
         "metric": "threshold signatures (sign t+1 shares + combine + verify)/sec", "value": round(B * world / step_s, 1),
         "unit": "threshold_signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,31 +176,3 @@ def run_bench(args, eng, dev, rank, world, peak, roofline):
         "valid_total_all_ranks": res["valid_total"], "rank_records_start_jobs_valid_digest": res["records"],
         "verified_all": True, "roofline": legs["combine"], "secondary_rooflines": legs, "cpu_baseline": cpu,
     }
-
-
-def cpu_baseline(res, t, seconds):
-    """Oracle B on a handful of the rank's jobs (a t=67 combination takes ~0.1 s per core): bit-exact check + rate."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-    import c_oracle
-    c_oracle.load()
-    threads = c_oracle.host_threads()
-    n = max(threads, 16)
-    idx = res["idx"][:n]
-    km = res["key_material"]
-    shares = np.empty((n, t + 1, 192), dtype=np.uint8)
-    hashes = res["hashes"].cpu().numpy() if hasattr(res["hashes"], "cpu") else np.asarray(res["hashes"])
-    t0 = time.perf_counter()
-    for j in range(n):
-        for k in range(t + 1):
-            rc, out = c_oracle.g2_mul(bytes(km.sk_table[int(idx[j, k])]), bytes(hashes[j]))
-            shares[j, k] = np.frombuffer(out, dtype=np.uint8)
-    sign_dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    out, rc = c_oracle.combine_g2_batch(t, idx, shares, threads)
-    dt = time.perf_counter() - t0
-    assert not rc.any() and (out == res["sig"][:n]).all(), "GPU config-5 signatures differ from the CPU oracle"
-    return {"value": round(n / dt, 2), "unit": "combine_signatures/s", "cores": threads, "kind": "port",
-            "sample": "first %d jobs of rank 0 (t=%d): shares signed by Oracle B single-threaded (%.1f s), combined on %d pthreads; "
-                      "every sampled signature compared bit-exact with the GPU output" % (n, t, sign_dt, threads)}

@@ -427,3 +427,84 @@ class Engine:
         st = self._empty(dev, (B,), ref=xs)
         self._call("tc_fr_interpolate_batch", int(n), _ptr(xs), _ptr(ys), B, _ptr(out), _ptr(st))
         return out, st
+
+
+class Group:
+    """tc_group: several GPUs of one node driven from this process (one worker thread per GPU inside the library),
+    host-memory batches sharded contiguously, key-set broadcast and valid-count all-reduce on RCCL."""
+
+    def __init__(self, devices):
+        self._lib = _native.load()
+        g = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.tc_group_create(ctypes.byref(g), arr, len(devices))
+        if rc != _native.TC_OK:
+            raise TcError(rc, "tc_group_create failed for devices %s" % (list(devices),))
+        self._g = g
+        self.t = None
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.tc_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        rc = getattr(self._lib, name)(self._g, *args)
+        if rc != _native.TC_OK:
+            raise TcError(rc, self._lib.tc_group_last_error(self._g).decode())
+
+    def size(self):
+        return int(self._lib.tc_group_size(self._g))
+
+    def uses_rccl(self):
+        return bool(self._lib.tc_group_uses_rccl(self._g))
+
+    def shard(self, B, rank):
+        s, c = ctypes.c_size_t(), ctypes.c_size_t()
+        self._call("tc_group_shard", int(B), int(rank), ctypes.byref(s), ctypes.byref(c))
+        return int(s.value), int(c.value)
+
+    def set_keyset(self, commit):
+        Engine._arg(commit, (None, G1_BYTES), "u8", "commit")
+        self._call("tc_group_set_keyset", commit.shape[0] - 1, _ptr(commit))
+        self.t = commit.shape[0] - 1
+
+    def get_keyset(self, rank):
+        out = np.empty((self.t + 1, G1_BYTES), dtype=np.uint8)
+        self._call("tc_group_get_keyset", int(rank), _ptr(out))
+        return out
+
+    def combine_signatures(self, idx, shares):
+        Engine._arg(idx, (None, None), "u64", "idx")
+        B, n = idx.shape
+        Engine._arg(shares, (B, n, G2_BYTES), "u8", "shares")
+        out = np.empty((B, G2_BYTES), dtype=np.uint8)
+        st = np.empty(B, dtype=np.uint8)
+        self._call("tc_group_combine_signatures", n, _ptr(idx), _ptr(shares), B, _ptr(out), _ptr(st))
+        return out, st
+
+    def verify_g2(self, sig, hashes):
+        Engine._arg(sig, (None, G2_BYTES), "u8", "sig")
+        B = sig.shape[0]
+        Engine._arg(hashes, (B, G2_BYTES), "u8", "hashes")
+        ok = np.empty(B, dtype=np.uint8)
+        nv = ctypes.c_uint64(0)
+        self._call("tc_group_verify_g2", _ptr(sig), _ptr(hashes), B, _ptr(ok), ctypes.byref(nv))
+        return ok, int(nv.value)
+
+    def sign_combine_verify(self, sk_table, idx, msgs, off):
+        Engine._arg(sk_table, (None, FR_BYTES), "u8", "sk_table")
+        Engine._arg(idx, (None, None), "u64", "idx")
+        B, n = idx.shape
+        sig = np.empty((B, G2_BYTES), dtype=np.uint8)
+        ok = np.empty(B, dtype=np.uint8)
+        nv = ctypes.c_uint64(0)
+        self._call("tc_group_sign_combine_verify", _ptr(sk_table), sk_table.shape[0], _ptr(idx), n, _ptr(msgs), _ptr(off), B, _ptr(sig),
+                   _ptr(ok), ctypes.byref(nv))
+        return sig, ok, int(nv.value)
