@@ -1,6 +1,7 @@
 // gfx950 kernels: Lagrange coefficients and the share combiner (interpolate).
 #include "tc_jobs.h"
 #include "tc_launch.h"
+#include "tc_stage.h"
 
 namespace tc {
 
@@ -76,20 +77,22 @@ __global__ void k_combine_scatter(const uint8_t* __restrict__ cls, size_t B, uin
   }
 }
 
-template <class F>
-TC_D bool combine_fast(size_t t, const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* st) {
-  if (t == 1) return job_combine_small<F, 2>(idx, shares, out, st);
-  if (t == 2) return job_combine_small<F, 3>(idx, shares, out, st);
-  if (t == 3) return job_combine_small<F, 4>(idx, shares, out, st);
-  return false;
+template <class F, class IO>
+TC_D bool combine_fast(size_t t, const uint64_t* idx, bool live, IO& io, uint8_t* st) {
+  if (t == 1) return job_combine_small_io<F, 2>(idx, live, io, st);
+  if (t == 2) return job_combine_small_io<F, 3>(idx, live, io, st);
+  return job_combine_small_io<F, 4>(idx, live, io, st);
 }
 
 // The combination runs as TWO kernels so that each carries only its own private segment (the general
 // path's 4-share psi tables are 15 KB per lane, the fast path needs a fraction of that):
 //   k_combine_fast     t in {1, 2, 3}, small distinct indices: short joint ladder + ONE division by the
-//                      common denominator (tc_threshold.h lagrange_small_coeffs); leaves other jobs alone
-//   k_combine_general  everything else (t = 0, t > 3, large or repeated indices): Lagrange coefficients
+//                      common denominator (tc_threshold.h lagrange_small_coeffs); leaves other jobs alone.
+//                      Shares and results move through LDS a wave at a time (tc_stage.h): coalesced HBM access
+//                      instead of one strided byte gather per lane.
+//   k_combine_general  everything else (t = 0, 4 <= t < 7, large or repeated indices): Lagrange coefficients
 //                      from k_lagrange + Straus / GLS chunks; leaves at once when *need_general == 0
+//                      (t + 1 >= 8 goes through the two-stage kernels of k_msm.hip instead)
 template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine_fast(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                     const uint8_t* __restrict__ shares, size_t B,
@@ -97,13 +100,17 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
                                                     const uint32_t* __restrict__ perm, size_t slots) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
+  using IO = WaveRowIO<PB, L>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[IO::BYTES];
   const size_t slot = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
-  if (slot >= slots) return;
-  const size_t j = perm ? (size_t)perm[slot] : slot;  // grouped by denominator class, or the identity
-  if (j >= B) return;                                 // padding between two classes
+  size_t j = B;                                            // B = no job on this lane (past the end, or class padding)
+  if (slot < slots) j = perm ? (size_t)perm[slot] : slot;  // grouped by denominator class, or the identity
+  const bool live = j < B;
+  const size_t jj = live ? j : 0;
+  IO io{lds, live ? shares + jj * n_per_job * PB : nullptr, (size_t)PB, live ? out + jj * PB : nullptr};
   uint8_t st = TC_JOB_OK;
-  if (!combine_fast<F>(t, idx + j * n_per_job, shares + j * n_per_job * PB, out + j * PB, &st)) return;
-  if (status && (L == 1 || pair_leader())) status[j] = st;
+  const bool done = combine_fast<F>(t, idx + jj * n_per_job, live, io, &st);
+  if (done && status && (L == 1 || pair_leader())) status[j] = st;
 }
 
 template <class F>

@@ -255,28 +255,56 @@ TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
   return r;
 }
 
-// combination through the small-index fast path (tc_threshold.h); false => not applicable
-template <class F, int K>
-TC_HD bool job_combine_small(const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* status) {
-  constexpr int PB = PointIO<F>::BYTES;
-  uint64_t c_abs[K], d_abs;
-  bool c_neg[K], d_neg;
-  if (!lagrange_small_coeffs<K>(idx, c_abs, c_neg, &d_abs, &d_neg)) return false;
+// Where a job body finds the encodings of its operands and where its result goes.  DirectIO addresses global
+// memory as it is (one job per lane: 96/192-byte records `stride` apart); the kernels pass tc_stage.h's WaveRowIO
+// instead, which moves whole-wave rows through LDS with coalesced 8-byte loads and stores.  Every lane of a wave
+// -- live or not -- must make the same sequence of operand() / result() / commit(wrote) calls.
+struct DirectIO {
+  const uint8_t* in;
+  size_t stride;
+  uint8_t* out;
+  TC_HD const uint8_t* operand(int k) const { return in + (size_t)k * stride; }
+  TC_HD uint8_t* result() const { return out; }
+  TC_HD void commit(bool) const {}
+};
+
+// combination through the small-index fast path (tc_threshold.h); false => not applicable (or !live)
+template <class F, int K, class IO>
+TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t* status) {
+  uint64_t c_abs[K], d_abs = 1;
+  bool c_neg[K], d_neg = false;
+  TC_UNROLL for (int k = 0; k < K; k++) {
+    c_abs[k] = 0;
+    c_neg[k] = false;
+  }
+  const bool applies = live && lagrange_small_coeffs<K>(idx, c_abs, c_neg, &d_abs, &d_neg);
   Affine<F> pts[K];
   bool ok = true;
   TC_NOUNROLL for (int k = 0; k < K; k++) {
-    ok &= PointIO<F>::decode(shares + (size_t)k * PB, pts[k]);
-    if (c_neg[k]) pts[k].y = (-pts[k].y).norm();
+    const uint8_t* enc = io.operand(k);  // wave-uniform: stages share k of every job of the wave
+    if (applies) {
+      ok &= PointIO<F>::decode(enc, pts[k]);
+      if (c_neg[k]) pts[k].y = (-pts[k].y).norm();
+    }
   }
-  if (!ok) {
-    PointIO<F>::encode(Affine<F>::infinity(), out);
-    *status = TC_JOB_INVALID_ENCODING;
-    return true;
+  uint8_t* dst = io.result();
+  if (applies) {
+    if (!ok) {
+      PointIO<F>::encode(Affine<F>::infinity(), dst);
+      *status = TC_JOB_INVALID_ENCODING;
+    } else {
+      Jac<F> a = straus_small<F, K>(pts, c_abs);
+      PointIO<F>::encode(jac_to_affine(combine_divide(a, d_abs, d_neg)), dst);
+      *status = TC_JOB_OK;
+    }
   }
-  Jac<F> a = straus_small<F, K>(pts, c_abs);
-  PointIO<F>::encode(jac_to_affine(combine_divide(a, d_abs, d_neg)), out);
-  *status = TC_JOB_OK;
-  return true;
+  io.commit(applies);
+  return applies;
+}
+template <class F, int K>
+TC_HD bool job_combine_small(const uint64_t* idx, const uint8_t* shares, uint8_t* out, uint8_t* status) {
+  DirectIO io{shares, (size_t)PointIO<F>::BYTES, out};
+  return job_combine_small_io<F, K>(idx, true, io, status);
 }
 
 // class of the job's denominator (kCombineClass*); generic when the fast path does not apply
@@ -325,6 +353,25 @@ TC_HD uint8_t job_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_
   ok &= g2_decode_uncompressed(b, qb);
   ok &= g1_decode_uncompressed(c, pc);
   ok &= g2_decode_uncompressed(d, qd);
+  if (!ok) return 0;
+  return pairing_check(pa, qb, pc, qd) ? 1 : 0;
+}
+
+// the same with the four operands fetched through IO objects (tc_stage.h: whole-wave rows through LDS); every
+// lane of the wave calls the four operand() functions, live or not
+template <class IOA, class IOB, class IOC, class IOD>
+TC_HD uint8_t job_pairing_check_io(bool live, IOA& a, IOB& b, IOC& c, IOD& d) {
+  G1Affine pa = G1Affine::infinity(), pc = G1Affine::infinity();
+  G2Affine qb = G2Affine::infinity(), qd = G2Affine::infinity();
+  bool ok = live;
+  const uint8_t* e = a.operand(0);
+  if (live) ok &= g1_decode_uncompressed(e, pa);
+  e = b.operand(0);
+  if (live) ok &= g2_decode_uncompressed(e, qb);
+  e = c.operand(0);
+  if (live) ok &= g1_decode_uncompressed(e, pc);
+  e = d.operand(0);
+  if (live) ok &= g2_decode_uncompressed(e, qd);
   if (!ok) return 0;
   return pairing_check(pa, qb, pc, qd) ? 1 : 0;
 }
