@@ -423,6 +423,18 @@ for m in (b"", b"bound check", bytes(200)):
     out = buf(192); L.hs_hash_g2(m, len(m), out); assert out.raw == o.g2_uncompressed(o.hash_g2(m))
 out = buf(192); assert L.hs_hash_g1_g2(o.g1_uncompressed(P), b"x" * 70, 70, out) == 0
 out = buf(48); L.hs_compress_g1(o.g1_uncompressed(P), out); assert out.raw == o.g1_compressed(P)
+# DKG algebra (tc_dkg.h) and the two-stage combination with a partial last chunk (tc_msm.h)
+for kk in (k, o.R - 1, int("8" * 63, 16) %% o.R):
+    out = buf(96); assert L.hs_g1_fixed_base_mul(o.fr_to_bytes(kk), out) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(o.G1_GEN, kk))
+cm = [o.E1.mul(o.G1_GEN, rnd.randrange(o.R)) for _ in range(6)]
+out = buf(96); assert L.hs_bivar_commitment_row(b"".join(o.g1_uncompressed(c) for c in cm), 2, 1, ctypes.c_uint64(7), out) == 0
+assert out.raw == o.g1_uncompressed(o.bivar_commitment_row(2, cm, 7)[1])
+pts = [o.E2.mul(Q2, rnd.randrange(1, o.R)) for _ in range(9)]; pts[4] = None
+scs = [rnd.randrange(o.R) for _ in range(9)]; scs[0] = 0; scs[1] = 2
+want = None
+for p_, s_ in zip(pts, scs): want = o.E2.add(want, o.E2.mul(p_, s_))
+words = (ctypes.c_uint32 * 72)(*[(s_ >> (32 * i)) & 0xffffffff for s_ in scs for i in range(8)])
+out = buf(192); assert L.hs_msm_g2(9, b"".join(o.g2_uncompressed(p_) for p_ in pts), words, out) == 0 and out.raw == o.g2_uncompressed(want)
 print("BOUNDS-OK")
 ''' % (os.path.join(os.path.dirname(HERE), "oracle"), lib)
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600)

@@ -137,7 +137,9 @@ TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes) {
     TC_NOUNROLL for (size_t s = 0; s < shares4; s++) {
       const uint32_t code = cc[s];
       G2Affine e = msm_load_entry(tbl + (s * 8 + (code & 7)) * kMsmEntryWords);
-      e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
+      // (column 64 adds every entry as it is: no sign select there, so that the accumulator starts from a
+      // carry-normalised y -- the lazy-limb budget of the first real addition depends on it)
+      if (col != kMsmColumns - 1) e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
       acc = jac_add_mixed(acc, e);
     }
   }
