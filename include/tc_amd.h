@@ -155,11 +155,11 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk_g1, size_t pk_stride, con
                         const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* ok);
 /* OPT-IN fast path for validating the N signature shares of each of B messages against the N public key
  * shares (the loop of examples/threshold_sig.rs:115-131 over PublicKeyShare::verify, src/lib.rs:177-179): per
- * message ONE check  e(sum_i r_i pk_i, H(m)) == e(g1, sum_i r_i sig_i)  with 64-bit r_i drawn from a ChaCha20
+ * message ONE check  e(sum_i r_i pk_i, H(m)) == e(g1, sum_i r_i sig_i)  with 63-bit r_i (four 16-bit base-|x| digits) drawn from a ChaCha20
  * stream keyed by seed32 (HOST memory in both I/O modes: 32 bytes of fresh secret randomness per call), then
  * per-share checks only for the messages whose combined check failed.  ok[j*N + i] equals
  * PublicKeyShare::verify(pk_i, sig_{j,i}, m_j) except that a message holding an invalid share is accepted as a
- * whole with probability <= 2^-64.  sig_shares: B x N x 192, pk_shares: N x 96; n_fallback (optional, host):
+ * whole with probability <= 2^-63.  sig_shares: B x N x 192, pk_shares: N x 96; n_fallback (optional, host):
  * number of messages that needed the per-share pass. */
 int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* sig_shares, const uint8_t* msgs,
                                const uint64_t* off, size_t B, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback);

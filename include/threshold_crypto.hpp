@@ -448,4 +448,107 @@ class PublicKeySet {
   std::vector<G1Bytes> commit_;
 };
 
+// ---- membership, the opt-in share validation, DKG algebra, several GPUs (round 2 of the C ABI) ---------------------
+// Uncompressed bytes from an untrusted source are NOT yet values of the reference's types: from_bytes
+// (src/lib.rs:140-146, 246-252) only admits points of the order-r subgroup, and the kernels rely on it.  Either
+// decode through from_bytes, or test with these, or run the Engine in checked-input mode.
+inline bool is_member(const G1Bytes& p, Engine& e = Engine::instance()) {
+  std::uint8_t ok = 0;
+  e.check(tc_g1_subgroup_check_batch(e.ctx(), p.data(), 1, &ok));
+  return ok != 0;
+}
+inline bool is_member(const G2Bytes& p, Engine& e = Engine::instance()) {
+  std::uint8_t ok = 0;
+  e.check(tc_g2_subgroup_check_batch(e.ctx(), p.data(), 1, &ok));
+  return ok != 0;
+}
+inline void set_input_checks(bool on, Engine& e = Engine::instance()) { e.check(tc_ctx_set_input_checks(e.ctx(), on ? 1 : 0)); }
+
+// The share-validation loop of examples/threshold_sig.rs:115-131 -- ok[j][i] = pk_shares[i].verify(shares[j][i], msgs[j])
+// (src/lib.rs:177-179) -- through one random linear combination per message (tc_verify_shares_rlc_batch; per-share checks
+// only for messages whose combined check fails).  seed: 32 bytes of fresh secret randomness.
+inline std::vector<std::vector<bool>> verify_shares_rlc_batch(const std::vector<PublicKeyShare>& pk_shares,
+                                                              const std::vector<std::vector<SignatureShare>>& shares, const Messages& msgs,
+                                                              const std::array<std::uint8_t, 32>& seed, std::uint64_t* n_fallback = nullptr,
+                                                              Engine& e = Engine::instance()) {
+  const std::size_t N = pk_shares.size(), B = shares.size();
+  if (B != msgs.size()) throw std::invalid_argument("one share row per message");
+  std::vector<std::uint8_t> pk(N * 96 + 1), sg(B * N * 192 + 1), ok(B * N + 1);
+  for (std::size_t i = 0; i < N; i++) std::memcpy(&pk[i * 96], pk_shares[i].pk.g1.data(), 96);
+  for (std::size_t j = 0; j < B; j++) {
+    if (shares[j].size() != N) throw std::invalid_argument("every message needs one share per key");
+    for (std::size_t i = 0; i < N; i++) std::memcpy(&sg[(j * N + i) * 192], shares[j][i].sig.g2.data(), 192);
+  }
+  std::uint64_t nfb = 0;
+  if (B && N) e.check(tc_verify_shares_rlc_batch(e.ctx(), pk.data(), N, sg.data(), msgs.data(), msgs.off.data(), B, seed.data(), ok.data(), &nfb));
+  if (n_fallback) *n_fallback = nfb;
+  std::vector<std::vector<bool>> out(B, std::vector<bool>(N));
+  for (std::size_t j = 0; j < B; j++)
+    for (std::size_t i = 0; i < N; i++) out[j][i] = ok[j * N + i] != 0;
+  return out;
+}
+
+// Poly::commitment (src/poly.rs:372-377) / BivarPoly::commitment (:625-632): coefficient * g1 for every Fr
+// coefficient, fixed-base on the device (LDS window table of the generator)
+inline std::vector<G1Bytes> commitment(const std::vector<FrBytes>& coeff, Engine& e = Engine::instance()) {
+  std::vector<std::uint8_t> fr(coeff.size() * 32 + 1), out(coeff.size() * 96 + 1), st(coeff.size() + 1);
+  for (std::size_t i = 0; i < coeff.size(); i++) std::memcpy(&fr[i * 32], coeff[i].data(), 32);
+  if (!coeff.empty()) e.check(tc_g1_commitment_batch(e.ctx(), fr.data(), coeff.size(), out.data(), st.data()));
+  std::vector<G1Bytes> res(coeff.size());
+  for (std::size_t i = 0; i < coeff.size(); i++) {
+    raise_status(st[i]);
+    std::memcpy(res[i].data(), &out[i * 96], 96);
+  }
+  return res;
+}
+// BivarCommitment::row (src/poly.rs:713-727): coeff holds the (degree+1)(degree+2)/2 commitments in coeff_pos order
+inline std::vector<G1Bytes> bivar_commitment_row(const std::vector<G1Bytes>& coeff, std::size_t degree, std::uint64_t x,
+                                                 Engine& e = Engine::instance()) {
+  if (coeff.size() != (degree + 1) * (degree + 2) / 2) throw std::invalid_argument("bivariate commitment size");
+  std::vector<std::uint8_t> c(coeff.size() * 96), out((degree + 1) * 96), st(degree + 1);
+  for (std::size_t i = 0; i < coeff.size(); i++) std::memcpy(&c[i * 96], coeff[i].data(), 96);
+  e.check(tc_bivar_commitment_row_batch(e.ctx(), c.data(), degree, &x, 1, out.data(), st.data()));
+  std::vector<G1Bytes> res(degree + 1);
+  for (std::size_t i = 0; i <= degree; i++) {
+    raise_status(st[i]);
+    std::memcpy(res[i].data(), &out[i * 96], 96);
+  }
+  return res;
+}
+
+// Several GPUs of one node from this process (tc_group_*): contiguous job sharding, RCCL broadcast of the key set
+class Group {
+ public:
+  explicit Group(const std::vector<int>& devices) {
+    if (tc_group_create(&g_, devices.data(), (int)devices.size()) != TC_OK) throw GpuError("tc_group_create failed");
+  }
+  ~Group() { tc_group_destroy(g_); }
+  Group(const Group&) = delete;
+  Group& operator=(const Group&) = delete;
+  int size() const { return tc_group_size(g_); }
+  void set_keyset(const std::vector<G1Bytes>& commit) {
+    std::vector<std::uint8_t> c(commit.size() * 96);
+    for (std::size_t i = 0; i < commit.size(); i++) std::memcpy(&c[i * 96], commit[i].data(), 96);
+    check(tc_group_set_keyset(g_, commit.size() - 1, c.data()));
+  }
+  // PublicKeySet::combine_signatures for B jobs of n shares each, sharded over the GPUs
+  std::vector<Signature> combine_signatures(std::size_t n, const std::vector<std::uint64_t>& idx, const std::vector<std::uint8_t>& shares,
+                                            std::vector<std::uint8_t>& status) {
+    const std::size_t B = n ? idx.size() / n : 0;
+    std::vector<std::uint8_t> out(B * 192 + 1);
+    status.assign(B, 0);
+    if (B) check(tc_group_combine_signatures(g_, n, idx.data(), shares.data(), B, out.data(), status.data()));
+    std::vector<Signature> res(B);
+    for (std::size_t j = 0; j < B; j++) std::memcpy(res[j].g2.data(), &out[j * 192], 192);
+    return res;
+  }
+  tc_group* raw() const { return g_; }
+
+ private:
+  void check(int rc) const {
+    if (rc != TC_OK) throw GpuError(std::string("libtc_amd group: ") + tc_group_last_error(g_));
+  }
+  tc_group* g_ = nullptr;
+};
+
 }  // namespace threshold_crypto

@@ -100,6 +100,42 @@ int main(int argc, char** argv) {
   fake.v[0] ^= 1;
   CHECK(!fake.verify());
   CHECK(!shares[2].decrypt_share(fake).has_value());
+  // -- membership, RLC share validation, DKG commitments, a two-worker group (round 2 of the C ABI) -----------------
+  CHECK(is_member(sig.g2) && is_member(pk_set.public_key().g1));
+  {
+    std::vector<PublicKeyShare> pks;
+    for (std::uint32_t i = 0; i < n; i++) pks.push_back(pk_set.public_key_share(i));
+    std::vector<std::vector<SignatureShare>> rows(all.begin(), all.end());
+    rows[3][2] = rows[3][5];  // node 2 sends node 5's share for message 3
+    std::array<std::uint8_t, 32> seed{};
+    for (int i = 0; i < 32; i++) seed[i] = (std::uint8_t)(i * 7 + 1);
+    std::uint64_t nfb = 0;
+    auto okm = verify_shares_rlc_batch(pks, rows, m, seed, &nfb);
+    CHECK(nfb == 1);
+    for (std::size_t j = 0; j < rows.size(); j++)
+      for (std::uint32_t i = 0; i < n; i++) CHECK(okm[j][i] == !(j == 3 && i == 2));
+    // Poly::commitment of the share scalars = the public key shares (sk_i * g1)
+    std::vector<FrBytes> frs;
+    for (std::uint32_t i = 0; i < n; i++) frs.push_back(shares[i].key().fr());
+    auto cm = commitment(frs);
+    for (std::uint32_t i = 0; i < n; i++) CHECK(cm[i] == pks[i].pk.g1);
+    // BivarCommitment::row of the degree-0 "matrix" {c} is {c}; of degree 1 with x = 0 it is (c00, c01)
+    std::vector<G1Bytes> bc = {cm[0], cm[1], cm[2]};
+    auto row0 = bivar_commitment_row(bc, 1, 0);
+    CHECK(row0[0] == cm[0] && row0[1] == cm[1]);
+    // two workers on GPU 0 (no RCCL with duplicate devices: test configuration), same bytes as one context
+    Group grp({0, 0});
+    grp.set_keyset(commit);
+    std::vector<std::uint64_t> gidx;
+    std::vector<std::uint8_t> gsh, gst;
+    for (std::size_t j = 0; j < jobs.size(); j++)
+      for (const auto& kv : jobs[j]) {
+        gidx.push_back(kv.first);
+        gsh.insert(gsh.end(), kv.second.sig.g2.begin(), kv.second.sig.g2.end());
+      }
+    auto gsig = grp.combine_signatures(4, gidx, gsh, gst);
+    for (std::size_t j = 0; j < jobs.size(); j++) CHECK(gst[j] == 0 && gsig[j] == combined[j]);
+  }
   std::puts("CPP-API-OK");
   return 0;
 }

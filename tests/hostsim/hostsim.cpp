@@ -274,17 +274,21 @@ int hs_fr_interpolate(size_t n, const uint32_t* xs, const uint32_t* ys, uint32_t
 }
 
 // ---- two-stage G2 linear combination (tc_msm.h): stage T for every chunk, then stage L ----------------------
+int hs_msm_g2_nbits(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out192, int nbits);
 int hs_msm_g2(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out192) {
+  return hs_msm_g2_nbits(n, points, scalars, out192, 64);
+}
+int hs_msm_g2_nbits(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out192, int nbits) {
   const size_t chunks = msm_chunks(n), shares4 = chunks * kMsmChunk;
   std::vector<int32_t> tbl(shares4 * 8 * kMsmEntryWords);
   std::vector<uint8_t> codes(kMsmColumns * shares4);
   bool ok = true;
-  for (size_t c = 0; c < chunks; c++) ok &= job_msm_tables(n, c, points, scalars, tbl.data(), codes.data(), true);
+  for (size_t c = 0; c < chunks; c++) ok &= job_msm_tables(n, c, points, scalars, tbl.data(), codes.data(), true, nbits);
   if (!ok) {
     g2_encode_uncompressed(G2Affine::infinity(), out192);
     return TC_JOB_INVALID_ENCODING;
   }
-  g2_encode_uncompressed(jac_to_affine(job_msm_ladder(n, tbl.data(), codes.data())), out192);
+  g2_encode_uncompressed(jac_to_affine(job_msm_ladder(n, tbl.data(), codes.data(), nbits)), out192);
   return TC_JOB_OK;
 }
 

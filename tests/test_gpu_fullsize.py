@@ -338,3 +338,57 @@ def test_rlc_share_validation_equals_per_share_path(engine):
     assert ok.all() and nfb == 0
     # one of the oracle's own checks on a sampled share
     assert c.verify(bytes(pks[3]), bytes(bad[5, 3]), msgs[5]) == 0 and c.verify(bytes(pks[4]), bytes(bad[5, 3]), msgs[5]) == 1
+
+
+def test_large_threshold_g1_and_g2_combination_vs_oracle(engine):
+    """t = 9 and t = 21 through BOTH groups: G2 takes the two-stage kernels (k_lagrange_all + k_msm_*), G1 the
+    chunked Straus path fed by the same one-inversion Lagrange kernel; every job against Oracle B, including a job
+    with a repeated index (filtered by value, src/lib.rs:758) and one whose index list is not sorted."""
+    rnd = random.Random(4242)
+    for t in (9, 21):
+        N, B = 40, 70
+        poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+        h2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+        h1 = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        sk = [o.secret_key_share(poly, i) for i in range(N)]
+        s2 = [u8(o.g2_uncompressed(o.E2.mul(h2, k))) for k in sk]
+        s1 = [u8(o.g1_uncompressed(o.E1.mul(h1, k))) for k in sk]
+        idx = np.zeros((B, t + 2), dtype=np.uint64)            # one surplus sample per job: take(t + 1) ignores it
+        for j in range(B):
+            idx[j] = sorted(rnd.sample(range(N), t + 2))
+        idx[3, 5] = idx[3, 2]                                   # duplicate index
+        idx[4, :4] = idx[4, :4][::-1].copy()                    # unsorted head
+        sh2 = np.stack([np.stack([s2[int(i)] for i in row]) for row in idx])
+        sh1 = np.stack([np.stack([s1[int(i)] for i in row]) for row in idx])
+        out2, st2 = engine.combine_g2(t, idx, sh2)
+        out1, st1 = engine.combine_g1(t, idx, sh1)
+        assert not st2.any() and not st1.any()
+        for j in range(B):
+            ids = [int(i) for i in idx[j]]
+            rc, want = c.combine_g2(t, ids, [bytes(x) for x in sh2[j]])
+            assert rc == 0 and bytes(out2[j]) == want, (t, j)
+            rc, want = c.combine_g1(t, ids, [bytes(x) for x in sh1[j]])
+            assert rc == 0 and bytes(out1[j]) == want, (t, j)
+        assert bytes(out2[0]) == o.g2_uncompressed(o.E2.mul(h2, poly[0])) and bytes(out1[0]) == o.g1_uncompressed(o.E1.mul(h1, poly[0]))
+
+
+def test_config5_one_gpu_slice_properties(engine):
+    """BASELINE config 5 (t=67, N=200): one GPU's share of the 1 048 576-job batch (131 072 jobs; the other seven
+    run the same code on other job indices) -- sign on the device, combine, verify; size-independent properties on
+    EVERY job: no status errors, every signature verifies and equals the master key's own signature of the job's hash
+    point; the first jobs are also recomputed by Oracle B.  TC_TEST_CONFIG5_JOBS shrinks it for local iterations."""
+    import os
+    import torch
+    from threshold_crypto_amd import config5
+    B = int(os.environ.get("TC_TEST_CONFIG5_JOBS", "131072"))
+    res = config5.run_pipeline(engine, 67, 200, B, 0, 1, device=torch.device("cuda", 0), steps=1,
+                               sync=lambda: (engine.sync(), torch.cuda.synchronize()))
+    assert res["status_errors"] == 0 and res["valid_local"] == B == res["valid_total"]
+    msk = res["secret_key_set"].poly[0]
+    msig, st = engine.g2_mul(torch.from_numpy(u8(msk.to_bytes(32, "little"))[None].copy()).cuda(), res["hashes"])
+    assert not st.any() and bool((msig[:, 0].cpu() == torch.from_numpy(res["sig"])).all())
+    km, hashes = res["key_material"], res["hashes"].cpu().numpy()
+    for j in range(2):
+        shares = [c.g2_mul(bytes(km.sk_table[int(i)]), bytes(hashes[j]))[1] for i in res["idx"][j]]
+        rc, want = c.combine_g2(67, [int(i) for i in res["idx"][j]], shares)
+        assert rc == 0 and want == res["sig"][j].tobytes()

@@ -613,3 +613,29 @@ def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
         assert L.hs_lagrange_all((ctypes.c_uint64 * len(ids))(*ids), t, out) == 0
         got = [sum(out[8 * k + i] << (32 * i) for i in range(8)) for k in range(t + 1)]
         assert got == o.lagrange_coeffs(t, [o.into_fr_plus_1(i) for i in ids]), ids
+
+
+def test_two_stage_msm_short_scalar_mode(L, rnd):
+    """tc_msm.h with 16-bit base-|x| digits (the random scalars of the batch share validation): 16 doublings; a
+    scalar that is even or has a long digit fails the job."""
+    X = o.BLS_X
+    n = 10
+    pts = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(n)]
+    sc = []
+    for _ in range(n):
+        d = [rnd.randrange(1 << 16) for _ in range(4)]
+        d[0] |= 1
+        sc.append(d[0] + d[1] * X + d[2] * X ** 2 + d[3] * X ** 3)
+    sc[0] = 1
+    sc[1] = (2 ** 16 - 1) * (1 + X + X ** 2 + X ** 3)
+    want = None
+    for p, s in zip(pts, sc):
+        want = o.E2.add(want, o.E2.mul(p, s))
+    enc = b"".join(o.g2_uncompressed(p) for p in pts)
+    words = lambda v: (ctypes.c_uint32 * (8 * n))(*[(s >> (32 * i)) & 0xffffffff for s in v for i in range(8)])
+    out = buf(192)
+    assert L.hs_msm_g2_nbits(n, enc, words(sc), out, 16) == 0 and out.raw == o.g2_uncompressed(want)
+    out64 = buf(192)
+    assert L.hs_msm_g2_nbits(n, enc, words(sc), out64, 64) == 0 and out64.raw == out.raw
+    assert L.hs_msm_g2_nbits(n, enc, words([sc[0] + 1] + sc[1:]), buf(192), 16) == 3          # even
+    assert L.hs_msm_g2_nbits(n, enc, words([sc[0] + (1 << 16)] + sc[1:]), buf(192), 16) == 3  # a 17-bit digit

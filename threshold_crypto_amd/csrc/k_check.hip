@@ -45,8 +45,11 @@ __global__ void k_invalidate_jobs(const uint8_t* __restrict__ valid, size_t per_
   }
 }
 
-// r[i] = a non-zero 64-bit scalar (32 B LE, upper bytes zero) from ChaCha20(key = seed, block counter = i):
-// unpredictable to whoever produced the shares as long as the seed is drawn after they were received
+// r[i] = d0 + d1 |x| + d2 |x|^2 + d3 |x|^3 with four 16-bit digits from ChaCha20(key = seed, block counter = i), d0
+// odd: 2^63 equally likely scalars, pairwise distinct mod r (base-|x| digits are unique), so a bad share survives
+// the combined check with probability <= 2^-63 -- and on G2, where psi = [x], the multiplication is a 16-column
+// ladder over the psi-images (tc_msm.h short-scalar mode).  Unpredictable to whoever produced the shares as long as
+// the seed is drawn after they were received.  Output: 32 B little-endian canonical scalars (r[i] < 2^208).
 __global__ void k_rlc_scalars(const uint8_t* __restrict__ seed32, size_t n, uint8_t* __restrict__ out_fr) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -56,12 +59,20 @@ __global__ void k_rlc_scalars(const uint8_t* __restrict__ seed32, size_t n, uint
   ChaChaRng rng;
   rng.init(key);
   rng.counter = i;
-  const uint32_t lo = rng.next_u32() | 1u, hi = rng.next_u32();
-  for (int b = 0; b < 32; b++) out_fr[i * 32 + b] = 0;
-  for (int b = 0; b < 4; b++) {
-    out_fr[i * 32 + b] = (uint8_t)(lo >> (8 * b));
-    out_fr[i * 32 + 4 + b] = (uint8_t)(hi >> (8 * b));
+  const uint32_t w0 = rng.next_u32(), w1 = rng.next_u32();
+  const uint64_t d[4] = {(uint64_t)(w0 & 0xffffu) | 1ull, (uint64_t)(w0 >> 16), (uint64_t)(w1 & 0xffffu), (uint64_t)(w1 >> 16)};
+  // Horner in base |x| on 4 x 64-bit words: acc = ((d3 X + d2) X + d1) X + d0 < 2^208
+  uint64_t acc[4] = {d[3], 0, 0, 0};
+  for (int j = 2; j >= 0; j--) {
+    unsigned __int128 carry = d[j];
+    for (int w = 0; w < 4; w++) {
+      carry += (unsigned __int128)acc[w] * BLS_X_ABS;
+      acc[w] = (uint64_t)carry;
+      carry >>= 64;
+    }
   }
+  for (int w = 0; w < 4; w++)
+    for (int b = 0; b < 8; b++) out_fr[i * 32 + 8 * w + b] = (uint8_t)(acc[w] >> (8 * b));
 }
 __global__ void k_gather_rows(const uint8_t* __restrict__ src, size_t row_words, const uint32_t* __restrict__ map, size_t rows,
                               uint8_t* __restrict__ dst) {

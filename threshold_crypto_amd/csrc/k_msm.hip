@@ -9,21 +9,21 @@ namespace tc {
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_tables(size_t n, size_t pts_stride, const uint8_t* __restrict__ points,
                                                                   const uint32_t* __restrict__ scalars, size_t B,
                                                                   int32_t* __restrict__ tbl, uint8_t* __restrict__ codes,
-                                                                  uint8_t* __restrict__ status) {
+                                                                  uint8_t* __restrict__ status, int nbits) {
   const size_t chunks = msm_chunks(n);
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (tid >= B * chunks) return;
   const size_t j = tid / chunks, c = tid % chunks;
   const size_t shares4 = chunks * kMsmChunk;
   const bool ok = job_msm_tables(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + j * shares4 * 8 * kMsmEntryWords,
-                                 codes + j * kMsmColumns * shares4, pair_leader());
+                                 codes + j * kMsmColumns * shares4, pair_leader(), nbits);
   if (!ok && pair_leader() && status[j] == TC_JOB_OK) status[j] = TC_JOB_INVALID_ENCODING;
 }
 
 // stage L: one lane pair per job
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder(size_t n, size_t B, const int32_t* __restrict__ tbl,
                                                                   const uint8_t* __restrict__ codes, uint8_t* __restrict__ out,
-                                                                  const uint8_t* __restrict__ status) {
+                                                                  const uint8_t* __restrict__ status, int nbits) {
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
   if (status[j] != TC_JOB_OK) {
@@ -31,20 +31,22 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder(size_t n, si
     return;
   }
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
-  const G2Jac r = job_msm_ladder(n, tbl + j * shares4 * 8 * kMsmEntryWords, codes + j * kMsmColumns * shares4);
+  const G2Jac r = job_msm_ladder(n, tbl + j * shares4 * 8 * kMsmEntryWords, codes + j * kMsmColumns * shares4, nbits);
   g2_encode_uncompressed(jac_to_affine(r), out + j * 192);
 }
 
 size_t msm_table_bytes(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWords * sizeof(int32_t); }
 size_t msm_code_bytes(size_t n, size_t B) { return B * kMsmColumns * msm_chunks(n) * kMsmChunk; }
 // status: B bytes, TC_JOB_OK for the jobs to run (others get the identity and keep their status)
+// nbits = 64: any scalars below r.  nbits < 64: odd scalars whose four base-|x| digits are below 2^nbits (a job with
+// another scalar fails): nbits doublings instead of 64.
 void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
-                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status) {
+                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits) {
   if (!B || !n) return;
   const size_t lanes = B * msm_chunks(n) * kG2Lanes;
-  hipLaunchKernelGGL(k_msm_tables, dim3(grid_for(lanes)), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status);
+  hipLaunchKernelGGL(k_msm_tables, dim3(grid_for(lanes)), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status, nbits);
   hipLaunchKernelGGL(k_msm_ladder, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                     (const uint8_t*)status);
+                     (const uint8_t*)status, nbits);
 }
 
 }  // namespace tc

@@ -190,10 +190,10 @@ bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
 // sum_i scalars[j][i] * points[j][i] in G2 for n >= kMsmMinPoints through the two-stage kernels (k_msm.hip);
 // d_st must hold B zeroed-or-flagged status bytes
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
-            uint8_t* d_st) {
+            uint8_t* d_st, int nbits = 64) {
   int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes(n, B) / sizeof(int32_t));
   uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, B));
-  if (!k.failed) tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts, d_scalars, B, d_tbl, d_codes, d_out, d_st);
+  if (!k.failed) tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts, d_scalars, B, d_tbl, d_codes, d_out, d_st, nbits);
 }
 
 #define TC_REQUIRE(cond)            \
@@ -467,7 +467,8 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
     }
     if (g2 && t + 1 >= tc::kMsmMinPoints) msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds
     else if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
-    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need);
+    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st,
+                               t + 1 >= tc::kMsmMinPoints ? nullptr : d_need);  // (k_lagrange_all does not count: every job is general)
     k.apply_checks(B, d_st, d_pt, PB, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
   }
@@ -637,9 +638,9 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
 
 // Share validation by ONE random linear combination per message (opt-in fast path of the loop at
 // examples/threshold_sig.rs:115-131): instead of N pairing checks  e(pk_i, H(m)) == e(g1, sig_i)  the device
-// checks  e(sum_i r_i pk_i, H(m)) == e(g1, sum_i r_i sig_i)  with secret 64-bit r_i, which holds whenever all N
-// do and fails with probability >= 1 - 2^-64 otherwise; messages whose combined check fails are re-checked
-// share by share, so ok[] equals the per-share path's (up to that 2^-64).
+// checks  e(sum_i r_i pk_i, H(m)) == e(g1, sum_i r_i sig_i)  with secret r_i (2^63 values), which holds whenever all N
+// do and fails with probability >= 1 - 2^-63 otherwise; messages whose combined check fails are re-checked
+// share by share, so ok[] equals the per-share path's (up to that 2^-63).
 int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* sig_shares, const uint8_t* msgs,
                                const uint64_t* off, size_t B, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
   TC_REQUIRE(ctx);
@@ -675,9 +676,9 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
   std::vector<uint8_t> h_okmsg(B);
   if (!k.failed) {
     tc::launch_rlc_scalars(ctx->stream, d_seed, B * N, d_r);
-    if (N >= tc::kMsmMinPoints) {
+    if (N >= 2) {  // (the two-stage kernels' short-scalar mode: 16 doublings for the 64-bit random scalars)
       k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
-      msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS);
+      msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16);  // short scalars
     } else {
       tc::launch_lincomb_g2(ctx->stream, N, d_r, d_sig, B, d_S, d_stS);
     }

@@ -68,14 +68,17 @@ struct SacDigits {
   uint32_t top;   // bit j-1: u_j[64]
   bool fix;
 };
-TC_HD SacDigits sac_recode4(const uint64_t* d) {
+// nbits < 64: the same recoding for SHORT digits (every d_j < 2^nbits): columns 0 .. nbits, the leading +1 at
+// column nbits -- a ladder of nbits doublings instead of 64 (tc_msm.h uses 16-bit digits for the random scalars of
+// the batch share validation).
+TC_HD SacDigits sac_recode4(const uint64_t* d, int nbits = 64) {
   SacDigits r;
   r.fix = (d[0] & 1ull) == 0;
   r.neg = ~((d[0] | 1ull) >> 1);
   r.top = 0;
   TC_NOUNROLL for (int j = 0; j < 3; j++) {
     uint64_t k = d[j + 1], u = 0;
-    TC_NOUNROLL for (int i = 0; i < 64; i++) {
+    TC_NOUNROLL for (int i = 0; i < nbits; i++) {
       const uint64_t odd = k & 1ull;
       u |= odd << i;
       k = (k >> 1) + (odd & (r.neg >> i));  // (k - s_i) / 2

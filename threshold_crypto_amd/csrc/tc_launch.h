@@ -64,7 +64,7 @@ constexpr size_t kMsmMinPoints = 8;
 size_t msm_table_bytes(size_t n, size_t B);
 size_t msm_code_bytes(size_t n, size_t B);
 void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
-                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status);
+                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits = 64);
 
 // opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
 // records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an

@@ -19,7 +19,8 @@ namespace tc {
 constexpr int kMsmChunk = 4;          // shares per stage-T lane pair
 constexpr int kMsmEntryWords = 64;    // one table entry: x (2 x 16 words), y (2 x 16 words); word 15 of x[0] = flags
 constexpr int kMsmCoordWords = 16;    // 14 limbs + 2 words of padding: one 64-byte row per coordinate and lane
-constexpr int kMsmColumns = 65;       // digit columns 0 .. 64 (column 64: the leading +1 of the sign-aligned form)
+constexpr int kMsmColumns = 65;       // digit columns 0 .. 64 (column 64: the leading +1 of the sign-aligned form);
+                                      // short scalars (all four base-|x| digits below 2^nbits) use columns 0 .. nbits
 
 TC_HD size_t msm_chunks(size_t n) { return (n + kMsmChunk - 1) / kMsmChunk; }
 
@@ -79,7 +80,7 @@ TC_HD G2Affine msm_load_entry(const int32_t* e) {
 //          bit 3 = subtract
 // Returns false when a point or scalar of the chunk does not decode (the job then fails as a whole).
 TC_HD bool job_msm_tables(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes,
-                          bool leader) {
+                          bool leader, int nbits = 64) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G2Jac sums[7 * kMsmChunk];
   G2Affine b0[kMsmChunk];
@@ -96,8 +97,20 @@ TC_HD bool job_msm_tables(size_t n, size_t c, const uint8_t* points, const uint3
     }
     if (!ok) p = G2Affine::infinity();
     uint64_t d[4];
-    const bool flip = gls_decompose_odd(sc, d);
-    sd[k] = sac_recode4(d);
+    bool flip = gls_decompose_odd(sc, d);
+    if (nbits < 64) {
+      // short-scalar mode: the caller promises odd scalars d0 + d1 |x| + d2 |x|^2 + d3 |x|^3 with digits below
+      // 2^nbits (never flipped: r - k would not be short); anything else fails the job
+      uint64_t dd[4];
+      gls_decompose(sc, dd);
+      bool fits = (sc[0] & 1u) != 0 || s >= n;
+      TC_UNROLL for (int j = 0; j < 4; j++) fits = fits && (dd[j] >> nbits) == 0;
+      if (s >= n) dd[0] = 1, dd[1] = dd[2] = dd[3] = 0;
+      ok &= fits;
+      TC_UNROLL for (int j = 0; j < 4; j++) d[j] = fits ? dd[j] : (uint64_t)(j == 0);
+      flip = false;
+    }
+    sd[k] = sac_recode4(d, nbits);
     G2Affine base[4];
     g2_gls_bases(p, base);
     TC_NOUNROLL for (int j = 0; j < 4; j++) base[j].y = Fq2::select(flip, -base[j].y, base[j].y).norm();
@@ -116,30 +129,30 @@ TC_HD bool job_msm_tables(size_t n, size_t c, const uint8_t* points, const uint3
     msm_store_entry(t, b0[k]);
     TC_NOUNROLL for (int m = 1; m < 8; m++) msm_store_entry(t + m * kMsmEntryWords, aff[7 * k + m - 1]);
     if (leader) {
-      TC_NOUNROLL for (int col = 0; col < 64; col++) {
+      TC_NOUNROLL for (int col = 0; col < nbits; col++) {
         const uint32_t m = (uint32_t)((sd[k].u[0] >> col) & 1) | ((uint32_t)((sd[k].u[1] >> col) & 1) << 1) |
                            ((uint32_t)((sd[k].u[2] >> col) & 1) << 2);
         codes[(size_t)col * shares4 + s] = (uint8_t)(m | (((sd[k].neg >> col) & 1) << 3));
       }
-      codes[(size_t)64 * shares4 + s] = (uint8_t)sd[k].top;  // column 64: every share adds +tbl[top]
+      codes[(size_t)nbits * shares4 + s] = (uint8_t)sd[k].top;  // top column: every share adds +tbl[top]
     }
   }
   return ok;
 }
 
 // Stage L: sum over the (4 * chunks) shares of one job from its tables and digit codes
-TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes) {
+TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits = 64) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G2Jac acc = G2Jac::infinity();
-  TC_NOUNROLL for (int col = kMsmColumns - 1; col >= 0; col--) {
-    if (col != kMsmColumns - 1) acc = jac_dbl(acc);
+  TC_NOUNROLL for (int col = nbits; col >= 0; col--) {
+    if (col != nbits) acc = jac_dbl(acc);
     const uint8_t* cc = codes + (size_t)col * shares4;
     TC_NOUNROLL for (size_t s = 0; s < shares4; s++) {
       const uint32_t code = cc[s];
       G2Affine e = msm_load_entry(tbl + (s * 8 + (code & 7)) * kMsmEntryWords);
-      // (column 64 adds every entry as it is: no sign select there, so that the accumulator starts from a
+      // (the top column adds every entry as it is: no sign select there, so that the accumulator starts from a
       // carry-normalised y -- the lazy-limb budget of the first real addition depends on it)
-      if (col != kMsmColumns - 1) e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
+      if (col != nbits) e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
       acc = jac_add_mixed(acc, e);
     }
   }
