@@ -292,6 +292,19 @@ int hs_msm_g2_nbits(size_t n, const uint8_t* points, const uint32_t* scalars, ui
   return TC_JOB_OK;
 }
 
+int hs_lagrange_split(const uint64_t* idx, int t, uint32_t* out) {  // k_lagrange_den + k_lagrange_finish, lane by lane
+  const int n = t + 1;
+  std::vector<uint32_t> xm(n * 8), den(n * 8), pre(n * 8);
+  for (int i = 0; i < n; i++) {
+    const Fr x = fr_from_u64(idx[i]) + Fr::one();
+    for (int w = 0; w < 8; w++) xm[i * 8 + w] = x.v.l[w];
+  }
+  for (int i = 0; i < n; i++) {
+    const Fr d = lagrange_denominator((const uint32_t*)xm.data(), idx, n, i);
+    for (int w = 0; w < 8; w++) den[i * 8 + w] = d.v.l[w];
+  }
+  return lagrange_finish(n, xm.data(), den.data(), pre.data(), out);
+}
 int hs_lagrange_all(const uint64_t* idx, int t, uint32_t* out) {
   std::vector<uint32_t> ws(4 * (size_t)(t + 1) * 8);
   return lagrange_all_at_zero(idx, t, out, ws.data());

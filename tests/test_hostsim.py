@@ -613,6 +613,8 @@ def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
         assert L.hs_lagrange_all((ctypes.c_uint64 * len(ids))(*ids), t, out) == 0
         got = [sum(out[8 * k + i] << (32 * i) for i in range(8)) for k in range(t + 1)]
         assert got == o.lagrange_coeffs(t, [o.into_fr_plus_1(i) for i in ids]), ids
+        out2 = (ctypes.c_uint32 * (8 * (t + 1)))()
+        assert L.hs_lagrange_split((ctypes.c_uint64 * len(ids))(*ids), t, out2) == 0 and list(out2) == list(out)   # the device's two-kernel split
 
 
 def test_two_stage_msm_short_scalar_mode(L, rnd):

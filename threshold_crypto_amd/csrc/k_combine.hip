@@ -23,8 +23,46 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t
   if (st && status) status[j] = st;
 }
 
-// one lane per JOB: all t+1 coefficients with one inversion (tc_threshold.h lagrange_all_at_zero); used for the
-// large thresholds, where no job takes the small-index fast path
+// Large thresholds (no job takes the small-index fast path): all t+1 coefficients of a job with ONE inversion
+// (tc_threshold.h), in two kernels.
+//   k_lagrange_den     one lane per (job, i): the O(t^2) part.  A 256-lane workgroup takes floor(256 / (t+1)) jobs;
+//                      their abscissae x_i = idx_i + 1 go to LDS in Montgomery form (one conversion per lane, every
+//                      lane then reads all t+1 of its job: broadcast reads, no bank conflicts), the denominators
+//                      and the abscissae to HBM for the second kernel.
+//   k_lagrange_finish  one lane per job: prefix products, the inversion, lambda_i.
+constexpr int kLagBlock = 256;
+constexpr int kLagMaxN = 256;  // t + 1 above this falls back to one lane per job (k_lagrange_all)
+__global__ __launch_bounds__(kLagBlock) void k_lagrange_den(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
+                                                          uint32_t* __restrict__ xm, uint32_t* __restrict__ den) {
+  __shared__ uint32_t xs[kLagMaxN * 8];
+  const int n = (int)t + 1;
+  const int jobs_per_block = kLagBlock / n;
+  const int jl = (int)threadIdx.x / n, i = (int)threadIdx.x % n;
+  const size_t j = (size_t)blockIdx.x * jobs_per_block + jl;
+  const bool live = jl < jobs_per_block && j < B;
+  if (live) {
+    const Fr x = fr_from_u64(idx[j * n_per_job + i]) + Fr::one();
+    TC_UNROLL for (int w = 0; w < 8; w++) {
+      xs[(jl * n + i) * 8 + w] = x.v.l[w];
+      xm[(j * n + i) * 8 + w] = x.v.l[w];
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const Fr d = lagrange_denominator((const uint32_t*)(xs + jl * n * 8), idx + j * n_per_job, n, i);
+    TC_UNROLL for (int w = 0; w < 8; w++) den[(j * n + i) * 8 + w] = d.v.l[w];
+  }
+}
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange_finish(size_t t, size_t B, const uint32_t* __restrict__ xm,
+                                                                       const uint32_t* __restrict__ den, uint32_t* __restrict__ pre,
+                                                                       uint32_t* __restrict__ lam, uint8_t* __restrict__ status) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= B) return;
+  const size_t n = t + 1;
+  const uint8_t st = lagrange_finish((int)n, xm + j * n * 8, den + j * n * 8, pre + j * n * 8, lam + j * n * 8);
+  if (st && status) status[j] = st;
+}
+// one lane per JOB for everything (t + 1 > 256)
 __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange_all(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
                                                                     uint32_t* __restrict__ lam, uint32_t* __restrict__ ws,
                                                                     uint8_t* __restrict__ status) {
@@ -165,7 +203,19 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
 size_t lagrange_all_ws_words(size_t t, size_t B) { return B * 4 * (t + 1) * 8; }
 void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
                          uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_lagrange_all, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, ws, status);
+  if (!B) return;
+  const size_t n = t + 1;
+  if (n > (size_t)kLagMaxN) {
+    hipLaunchKernelGGL(k_lagrange_all, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, ws, status);
+    return;
+  }
+  uint32_t* xm = ws;                 // ws: 4 (t+1) x 8 words per job; the first three quarters are used here
+  uint32_t* den = ws + B * n * 8;
+  uint32_t* pre = ws + 2 * B * n * 8;
+  const size_t jobs_per_block = (size_t)kLagBlock / n;
+  hipLaunchKernelGGL(k_lagrange_den, dim3((unsigned)((B + jobs_per_block - 1) / jobs_per_block)), dim3(kLagBlock), 0, st, idx, n_per_job, t, B, xm,
+                     den);
+  hipLaunchKernelGGL(k_lagrange_finish, dim3(grid_for(B)), dim3(kBlock), 0, st, t, B, (const uint32_t*)xm, (const uint32_t*)den, pre, lam, status);
 }
 // need_general: one zeroed word the Lagrange stage counts non-fast jobs in (nullptr when t == 0: no
 // Lagrange stage, the general kernel takes every job)

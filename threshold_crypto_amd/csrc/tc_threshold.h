@@ -77,6 +77,54 @@ TC_HD uint8_t lagrange_all_at_zero(const uint64_t* idx, int t, uint32_t* out, ui
   return TC_JOB_OK;
 }
 
+// The same computation split for the device (k_combine.hip k_lagrange_den / k_lagrange_finish): the O(t^2)
+// denominators are one lane per (job, i) with the job's abscissae staged in LDS; the prefix products, the single
+// inversion and the coefficients are one lane per job.
+//   den_i = prod_{j : idx_j != idx_i} (x_j - x_i), x in Montgomery form (xs: n x 8 words, any address space)
+template <class XS>
+TC_HD Fr lagrange_denominator(XS xs, const uint64_t* idx, int n, int i) {
+  auto get = [&](int k) { Fr v; TC_UNROLL for (int w = 0; w < 8; w++) v.v.l[w] = xs[k * 8 + w]; return v; };
+  const Fr xi = get(i);
+  const uint64_t vi = idx[i];
+  Fr d = Fr::one();
+  TC_NOUNROLL for (int j = 0; j < n; j++) {
+    if (idx[j] != vi) d = d * (get(j) - xi);
+  }
+  return d;
+}
+//   xm, den: n x 8 words (Montgomery) as written by the denominator stage; pre: n x 8 words of scratch
+TC_HD uint8_t lagrange_finish(int n, const uint32_t* xm, const uint32_t* den, uint32_t* pre, uint32_t* out) {
+  auto put = [](uint32_t* dst, const Fr& v) { TC_UNROLL for (int i = 0; i < 8; i++) dst[i] = v.v.l[i]; };
+  auto get = [](const uint32_t* src) { Fr v; TC_UNROLL for (int i = 0; i < 8; i++) v.v.l[i] = src[i]; return v; };
+  const Fr one = Fr::one();
+  Fr accd = one;
+  TC_NOUNROLL for (int i = 0; i < n; i++) {
+    put(pre + (size_t)i * 8, accd);
+    accd = accd * get(den + (size_t)i * 8);
+  }
+  if (accd.is_zero()) {
+    TC_NOUNROLL for (int k = 0; k < n * 8; k++) out[k] = 0;
+    return TC_JOB_DUPLICATE_ENTRY;
+  }
+  // lambda_i = (prod_{k < i} x_k) (prod_{k > i} x_k) / den_i: the prefix products of x are rebuilt on the way back
+  // from the total (one more inversion-free pass: P_i = P_{i+1} / x_i is avoided by keeping them in `out`)
+  Fr accx = one;
+  TC_NOUNROLL for (int i = 0; i < n; i++) {
+    put(out + (size_t)i * 8, accx);  // prod_{k < i} x_k, parked in the output buffer
+    accx = accx * get(xm + (size_t)i * 8);
+  }
+  Fr inv = accd.inv();
+  Fr sufx = one;
+  TC_NOUNROLL for (int i = n - 1; i >= 0; i--) {
+    const Fr dinv = inv * get(pre + (size_t)i * 8);
+    inv = inv * get(den + (size_t)i * 8);
+    const Fr lam = get(out + (size_t)i * 8) * sufx * dinv;
+    sufx = sufx * get(xm + (size_t)i * 8);
+    lam.to_canonical(out + (size_t)i * 8);
+  }
+  return TC_JOB_OK;
+}
+
 // sum_{k < K} s_k * P_k for K <= 4 points with per-lane 255-bit scalars: joint (Straus)
 // double-and-add over a (2^K - 1)-entry subset-sum table held in the lane's scratch.
 // One shared doubling chain for the K points; control flow is lane-uniform except the
