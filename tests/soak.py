@@ -78,7 +78,7 @@ while time.time() < t_end:
                 fail("g1_mul", rounds, j)
     checked += 2 * B * S
     # ---- combine (G2 and G1), mixed index patterns --------------------------------------------------
-    t = rnd.choice([1, 2, 3, 3, 3, 5])
+    t = rnd.choice([1, 2, 3, 3, 3, 5, 7, 8, 12])   # 7+ : the two-stage large-threshold path in G2
     n = t + 1 + rnd.choice([0, 0, 1])
     N = rnd.choice([t + 2, 10, 40, 200])
     idx = np.zeros((B, n), np.uint64)
@@ -196,6 +196,46 @@ while time.time() < t_end:
         if int(okd[j]) != int(want_d):
             fail("verify_decryption_share", rounds, j)
     checked += Bc * (Sc + 4)
+    # ---- round-2 entries: on-device share generation, fixed-base commitments, membership, RLC share validation --
+    Bg = min(B, 24)
+    Ng, ng = rnd.choice([5, 12, 200]), rnd.choice([1, 3, 4, 5, 9])
+    skt = [rnd.choice([0, 1, o.R - 1, rnd.randrange(o.R)]) for _ in range(Ng)]
+    gidx = np.array([[rnd.randrange(Ng + (1 if rnd.random() < 0.05 else 0)) for _ in range(ng)] for _ in range(Bg)], dtype=np.uint64)
+    hp = [maybe_corrupt(rnd.choice(pool2)) for _ in range(Bg)]
+    gs, gst = e.sign_shares_g2(np.stack([u8(fr(k)) for k in skt]), gidx, np.stack([u8(p) for p in hp]))
+    for j in range(Bg):
+        for k_ in range(ng):
+            i_ = int(gidx[j, k_])
+            rc, want = c_oracle.g2_mul(fr(skt[i_]), hp[j]) if i_ < Ng else (3, b"")
+            if (gst[j, k_] != 0) != (rc != 0) or (rc == 0 and bytes(gs[j, k_]) != want):
+                fail("sign_shares_g2", rounds, j, "k=%d idx=%d" % (k_, i_))
+    cks = [rnd.choice([0, 1, 8, 9, o.R - 1, rnd.randrange(o.R), rnd.randrange(1 << 64)]) for _ in range(Bg)]
+    cm_, cst = e.g1_commitment(np.stack([u8(fr(k)) for k in cks]))
+    for j in range(Bg):
+        rc, want = c_oracle.g1_mul(fr(cks[j]), G1U)
+        if cst[j] != 0 or bytes(cm_[j]) != want:
+            fail("g1_commitment", rounds, j)
+    mem2 = e.g2_subgroup_check(np.stack([u8(p) for p in hp]))
+    for j in range(Bg):
+        if int(mem2[j]) != int(c_oracle.g2_mul(fr(1), hp[j])[0] == 0):      # pool points are members; corrupted ones are off the curve
+            fail("g2_subgroup_check", rounds, j)
+    Nr = rnd.choice([2, 3, 10])
+    rsk = [rnd.randrange(1, o.R) for _ in range(Nr)]
+    rpk = np.stack([u8(c_oracle.g1_mul(fr(k), G1U)[1]) for k in rsk])
+    rm = msgs[:Bg]
+    rflat, roff = pack_messages(rm)
+    rsig = np.zeros((Bg, Nr, 192), np.uint8)
+    rexp = np.ones((Bg, Nr), np.uint8)
+    for j in range(Bg):
+        hj = c_oracle.hash_g2(rm[j])
+        for i_ in range(Nr):
+            good = rnd.random() < 0.93
+            rsig[j, i_] = u8(c_oracle.g2_mul(fr((rsk[i_] + (0 if good else 1)) % o.R), hj)[1])
+            rexp[j, i_] = 1 if good else 0
+    rok, nfb = e.verify_shares_rlc(rpk, rsig, rflat, roff, seed=rbytes(32))
+    if (rok != rexp).any() or nfb != int((rexp.min(axis=1) == 0).sum()):
+        fail("verify_shares_rlc", rounds, int(np.flatnonzero((rok != rexp).any(axis=1))[0]) if (rok != rexp).any() else -1, "nfb=%d" % nfb)
+    checked += Bg * (ng + 2 + Nr)
     # ---- compressed round trip ------------------------------------------------------------------------
     c2, stc = e.g2_compress(np.stack([u8(p) for p in pts2]))
     d2, std = e.g2_decompress(c2)

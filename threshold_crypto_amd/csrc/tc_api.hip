@@ -188,12 +188,23 @@ bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
 }
 
 // sum_i scalars[j][i] * points[j][i] in G2 for n >= kMsmMinPoints through the two-stage kernels (k_msm.hip);
-// d_st must hold B zeroed-or-flagged status bytes
+// d_st must hold B zeroed-or-flagged status bytes.  The per-share tables live in HBM (2 KB per share): batches
+// whose tables would exceed kMsmTableBudget run as consecutive tiles of jobs through ONE table buffer (the stream
+// orders a tile's ladder before the next tile's table stage).
+constexpr size_t kMsmTableBudget = (size_t)24 << 30;
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
             uint8_t* d_st, int nbits = 64) {
-  int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes(n, B) / sizeof(int32_t));
-  uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, B));
-  if (!k.failed) tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts, d_scalars, B, d_tbl, d_codes, d_out, d_st, nbits);
+  const size_t per_job = tc::msm_table_bytes(n, 1);
+  size_t tile = kMsmTableBudget / (per_job ? per_job : 1);
+  if (tile < 1) tile = 1;
+  if (tile > B) tile = B;
+  int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes(n, tile) / sizeof(int32_t));
+  uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, tile));
+  for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
+    const size_t cnt = (B - lo < tile) ? B - lo : tile;
+    tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 192,
+                      d_st + lo, nbits);
+  }
 }
 
 #define TC_REQUIRE(cond)            \
