@@ -249,3 +249,10 @@ void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_
 }
 
 }  // namespace tc
+
+#if defined(TC_PHASE_TIMING)
+// experiment builds only: the phase stamps of the last launch (tools/phase_marks_probe.py)
+extern "C" int tc_debug_phase_marks(unsigned long long* out, size_t words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_phase_marks), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

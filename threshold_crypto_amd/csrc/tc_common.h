@@ -159,4 +159,20 @@ TC_HD uint64_t wave_uniform(uint64_t v) {
 #define TC_NOUNROLL
 #endif
 
+// -DTC_PHASE_TIMING (experiment builds only, tools/phase_marks_probe.py): lane 0 of every workgroup stamps the shader
+// clock at phase boundaries of the combine job into a per-translation-unit device array
+#if defined(TC_PHASE_TIMING) && defined(__HIPCC__)
+static __device__ unsigned long long tc_phase_marks[4096 * 16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TC_MARK(k)                                                                                        \
+  do {                                                                                                    \
+    if (threadIdx.x == 0) tc_phase_marks[(blockIdx.x & 4095u) * 16 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define TC_MARK(k) ((void)0)
+#endif
+#else
+#define TC_MARK(k) ((void)0)
+#endif
+
 #include "tc_constants.h"

@@ -434,6 +434,19 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
     } else {
       TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)a[i] * b[k - i];
     }
+#if defined(TC_SINGLE_CHAIN)
+    if (k < N) {
+      TC_UNROLL for (int i = 0; i < k; i++) s1 += (int64_t)m[i] * FQL_P[k - i];
+      m[k] = (int32_t)(((uint32_t)s1 * FQL_INV) & (uint32_t)FQ_MASK);
+      s1 += (int64_t)m[k] * FQL_P[0];
+      carry = s1 >> FQ_RADIX;
+    } else {
+      TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)m[i] * FQL_P[k - i];
+      out[k - N] = (int32_t)((uint32_t)s1 & (uint32_t)FQ_MASK);
+      carry = s1 >> FQ_RADIX;
+    }
+    (void)s2;
+#else
     if (k < N) {
       TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
       int64_t s = s1 + s2;
@@ -446,6 +459,7 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
+#endif
   }
   out[N - 1] = (int32_t)carry;
 }
@@ -465,6 +479,23 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
     const int hi = (k < N) ? k : (N - 1);
     // the two products share one accumulator chain, the reduction runs in a second one
     // (three chains or a single one measure the same on MI355X: the multiplier pipe is the limit)
+#if defined(TC_SINGLE_CHAIN)  // experiment: products and reduction in ONE accumulator chain (no 64-bit add per column)
+    int64_t s = carry;
+    TC_UNROLL for (int i = lo; i <= hi; i++) {
+      s += (int64_t)x[i] * y[k - i];
+      s += (int64_t)z[i] * w[k - i];
+    }
+    if (k < N) {
+      TC_UNROLL for (int i = 0; i < k; i++) s += (int64_t)m[i] * FQL_P[k - i];
+      m[k] = (int32_t)(((uint32_t)s * FQL_INV) & (uint32_t)FQ_MASK);
+      s += (int64_t)m[k] * FQL_P[0];
+      carry = s >> FQ_RADIX;
+    } else {
+      TC_UNROLL for (int i = lo; i <= hi; i++) s += (int64_t)m[i] * FQL_P[k - i];
+      out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
+      carry = s >> FQ_RADIX;
+    }
+#else
     int64_t s1 = carry;
     int64_t s2 = 0;
     TC_UNROLL for (int i = lo; i <= hi; i++) {
@@ -483,6 +514,7 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
+#endif
   }
   out[N - 1] = (int32_t)carry;
 }

@@ -137,6 +137,7 @@ TC_HD_NOINLINE G2Jac g2_sac_ladder_call(const G2SacTable& t, const uint64_t* d) 
 TC_HD_NOINLINE G2Jac g2_joint_mul4(const G2Affine* base, const uint64_t* d) {
   G2SacTable t;
   g2_sac_table(base, t);
+  TC_MARK(3);
   return g2_sac_ladder(t, d);
 }
 

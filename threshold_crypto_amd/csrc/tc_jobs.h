@@ -277,6 +277,7 @@ TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t*
     c_abs[k] = 0;
     c_neg[k] = false;
   }
+  TC_MARK(0);
   const bool applies = live && lagrange_small_coeffs<K>(idx, c_abs, c_neg, &d_abs, &d_neg);
   Affine<F> pts[K];
   bool ok = true;
@@ -288,17 +289,24 @@ TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t*
     }
   }
   uint8_t* dst = io.result();
+  TC_MARK(1);
   if (applies) {
     if (!ok) {
       PointIO<F>::encode(Affine<F>::infinity(), dst);
       *status = TC_JOB_INVALID_ENCODING;
     } else {
       Jac<F> a = straus_small<F, K>(pts, c_abs);
-      PointIO<F>::encode(jac_to_affine(combine_divide(a, d_abs, d_neg)), dst);
+      TC_MARK(2);
+      const Jac<F> q = combine_divide(a, d_abs, d_neg);
+      TC_MARK(4);
+      const Affine<F> qa = jac_to_affine(q);
+      TC_MARK(5);
+      PointIO<F>::encode(qa, dst);
       *status = TC_JOB_OK;
     }
   }
   io.commit(applies);
+  TC_MARK(6);
   return applies;
 }
 template <class F, int K>
