@@ -149,6 +149,20 @@ TC_HD uint64_t wave_uniform(uint64_t v) {
   return v;
 #endif
 }
+// Time-sliced issue priority.  A SIMD arbitrates its resident waves oldest-first: of the two waves these
+// kernels keep per SIMD the older one runs at the speed of a lone wave and the younger one gets the leftover
+// issue slots (about half speed: profiles/r02_phase_timing.txt), so the older wave of every SIMD finishes early
+// and the kernel's last third runs ONE wave per SIMD.  Alternating s_setprio between the two waves in slices of
+// 2^17 shader cycles -- (clock slice + hardware wave slot) parity -- makes them advance together, and both
+// finish at 4/3 of a lone wave's time instead of 1 and 3/2.  Called once per iteration of the long loops.
+TC_HD void tc_fair() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TC_NO_FAIR)
+  const uint32_t slice = (uint32_t)(__builtin_readcyclecounter() >> 17);
+  const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID, WAVE_ID = bits [3:0]
+  if ((slice + slot) & 1u) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 }  // namespace tc
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -168,11 +182,18 @@ static __device__ unsigned long long tc_phase_marks[4096 * 16];
   do {                                                                                                    \
     if (threadIdx.x == 0) tc_phase_marks[(blockIdx.x & 4095u) * 16 + (k)] = __builtin_readcyclecounter(); \
   } while (0)
+// wall clock (s_memrealtime, 100 MHz, the same counter on every XCD): slots 8.. hold absolute start / end times
+#define TC_MARK_WALL(k)                                                                       \
+  do {                                                                                        \
+    if (threadIdx.x == 0) tc_phase_marks[(blockIdx.x & 4095u) * 16 + (k)] = wall_clock64();  \
+  } while (0)
 #else
 #define TC_MARK(k) ((void)0)
+#define TC_MARK_WALL(k) ((void)0)
 #endif
 #else
 #define TC_MARK(k) ((void)0)
+#define TC_MARK_WALL(k) ((void)0)
 #endif
 
 #include "tc_constants.h"

@@ -171,6 +171,7 @@ TC_HD F field_pow_fixed(const F& a, EXP e, int nbits) {
   int top = ((nbits + 3) / 4) * 4 - 4;
   F r = tbl[(e(top >> 5) >> (top & 31)) & 15];
   TC_NOUNROLL for (int pos = top - 4; pos >= 0; pos -= 4) {
+    tc_fair();
     r = r.sqr();
     r = r.sqr();
     r = r.sqr();
@@ -434,19 +435,6 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
     } else {
       TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)a[i] * b[k - i];
     }
-#if defined(TC_SINGLE_CHAIN)
-    if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s1 += (int64_t)m[i] * FQL_P[k - i];
-      m[k] = (int32_t)(((uint32_t)s1 * FQL_INV) & (uint32_t)FQ_MASK);
-      s1 += (int64_t)m[k] * FQL_P[0];
-      carry = s1 >> FQ_RADIX;
-    } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)m[i] * FQL_P[k - i];
-      out[k - N] = (int32_t)((uint32_t)s1 & (uint32_t)FQ_MASK);
-      carry = s1 >> FQ_RADIX;
-    }
-    (void)s2;
-#else
     if (k < N) {
       TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
       int64_t s = s1 + s2;
@@ -459,7 +447,6 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
-#endif
   }
   out[N - 1] = (int32_t)carry;
 }
@@ -477,25 +464,11 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
   TC_UNROLL for (int k = 0; k < 2 * N - 1; k++) {
     const int lo = (k < N) ? 0 : (k - N + 1);
     const int hi = (k < N) ? k : (N - 1);
-    // the two products share one accumulator chain, the reduction runs in a second one
-    // (three chains or a single one measure the same on MI355X: the multiplier pipe is the limit)
-#if defined(TC_SINGLE_CHAIN)  // experiment: products and reduction in ONE accumulator chain (no 64-bit add per column)
-    int64_t s = carry;
-    TC_UNROLL for (int i = lo; i <= hi; i++) {
-      s += (int64_t)x[i] * y[k - i];
-      s += (int64_t)z[i] * w[k - i];
-    }
-    if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s += (int64_t)m[i] * FQL_P[k - i];
-      m[k] = (int32_t)(((uint32_t)s * FQL_INV) & (uint32_t)FQ_MASK);
-      s += (int64_t)m[k] * FQL_P[0];
-      carry = s >> FQ_RADIX;
-    } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s += (int64_t)m[i] * FQL_P[k - i];
-      out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
-      carry = s >> FQ_RADIX;
-    }
-#else
+    // the two products share one accumulator, the reduction runs in a second one -- in the SOURCE.  hipcc re-associates the
+    // column into one long dependent v_mad chain (plus a short carry chain joined by one v_lshl_add_u64); that is fine:
+    // chained v_mad_i64_i32 with stable multiplicands issue back-to-back (tools/ubench_chain: 1 chain = 4 chains), a
+    // lone wave gets every other multiplier slot and two waves per SIMD fill it (37.5 T/s).  Forcing a single chain
+    // from the carry (empty-asm barriers; saves the 26 adds) measured equal or 2-3 % slower (hazard padding): not built.
     int64_t s1 = carry;
     int64_t s2 = 0;
     TC_UNROLL for (int i = lo; i <= hi; i++) {
@@ -514,7 +487,6 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
-#endif
   }
   out[N - 1] = (int32_t)carry;
 }
@@ -708,6 +680,7 @@ TC_HD void fq_inv_words(const uint32_t* y, uint32_t* out) {
     v[i] = 0;
   }
   TC_NOUNROLL for (int round = 0; round < 26; round++) {
+    if ((round & 7) == 0) tc_fair();
     // ---- approximations ----------------------------------------------------------------------
     uint32_t hw = 0;
     int top = 0;

@@ -116,6 +116,7 @@ TC_HD G2Jac g2_sac_ladder(const G2SacTable& t, const uint64_t* d) {
   const SacDigits sd = sac_recode4(d);
   G2Jac acc = G2Jac::from_affine(t.tbl[sd.top]);
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((sd.u[0] >> bit) & 1) | ((uint32_t)((sd.u[1] >> bit) & 1) << 1) |
                        ((uint32_t)((sd.u[2] >> bit) & 1) << 2);
@@ -204,6 +205,7 @@ TC_HD_NOINLINE G2Jac g2_mul_by_x_abs(const G2Jac& p) {
   const G2Affine pa{p.x, p.y, p.is_inf()};
   G2Jac acc = G2Jac::from_affine(pa);
   TC_NOUNROLL for (int bit = 62; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     if ((BLS_X_ABS >> bit) & 1ull) acc = jac_add_mixed(acc, pa);
   }
@@ -243,6 +245,7 @@ TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa, bool fix = true) {
   const G2Affine sa{s.x, s.y, s.is_inf()};
   G2Jac acc = G2Jac::from_affine(sa);
   TC_NOUNROLL for (int bit = 61; bit >= 0; bit--) {  // bit 62 is the leading one
+    tc_fair();
     acc = jac_dbl(acc);
     if ((G2_COFACTOR_FIX_SHORT >> bit) & 1ull) acc = jac_add_mixed(acc, sa);
   }
@@ -299,6 +302,7 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   tbl[2] = affine_scale_z(tbl[2], zc2, zc3);
   G1Jac acc = G1Jac::infinity();
   TC_NOUNROLL for (int bit = 127; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
     if (m) acc = jac_add_mixed(acc, tbl[m]);
@@ -320,6 +324,7 @@ TC_HD_NOINLINE G1Jac g1_mul_by_x_abs(const G1Jac& p) {
   const G1Affine pa{p.x, p.y, p.is_inf()};
   G1Jac acc = G1Jac::from_affine(pa);
   TC_NOUNROLL for (int bit = 62; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     if ((BLS_X_ABS >> bit) & 1ull) acc = jac_add_mixed(acc, pa);
   }

@@ -245,6 +245,7 @@ TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
     const G2Affine ba{base.x, base.y, base.is_inf()};  // affine on the curve scaled by base.z (tc_gls.h)
     G2Jac acc = G2Jac::from_affine(ba);
     TC_NOUNROLL for (int bit = 46; bit >= 0; bit--) {  // bit 47 is the leading one
+      tc_fair();
       acc = jac_dbl(acc);
       if ((s >> bit) & 1ull) acc = jac_add_mixed(acc, ba);
     }
@@ -278,6 +279,7 @@ TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t*
     c_neg[k] = false;
   }
   TC_MARK(0);
+  TC_MARK_WALL(8);
   const bool applies = live && lagrange_small_coeffs<K>(idx, c_abs, c_neg, &d_abs, &d_neg);
   Affine<F> pts[K];
   bool ok = true;
@@ -307,6 +309,7 @@ TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t*
   }
   io.commit(applies);
   TC_MARK(6);
+  TC_MARK_WALL(9);
   return applies;
 }
 template <class F, int K>

@@ -145,6 +145,7 @@ TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, i
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G2Jac acc = G2Jac::infinity();
   TC_NOUNROLL for (int col = nbits; col >= 0; col--) {
+    tc_fair();
     if (col != nbits) acc = jac_dbl(acc);
     const uint8_t* cc = codes + (size_t)col * shares4;
     TC_NOUNROLL for (size_t s = 0; s < shares4; s++) {

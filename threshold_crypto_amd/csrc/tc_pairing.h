@@ -111,6 +111,7 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
   const uint64_t xs = BLS_X_ABS >> 1;
   LineCoeffs l[NP];
   TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
+    tc_fair();
     TC_UNROLL for (int k = 0; k < NP; k++)
       if (!skip[k]) l[k] = miller_doubling_step(r[k]);
     miller_apply_lines<NP>(f, l, ps, skip, i == 61);
@@ -190,6 +191,7 @@ TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x_arg) {
     CycloCompressed c = CycloCompressed::from(f);
     int ns = 0;
     TC_NOUNROLL for (;; bit++) {
+      tc_fair();
       if ((x >> bit) & 1ull) {
         saved[ns++] = c;
         if (ns == 3) break;
@@ -202,6 +204,7 @@ TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x_arg) {
   Fq12 r = pw[0] * pw[1] * pw[2];
   Fq12 t = pw[2];
   TC_NOUNROLL for (bit++; bit < 64; bit++) {
+    tc_fair();
     t = t.cyclotomic_sqr();
     if ((x >> bit) & 1ull) r = r * t;
   }

@@ -159,6 +159,7 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
   }
   Jac<F> acc = Jac<F>::infinity();
   TC_NOUNROLL for (int bit = 254; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     uint32_t m = 0;
     TC_UNROLL for (int k = 0; k < K; k++) m |= ((sc[k][bit >> 5] >> (bit & 31)) & 1u) << k;
@@ -206,6 +207,7 @@ TC_HD G2Jac straus_chunk_gls4(const G2Affine* pts, const uint32_t (*sc)[8]) {
   G2Jac acc = G2Jac::infinity();
   TC_NOUNROLL for (int k = 0; k < 4; k++) acc = jac_add_mixed(acc, tbl[8 * k + sd[k].top]);  // column 64: all positive
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     TC_NOUNROLL for (int k = 0; k < 4; k++) {
       const uint32_t m = (uint32_t)((sd[k].u[0] >> bit) & 1) | ((uint32_t)((sd[k].u[1] >> bit) & 1) << 1) |
@@ -389,6 +391,7 @@ TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   if (bits > 64) bits = 64;  // lanes that left for the general path contribute undefined values
   Jac<F> acc = Jac<F>::infinity();
   TC_NOUNROLL for (int bit = (int)bits - 1; bit >= 0; bit--) {
+    tc_fair();
     acc = jac_dbl(acc);
     uint32_t m = 0;
     TC_UNROLL for (int k = 0; k < K; k++) m |= (uint32_t)((c[k] >> bit) & 1ull) << k;

@@ -32,4 +32,14 @@ for lo, hi, tag in ((0, 1300, "generic_class_waves"), (1400, 1700, "D=1_class_wa
         d = blk[:, b] - blk[:, a]
         ph[nm] = round(float(np.median(d)) / 1e6, 3)
     out[tag] = {"median_total_Mcycles": round(float(np.median(tot)) / 1e6, 3), "phases_Mcycles": ph}
+# timeline: wall-clock start / end of every workgroup (100 MHz ticks -> microseconds from the first start)
+st, en = m[:2054, 8] / 100.0, m[:2054, 9] / 100.0
+t0 = st.min()
+st, en = st - t0, en - t0
+def q(a):
+    return [round(float(x), 1) for x in np.percentile(a, [0, 10, 50, 90, 100])]
+out["timeline_us"] = {"kernel_span": round(float(en.max()), 1)}
+for lo, hi, tag in ((0, 1024, "blocks 0-1023 (generic, first slots)"), (1024, 1372, "blocks 1024-1371 (generic, second slots)"),
+                    (1372, 1702, "D=1 class"), (1702, 2054, "D=2^a class")):
+    out["timeline_us"][tag] = {"start p0/10/50/90/100": q(st[lo:hi]), "end p0/10/50/90/100": q(en[lo:hi]), "duration p0/10/50/90/100": q(en[lo:hi] - st[lo:hi])}
 print(json.dumps(out, indent=1))

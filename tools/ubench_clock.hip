@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint64_t* ticks, uint32_
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int kx = 0; kx < NACC; kx++) {
+      if (OP == 4) {  // v_mad_i64_i32 as the field multiplier issues it: STABLE multiplicands, chained 64-bit accumulator
+        uint64_t cc_;
+        asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(sacc[kx & 1]), "=s"(cc_) : "v"(sb + kx), "v"(sb - kx));
+      }
       if (OP == 0) acc[kx] = (uint64_t)(uint32_t)acc[(kx + 1) & (NACC - 1)] * b + acc[kx];        // v_mad_u64_u32
       if (OP == 1) sacc[kx] = (int64_t)(int32_t)sacc[(kx + 1) & (NACC - 1)] * sb + sacc[kx];        // v_mad_i64_i32
       if (OP == 2) acc[kx] = acc[kx] + (acc[(kx + 1) & (NACC - 1)] << 3);                          // v_lshl_add_u64
@@ -90,10 +94,15 @@ int main(int argc, char** argv) {
   uint64_t *d_out, *d_ticks;
   hipMalloc(&d_out, (size_t)cus * 8 * 256 * 8);
   hipMalloc(&d_ticks, (size_t)cus * 8 * 4 * 16);
-  // the roofline denominator: the multiplier's own instruction, every SIMD full (8 waves), ~25 ms per
-  // launch so that the clock is the one the chip SUSTAINS under this load
-  run<1>("v_mad_i64_i32", d_out, d_ticks, cus * 8, 8, 8192 * 20);
+  // the roofline denominator: the multiplier's own instruction in the multiplier's own pattern (stable
+  // multiplicands, two chained accumulators), every SIMD full (8 waves), ~20 ms per launch so that the clock is
+  // the one the chip SUSTAINS under this load.  (A multiplicand that is itself a fresh result -- the pattern of the
+  // "v_mad_i64_i32" / "v_mad_u64_u32" rows below and of round 1's peak -- issues ~25 % slower.)
+  run<4>("v_mad_i64_i32_chained", d_out, d_ticks, cus * 8, 8, 8192 * 20);
   if (peak_only) return 0;
+  run<4>("v_mad_i64_i32_chained", d_out, d_ticks, cus * 2, 2, 8192 * 4);
+  run<4>("v_mad_i64_i32_chained", d_out, d_ticks, cus * 1, 1, 8192 * 4);
+  run<1>("v_mad_i64_i32", d_out, d_ticks, cus * 8, 8, 8192 * 20);
   run<0>("v_mad_u64_u32", d_out, d_ticks, cus * 8, 8, 8192 * 20);
   for (int wps : {1, 2, 8}) {
     run<0>("v_mad_u64_u32", d_out, d_ticks, cus * wps, wps);
