@@ -407,10 +407,19 @@ struct Fq {
 };
 
 // ---- the multiplier ----------------------------------------------------------------------
-// Product-scanning Montgomery multiplication.  Column k gathers sum a_i b_{k-i} (chain 1, with
-// the carry from column k-1) and sum m_i p_{k-i} (chain 2): two independent v_mad_i64_i32
-// dependency chains, so a lone wave on a SIMD still overlaps multiplier latency.
+// Product-scanning Montgomery multiplication.  Column k gathers the carry from column k-1, sum a_i b_{k-i} and
+// sum m_i p_{k-i} in one v_mad chain (see TC_PIN).
 //   T = a*b + m*p,  T = 0 mod R,  result = T / R  in (-p/4, 5p/4)
+// TC_PIN(sum) gives a partial column sum a second (ephemeral) use, so LLVM's reassociation pass treats it as a leaf
+// and keeps the accumulation order written here -- carry first.  Left alone it sorts the carry (the deepest value) to
+// the END of the column: the products then start from zero and the carry costs one v_lshl_add_u64 per column.
+// The assumed fact is unconditionally true (squares are 0, 1 or 4 mod 8, also after wrap-around) and no code is
+// generated for it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TC_PIN(v) __builtin_assume((uint64_t)(v) * (uint64_t)(v) != 2u)
+#else
+#define TC_PIN(v)
+#endif
 template <bool SQUARE>
 TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
   constexpr int N = FQ_LIMBS;
@@ -424,26 +433,25 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
     const int lo = (k < N) ? 0 : (k - N + 1);
     const int hi = (k < N) ? k : (N - 1);
     int64_t s1 = carry;
-    int64_t s2 = 0;
     if (SQUARE) {
       // pairs i < j with i + j = k, doubled, plus the diagonal term
       TC_UNROLL for (int i = lo; i <= hi; i++) {
         const int j = k - i;
-        if (i < j) s1 += (int64_t)a[i] * a2[j];
-        if (i == j) s1 += (int64_t)a[i] * a[i];
+        if (i < j) { s1 += (int64_t)a[i] * a2[j]; TC_PIN(s1); }
+        if (i == j) { s1 += (int64_t)a[i] * a[i]; TC_PIN(s1); }
       }
     } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s1 += (int64_t)a[i] * b[k - i];
+      TC_UNROLL for (int i = lo; i <= hi; i++) { s1 += (int64_t)a[i] * b[k - i]; TC_PIN(s1); }
     }
     if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
-      int64_t s = s1 + s2;
+      TC_UNROLL for (int i = 0; i < k; i++) { s1 += (int64_t)m[i] * FQL_P[k - i]; TC_PIN(s1); }
+      int64_t s = s1;
       m[k] = (int32_t)(((uint32_t)s * FQL_INV) & (uint32_t)FQ_MASK);
       s += (int64_t)m[k] * FQL_P[0];
       carry = s >> FQ_RADIX;
     } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
-      int64_t s = s1 + s2;
+      TC_UNROLL for (int i = lo; i <= hi; i++) { s1 += (int64_t)m[i] * FQL_P[k - i]; TC_PIN(s1); }
+      int64_t s = s1;
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
@@ -454,7 +462,7 @@ TC_HD void fq_mul_body(const int32_t* a, const int32_t* b, int32_t* out) {
 // Two products, one reduction:  out = (x*y + z*w + m*p) / R.  This is what one lane of an
 // Fq2 lane pair computes for its own coefficient of a product (c0 = a0 b0 - a1 b1 or
 // c1 = a0 b1 + a1 b0): 588 multiply-adds instead of the 784 two separate Montgomery
-// multiplications would take, and three independent chains per column.
+// multiplications would take.
 // Column bound: 14 * 2^56 * (Bx By + Bz Bw + 1) < 2^63  <=>  Bx By + Bz Bw < 8.14.
 constexpr float FQ_MAX_BOUND_PRODUCT2 = 8.14f;
 TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, const int32_t* w, int32_t* out) {
@@ -464,26 +472,24 @@ TC_HD void fq_mul2_body(const int32_t* x, const int32_t* y, const int32_t* z, co
   TC_UNROLL for (int k = 0; k < 2 * N - 1; k++) {
     const int lo = (k < N) ? 0 : (k - N + 1);
     const int hi = (k < N) ? k : (N - 1);
-    // the two products share one accumulator, the reduction runs in a second one -- in the SOURCE.  hipcc re-associates the
-    // column into one long dependent v_mad chain (plus a short carry chain joined by one v_lshl_add_u64); that is fine:
-    // chained v_mad_i64_i32 with stable multiplicands issue back-to-back (tools/ubench_chain: 1 chain = 4 chains), a
-    // lone wave gets every other multiplier slot and two waves per SIMD fill it (37.5 T/s).  Forcing a single chain
-    // from the carry (empty-asm barriers; saves the 26 adds) measured equal or 2-3 % slower (hazard padding): not built.
+    // ONE accumulator chain per column, started from the previous column's carry: every term becomes a
+    // v_mad_i64_i32 / v_mad_u64_u32 whose addend is the running sum, and no separate 64-bit add is left (TC_PIN above;
+    // saves 26 v_lshl_add_u64 per multiplication).  Chained multiply-adds issue back to back
+    // (tools/ubench_chain: 1 chain = 4 chains), two waves per SIMD fill the multiplier.
     int64_t s1 = carry;
-    int64_t s2 = 0;
     TC_UNROLL for (int i = lo; i <= hi; i++) {
-      s1 += (int64_t)x[i] * y[k - i];
-      s1 += (int64_t)z[i] * w[k - i];
+      s1 += (int64_t)x[i] * y[k - i]; TC_PIN(s1);
+      s1 += (int64_t)z[i] * w[k - i]; TC_PIN(s1);
     }
     if (k < N) {
-      TC_UNROLL for (int i = 0; i < k; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
-      int64_t s = s1 + s2;
+      TC_UNROLL for (int i = 0; i < k; i++) { s1 += (int64_t)m[i] * FQL_P[k - i]; TC_PIN(s1); }
+      int64_t s = s1;
       m[k] = (int32_t)(((uint32_t)s * FQL_INV) & (uint32_t)FQ_MASK);
       s += (int64_t)m[k] * FQL_P[0];
       carry = s >> FQ_RADIX;
     } else {
-      TC_UNROLL for (int i = lo; i <= hi; i++) s2 += (int64_t)m[i] * FQL_P[k - i];
-      int64_t s = s1 + s2;
+      TC_UNROLL for (int i = lo; i <= hi; i++) { s1 += (int64_t)m[i] * FQL_P[k - i]; TC_PIN(s1); }
+      int64_t s = s1;
       out[k - N] = (int32_t)((uint32_t)s & (uint32_t)FQ_MASK);
       carry = s >> FQ_RADIX;
     }
@@ -518,19 +524,20 @@ __device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_
 // ---- Fq2 spread over a lane pair (tc_common.h) ---------------------------------------------
 // A product needs the partner's coefficients: they come over DPP inside the callee, so a call
 // still passes only its own 15 + 15 limbs (+ the lane parity) in VGPRs.
-//   even lane: c0 = a0 b0 - a1 b1 = mine*mine' + (-other)*other'
-//   odd  lane: c1 = a1 b0 + a0 b1 = mine*other' + other*mine'
+//   even lane: c0 = a0 b0 - a1 b1 = mine*b0 + (-other)*b1
+//   odd  lane: c1 = a1 b0 + a0 b1 = mine*b0 +   other *b1
+// with b0 / b1 broadcast to both lanes of the pair (two DPP moves per limb) and the partner's a negated on the even
+// lane by xor/subtract with a lane mask (the xor carries the DPP swap): 56 prologue instructions, no branch.
 __device__ __attribute__((noinline)) inline FqRaw fq2p_mul_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13, int32_t odd) {
   const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
   const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13};
   int32_t y[FQ_LIMBS], z[FQ_LIMBS], w[FQ_LIMBS];
-  const bool o = odd != 0;
+  const int32_t mneg = odd - 1;  // even lane: -1 (negate the partner's coefficient), odd lane: 0
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
     const int32_t ao = pair_swap(a[i]);
-    const int32_t bo = pair_swap(b[i]);
-    y[i] = o ? bo : b[i];
-    w[i] = o ? b[i] : bo;
-    z[i] = o ? ao : -ao;
+    y[i] = __builtin_amdgcn_mov_dpp(b[i], 0xA0, 0xF, 0xF, true);  // b0 on both lanes
+    w[i] = __builtin_amdgcn_mov_dpp(b[i], 0xF5, 0xF, 0xF, true);  // b1 on both lanes
+    z[i] = (ao ^ mneg) - mneg;
   }
   FqRaw r;
   fq_mul2_body(a, y, z, w, r.l);
@@ -540,11 +547,13 @@ __device__ __attribute__((noinline)) inline FqRaw fq2p_mul_call(int32_t a0, int3
 __device__ __attribute__((noinline)) inline FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t odd) {
   const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
   int32_t x[FQ_LIMBS], y[FQ_LIMBS];
-  const bool o = odd != 0;
+  int32_t even = odd - 1;  // even lane: all ones
+  asm("" : "+v"(even));   // opaque: keeps the AND (one v_and_b32_dpp) from becoming a compare and a select
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
-    const int32_t ao = pair_swap(a[i]);
-    x[i] = a[i] + (o ? a[i] : ao);
-    y[i] = o ? ao : a[i] - ao;
+    const int32_t a1 = __builtin_amdgcn_mov_dpp(a[i], 0xF5, 0xF, 0xF, true);  // the odd lane's coefficient, on both lanes
+    const int32_t a0 = __builtin_amdgcn_mov_dpp(a[i], 0xA0, 0xF, 0xF, true);  // the even lane's
+    x[i] = a[i] + a1;                         // a0 + a1 | 2 a1
+    y[i] = a0 - (pair_swap(a[i]) & even);     // a0 - a1 | a0
   }
   FqRaw r;
   fq_mul_body<false>(x, y, r.l);
