@@ -135,11 +135,13 @@ template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine_fast(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                     const uint8_t* __restrict__ shares, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status,
-                                                    const uint32_t* __restrict__ perm, size_t slots) {
+                                                    const uint32_t* __restrict__ perm, size_t slots, TableArena ta) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
   using IO = WaveRowIO<PB, L>;
   __shared__ __attribute__((aligned(16))) uint8_t lds[IO::BYTES];
+  uint32_t tslot = 0;
+  if (L > 1) tslot = table_slot_acquire(ta);  // the G2 ladders keep their tables in the arena (tc_table.h)
   const size_t slot = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
   size_t j = B;                                            // B = no job on this lane (past the end, or class padding)
   if (slot < slots) j = perm ? (size_t)perm[slot] : slot;  // grouped by denominator class, or the identity
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   uint8_t st = TC_JOB_OK;
   const bool done = combine_fast<F>(t, idx + jj * n_per_job, live, io, &st);
   if (done && status && (L == 1 || pair_leader())) status[j] = st;
+  if (L > 1) table_slot_release(ta, tslot);
 }
 
 template <class F>
@@ -156,19 +159,23 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
                                                     const uint8_t* __restrict__ shares,
                                                     const uint32_t* __restrict__ lam, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status,
-                                                    const uint32_t* __restrict__ need_general) {
+                                                    const uint32_t* __restrict__ need_general, TableArena ta) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
   if (need_general && *need_general == 0) return;  // every job went through the fast path
+  uint32_t tslot = 0;
+  if (L > 1) tslot = table_slot_acquire(ta);
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
-  if (j >= B) return;
-  if (t >= 1 && t <= 3 && combine_small_applies(idx + j * n_per_job, (int)t)) return;  // done by k_combine_fast
-  if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
-    PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
-    return;
+  const bool mine = j < B && !(t >= 1 && t <= 3 && combine_small_applies(idx + j * n_per_job, (int)t));  // else: k_combine_fast's
+  if (mine) {
+    if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
+      PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
+    } else {
+      const uint8_t st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
+      if (status && (L == 1 || pair_leader())) status[j] = st;
+    }
   }
-  const uint8_t st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
-  if (status && (L == 1 || pair_leader())) status[j] = st;
+  if (L > 1) table_slot_release(ta, tslot);
 }
 
 // one lane per job: sum_i scalar_i * point_i with caller-supplied scalars (32 B LE each); the points of job
@@ -176,23 +183,27 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
 template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points, size_t pts_stride, size_t B,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
+  uint32_t tslot = 0;
+  if (L > 1) tslot = table_slot_acquire(ta);
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
-  if (j >= B) return;
-  uint8_t st = job_lincomb<F>((int)n, points + j * pts_stride, reinterpret_cast<const uint32_t*>(scalars + j * n * 32),
-                              out + j * PB);
-  if (status && (L == 1 || pair_leader())) status[j] = st;
+  if (j < B) {
+    uint8_t st = job_lincomb<F>((int)n, points + j * pts_stride, reinterpret_cast<const uint32_t*>(scalars + j * n * 32),
+                                out + j * PB);
+    if (status && (L == 1 || pair_leader())) status[j] = st;
+  }
+  if (L > 1) table_slot_release(ta, tslot);
 }
 
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status, bool shared_points) {
-  if (B) hipLaunchKernelGGL(k_lincomb<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 96, B, out, status);
+  if (B) hipLaunchKernelGGL(k_lincomb<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 96, B, out, status, TableArena{nullptr, nullptr});
 }
-void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+void launch_lincomb_g2(hipStream_t st, TableArena ta, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status, bool shared_points) {
-  if (B) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 192, B, out, status);
+  if (B && ta.mem && ta.flags) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 192, B, out, status, ta);
 }
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
@@ -223,16 +234,16 @@ void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general) {
   if (!B) return;
   if (t >= 1 && t <= 3)
-    hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B);
-  hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general);
+    hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});
+  hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, TableArena{nullptr, nullptr});
 }
 size_t combine_group_slots(size_t B) { return B + (size_t)kCombineClasses * kCombinePad; }
 // cls: B bytes, counters: 8 words, perm: combine_group_slots(B) words (scratch of the caller); pass
 // perm = nullptr to run the jobs in their own order
-void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
                        uint32_t* perm, const uint32_t* need_general) {
-  if (!B) return;
+  if (!B || !ta.mem || !ta.flags) return;
   if (t >= 1 && t <= 3) {
     size_t slots = B;
     if (perm) {
@@ -243,9 +254,9 @@ void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_
       hipLaunchKernelGGL(k_combine_offsets, dim3(1), dim3(64), 0, st, counters);
       hipLaunchKernelGGL(k_combine_scatter, dim3(grid_for(B)), dim3(kBlock), 0, st, cls, B, counters, perm);
     }
-    hipLaunchKernelGGL(k_combine_fast<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots);
+    hipLaunchKernelGGL(k_combine_fast<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots, ta);
   }
-  hipLaunchKernelGGL(k_combine_general<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general);
+  hipLaunchKernelGGL(k_combine_general<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, ta);
 }
 
 }  // namespace tc

@@ -35,12 +35,15 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_encrypt(const uint8_t* 
                                                     const uint8_t* __restrict__ r, const uint8_t* __restrict__ msgs,
                                                     const uint64_t* __restrict__ off, size_t B,
                                                     uint8_t* __restrict__ out_u, uint8_t* __restrict__ out_v,
-                                                    uint8_t* __restrict__ out_w, uint8_t* __restrict__ status) {
+                                                    uint8_t* __restrict__ out_w, uint8_t* __restrict__ status, TableArena ta) {
+  const uint32_t tslot = table_slot_acquire(ta);  // W = r H(U, V): a GLS ladder with its table in the arena
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
-  if (j >= B) return;
-  uint8_t st = job_encrypt(pk + j * pk_stride, r + j * 32, msgs + off[j], (size_t)(off[j + 1] - off[j]), out_u + j * 96,
-                           out_v + off[j], out_w + j * 192);
-  if (status && pair_leader()) status[j] = st;
+  if (j < B) {
+    uint8_t st = job_encrypt(pk + j * pk_stride, r + j * 32, msgs + off[j], (size_t)(off[j + 1] - off[j]), out_u + j * 96,
+                             out_v + off[j], out_w + j * 192);
+    if (status && pair_leader()) status[j] = st;
+  }
+  table_slot_release(ta, tslot);
 }
 
 __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_commitment_evaluate(const uint8_t* __restrict__ commit, size_t t,
@@ -52,9 +55,9 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_commitment_evaluate(con
   if (status) status[j] = st;
 }
 
-void launch_encrypt(hipStream_t st, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
+void launch_encrypt(hipStream_t st, TableArena ta, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_encrypt, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, pk, pk_stride, r, msgs, off, B, out_u, out_v, out_w, status);
+  if (B && ta.mem && ta.flags) hipLaunchKernelGGL(k_encrypt, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, pk, pk_stride, r, msgs, off, B, out_u, out_v, out_w, status, ta);
 }
 void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                                 uint8_t* status) {

@@ -9,44 +9,54 @@ namespace tc {
 template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_point_mul(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts,
                                                       size_t S, size_t B, uint8_t* __restrict__ out,
-                                                      uint8_t* __restrict__ status) {
+                                                      uint8_t* __restrict__ status, TableArena ta) {
   constexpr int PB = PointIO<F>::BYTES;
   constexpr int L = JobLanes<F>::N;
+  uint32_t tslot = 0;
+  if (L > 1) tslot = table_slot_acquire(ta);  // the GLS ladder's table lives in the arena (tc_table.h)
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
-  if (tid >= S * B) return;
-  const size_t s = tid / B, j = tid % B;
-  const size_t o = j * S + s;
-  uint8_t st = job_point_mul<F>(fr + s * 32, pts + j * PB, out + o * PB);
-  if (status && (L == 1 || pair_leader())) status[o] = st;
+  if (tid < S * B) {
+    const size_t s = tid / B, j = tid % B;
+    const size_t o = j * S + s;
+    uint8_t st = job_point_mul<F>(fr + s * 32, pts + j * PB, out + o * PB);
+    if (status && (L == 1 || pair_leader())) status[o] = st;
+  }
+  if (L > 1) table_slot_release(ta, tslot);
 }
 
 // S > 1 scalars over the same G2 points: a lane pair takes one point and a chunk of up to
 // kMulShare scalars (chunk-major lane order, so a wave shares its scalars).
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_shared(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts, size_t S,
-                                                                     size_t B, uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+                                                                     size_t B, uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
+  const uint32_t tslot = table_slot_acquire(ta);
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   const size_t chunks = (S + kMulShare - 1) / kMulShare;
-  if (tid >= chunks * B) return;
-  const size_t c = tid / B, j = tid % B;
-  const size_t s0 = c * kMulShare;
-  const int n = (int)((S - s0 < (size_t)kMulShare) ? S - s0 : (size_t)kMulShare);
-  const size_t o = j * S + s0;
-  job_g2_mul_shared(fr + s0 * 32, n, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
+  if (tid < chunks * B) {
+    const size_t c = tid / B, j = tid % B;
+    const size_t s0 = c * kMulShare;
+    const int n = (int)((S - s0 < (size_t)kMulShare) ? S - s0 : (size_t)kMulShare);
+    const size_t o = j * S + s0;
+    job_g2_mul_shared(fr + s0 * 32, n, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
+  }
+  table_slot_release(ta, tslot);
 }
 
 // shares of B messages by per-message signer subsets: a lane pair takes one hash point and up to kMulShare of the
 // n selected signers (chunk-major lane order as above); out[(j * n + k)] = sk[idx[j * n + k]] * pts[j]
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_gather(const uint8_t* __restrict__ sk, size_t N, const uint64_t* __restrict__ idx,
                                                                      const uint8_t* __restrict__ pts, size_t n, size_t B,
-                                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+                                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
+  const uint32_t tslot = table_slot_acquire(ta);
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   const size_t chunks = (n + kMulShare - 1) / kMulShare;
-  if (tid >= chunks * B) return;
-  const size_t c = tid / B, j = tid % B;
-  const size_t s0 = c * kMulShare;
-  const int cnt = (int)((n - s0 < (size_t)kMulShare) ? n - s0 : (size_t)kMulShare);
-  const size_t o = j * n + s0;
-  job_g2_mul_gather(sk, N, idx + o, cnt, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
+  if (tid < chunks * B) {
+    const size_t c = tid / B, j = tid % B;
+    const size_t s0 = c * kMulShare;
+    const int cnt = (int)((n - s0 < (size_t)kMulShare) ? n - s0 : (size_t)kMulShare);
+    const size_t o = j * n + s0;
+    job_g2_mul_gather(sk, N, idx + o, cnt, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
+  }
+  table_slot_release(ta, tslot);
 }
 
 template <class F>
@@ -89,23 +99,23 @@ __global__ void k_fill_g1_generator(uint8_t* out96, uint8_t* out96_unfix) {
 
 void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {
-  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, TableArena{nullptr, nullptr});
 }
-void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {
-  if (!(S * B)) return;
+  if (!(S * B) || !ta.mem || !ta.flags) return;
   if (S > 1) {
     const size_t chunks = (S + kMulShare - 1) / kMulShare;
-    hipLaunchKernelGGL(k_g2_mul_shared, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+    hipLaunchKernelGGL(k_g2_mul_shared, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, ta);
   } else {
-    hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status);
+    hipLaunchKernelGGL(k_point_mul<Fq2>, dim3(grid_for(S * B * kG2Lanes)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, ta);
   }
 }
-void launch_g2_mul_gather(hipStream_t st, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
+void launch_g2_mul_gather(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
                           uint8_t* out, uint8_t* status) {
-  if (!(n * B)) return;
+  if (!(n * B) || !ta.mem || !ta.flags) return;
   const size_t chunks = (n + kMulShare - 1) / kMulShare;
-  hipLaunchKernelGGL(k_g2_mul_gather, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, sk, N, idx, pts, n, B, out, status);
+  hipLaunchKernelGGL(k_g2_mul_gather, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, sk, N, idx, pts, n, B, out, status, ta);
 }
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_compress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);

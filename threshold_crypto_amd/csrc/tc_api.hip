@@ -36,6 +36,9 @@ struct tc_ctx {
   // e(pk, Q') == e([1/c] g1, sig)
   uint8_t* g1_gen_unfix = nullptr;
   int32_t* fb_table = nullptr;  // signed 4-bit window table of the G1 generator (tc_dkg.h), built on first use
+  // per-job ladder tables of the G2 kernels (tc_table.h): 256 MB + one flag word per wave slot, allocated on first use
+  int32_t* tbl_mem = nullptr;
+  uint32_t* tbl_flags = nullptr;
   int cus = 0;
 };
 
@@ -73,6 +76,15 @@ struct Call {
       return false;
     }
     return true;
+  }
+  // the table arena of the G2 ladder kernels (tc_table.h)
+  tc::TableArena tables() {
+    if (!c->tbl_mem && !failed) {
+      if (check(hipMalloc((void**)&c->tbl_mem, tc::kTableArenaWords * sizeof(int32_t)), "hipMalloc") &&
+          check(hipMalloc((void**)&c->tbl_flags, tc::kTableArenaFlags * sizeof(uint32_t)), "hipMalloc"))
+        check(hipMemsetAsync(c->tbl_flags, 0, tc::kTableArenaFlags * sizeof(uint32_t), c->stream), "memset");
+    }
+    return tc::TableArena{c->tbl_mem, c->tbl_flags};
   }
   void* scratch(size_t n) {
     if (n == 0) n = 8;
@@ -259,6 +271,8 @@ void tc_ctx_destroy(tc_ctx* c) {
   if (c->g1_gen) (void)hipFree(c->g1_gen);
   if (c->g1_gen_unfix) (void)hipFree(c->g1_gen_unfix);
   if (c->fb_table) (void)hipFree(c->fb_table);
+  if (c->tbl_mem) (void)hipFree(c->tbl_mem);
+  if (c->tbl_flags) (void)hipFree(c->tbl_flags);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -354,7 +368,7 @@ static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts
   k.begin_timing();
   k.check_points(g2, d_pts, PB, 1, 1, B, S);
   if (!k.failed) {
-    if (g2) tc::launch_g2_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
+    if (g2) tc::launch_g2_mul(ctx->stream, k.tables(), d_fr, d_pts, S, B, d_out, d_st);
     else tc::launch_g1_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
   }
   k.apply_checks(S * B, d_st, d_out, PB, nullptr);
@@ -385,7 +399,7 @@ int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, cons
   uint8_t* d_st = k.out(status, B * n);
   k.begin_timing();
   k.check_points(true, d_h, 192, 1, 1, B, n);
-  if (!k.failed) tc::launch_g2_mul_gather(ctx->stream, d_sk, N, d_idx, d_h, n, B, d_out, d_st);
+  if (!k.failed) tc::launch_g2_mul_gather(ctx->stream, k.tables(), d_sk, N, d_idx, d_h, n, B, d_out, d_st);
   k.apply_checks(B * n, d_st, d_out, 192, nullptr);
   k.end_timing();
   return k.finish();
@@ -413,7 +427,7 @@ int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uin
     // sk * hash_g2(m) = (sk c) * Q': the hash skips its last constant multiplication, the scalars carry it
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     tc::launch_fr_scale_cofactor_fix(ctx->stream, d_fr, S, d_frc);
-    tc::launch_g2_mul(ctx->stream, d_frc, d_hash, S, B, d_out, d_st);
+    tc::launch_g2_mul(ctx->stream, k.tables(), d_frc, d_hash, S, B, d_out, d_st);
   }
   k.end_timing();
   return k.finish();
@@ -477,7 +491,7 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
       tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
     }
     if (g2 && t + 1 >= tc::kMsmMinPoints) msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds
-    else if (g2) tc::launch_combine_g2(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+    else if (g2) tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
     else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st,
                                t + 1 >= tc::kMsmMinPoints ? nullptr : d_need);  // (k_lagrange_all does not count: every job is general)
     k.apply_checks(B, d_st, d_pt, PB, nullptr);
@@ -528,7 +542,7 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
       uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
       if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
       msm_g2(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
-    } else if (g2) tc::launch_lincomb_g2(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
+    } else if (g2) tc::launch_lincomb_g2(ctx->stream, k.tables(), n, d_sc, d_pt, B, d_out, d_st);
     else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
   }
   k.apply_checks(B, d_st, d_out, PB, nullptr);
@@ -691,7 +705,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
       k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
       msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16);  // short scalars
     } else {
-      tc::launch_lincomb_g2(ctx->stream, N, d_r, d_sig, B, d_S, d_stS);
+      tc::launch_lincomb_g2(ctx->stream, k.tables(), N, d_r, d_sig, B, d_S, d_stS);
     }
     tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
@@ -946,7 +960,7 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uin
   uint8_t* d_st = k.out(status, B);
   k.begin_timing();
   k.check_points(false, d_pk, pk_stride, 1, 1, B, 1);
-  if (!k.failed) tc::launch_encrypt(ctx->stream, d_pk, pk_stride, d_r, d_msgs, d_off, B, d_u, d_v, d_w, d_st);
+  if (!k.failed) tc::launch_encrypt(ctx->stream, k.tables(), d_pk, pk_stride, d_r, d_msgs, d_off, B, d_u, d_v, d_w, d_st);
   if (!k.checks.empty()) {
     // an invalid key fails the job: status + identity u and w (v keeps the kernel's bytes and must be ignored)
     auto pending = k.checks;

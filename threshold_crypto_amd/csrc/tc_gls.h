@@ -15,7 +15,7 @@
 //   c = (3(x^2-1))^-1 mod r: the reference's 507-bit scale_by_cofactor becomes two 64-bit
 //   ladders and one GLS multiplication.
 #pragma once
-#include "tc_curve.h"
+#include "tc_table.h"
 
 namespace tc {
 
@@ -93,10 +93,13 @@ TC_HD SacDigits sac_recode4(const uint64_t* d, int nbits = 64) {
 // 8-entry table B0 + (subset sums of B1, B2, B3) with sign-aligned digits (above).  The 7 proper
 // sums are brought to one common Z (no inversion: jac_batch_to_common_z) and B0 scaled to it, so
 // every addition of the 64-step ladder is a mixed one on the isomorphic curve (7M + 4S instead of
-// 11M + 5S in Fq2), and a table entry is two coordinates.
+// 11M + 5S in Fq2), and a table entry is two coordinates.  The table itself lives in HBM (tc_table.h): the
+// kernel must hold a table slot (table_slot_acquire) while any of this runs.
 struct G2SacTable {
-  G2Affine tbl[8];  // B0 + (subset sums of B1, B2, B3), affine on the curve scaled by zc
+  tbl_word* mem;  // this lane pair's 8 entries in the table arena (tc_table.h): B0 + (subset sums of B1, B2, B3),
+                  // affine on the curve scaled by zc
   Fq2 zc;
+  TC_HD G2Affine entry(uint32_t m) const { return tbl_load_g2(mem + m * kTblEntryWords); }
 };
 TC_HD void g2_sac_table(const G2Affine* base, G2SacTable& t) {
   G2Jac sums[7];
@@ -109,23 +112,24 @@ TC_HD void g2_sac_table(const G2Affine* base, G2SacTable& t) {
   t.zc = jac_batch_to_common_z(sums, sums_aff, 7);
   const Fq2 zc2 = t.zc.sqr();
   const Fq2 zc3 = zc2 * t.zc;
-  t.tbl[0] = affine_scale_z(base[0], zc2, zc3);
-  TC_NOUNROLL for (int m = 1; m < 8; m++) t.tbl[m] = sums_aff[m - 1];
+  t.mem = pair_table();
+  tbl_store_g2(t.mem, affine_scale_z(base[0], zc2, zc3));
+  TC_NOUNROLL for (int m = 1; m < 8; m++) tbl_store_g2(t.mem + m * kTblEntryWords, sums_aff[m - 1]);
 }
 TC_HD G2Jac g2_sac_ladder(const G2SacTable& t, const uint64_t* d) {
   const SacDigits sd = sac_recode4(d);
-  G2Jac acc = G2Jac::from_affine(t.tbl[sd.top]);
+  G2Jac acc = G2Jac::from_affine(t.entry(sd.top));
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
     tc_fair();
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((sd.u[0] >> bit) & 1) | ((uint32_t)((sd.u[1] >> bit) & 1) << 1) |
                        ((uint32_t)((sd.u[2] >> bit) & 1) << 2);
-    G2Affine e = t.tbl[m];
+    G2Affine e = t.entry(m);
     e.y = Fq2::select((sd.neg >> bit) & 1, -e.y, e.y);
     acc = jac_add_mixed(acc, e);
   }
   if (wave_any(sd.fix)) {
-    G2Affine e = t.tbl[0];
+    G2Affine e = t.entry(0);
     e.y = -e.y;
     acc = G2Jac::select(sd.fix, jac_add_mixed(acc, e), acc);
   }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "tc_arena.h"
 
 namespace tc {
 
@@ -22,10 +23,10 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 
 void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status);
-void launch_g2_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status);
 // out[j*n + k] = sk[idx[j*n + k]] * pts[j]: the shares of message j by its n selected signers out of N
-void launch_g2_mul_gather(hipStream_t st, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
+void launch_g2_mul_gather(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
                           uint8_t* out, uint8_t* status);
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
@@ -43,13 +44,13 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general);
 size_t combine_group_slots(size_t B);
-void launch_combine_g2(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
+void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
                        uint32_t* perm, const uint32_t* need_general);
 // shared_points: every job combines the SAME n points (points holds n of them) with its own n scalars
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status, bool shared_points = false);
-void launch_lincomb_g2(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
+void launch_lincomb_g2(hipStream_t st, TableArena ta, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status, bool shared_points = false);
 // random-linear-combination share validation (k_check.hip): 64-bit scalars from a ChaCha20 stream keyed
 // by the caller's seed; row gather / byte scatter for the per-share fallback of failed messages
@@ -89,7 +90,7 @@ void launch_fr_scale_cofactor_fix(hipStream_t st, const uint8_t* fr, size_t S, u
 void launch_g1_scale_cofactor_fix(hipStream_t st, const uint8_t* in, size_t stride, size_t n, uint8_t* out);
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                           uint8_t* out, uint8_t* status);
-void launch_encrypt(hipStream_t st, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
+void launch_encrypt(hipStream_t st, TableArena ta, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status);
 void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
                                 uint8_t* status);

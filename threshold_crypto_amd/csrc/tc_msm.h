@@ -17,62 +17,15 @@
 namespace tc {
 
 constexpr int kMsmChunk = 4;          // shares per stage-T lane pair
-constexpr int kMsmEntryWords = 64;    // one table entry: x (2 x 16 words), y (2 x 16 words); word 15 of x[0] = flags
-constexpr int kMsmCoordWords = 16;    // 14 limbs + 2 words of padding: one 64-byte row per coordinate and lane
+constexpr int kMsmEntryWords = kTblEntryWords;  // one table entry (tc_table.h): 256 B
 constexpr int kMsmColumns = 65;       // digit columns 0 .. 64 (column 64: the leading +1 of the sign-aligned form);
                                       // short scalars (all four base-|x| digits below 2^nbits) use columns 0 .. nbits
 
 TC_HD size_t msm_chunks(size_t n) { return (n + kMsmChunk - 1) / kMsmChunk; }
 
-// this lane's half of an affine G2 point -> its two 64-byte rows of a table entry (hipcc: one coefficient per
-// lane of the pair; g++ test build: both coefficients)
-TC_HD void msm_store_entry(int32_t* e, const G2Affine& p) {
-#if TC_PAIR
-  const int o = pair_odd() * kMsmCoordWords;
-  const Fq x = p.x.m.norm(), y = p.y.m.norm();
-  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
-    e[o + i] = x.l[i];
-    e[2 * kMsmCoordWords + o + i] = y.l[i];
-  }
-  e[o + 14] = 0;
-  e[o + 15] = p.inf ? 1 : 0;
-  e[2 * kMsmCoordWords + o + 14] = 0;
-  e[2 * kMsmCoordWords + o + 15] = 0;
-#else
-  const Fq xs[2] = {p.x.c0.norm(), p.x.c1.norm()}, ys[2] = {p.y.c0.norm(), p.y.c1.norm()};
-  for (int h = 0; h < 2; h++) {
-    for (int i = 0; i < FQ_LIMBS; i++) {
-      e[h * kMsmCoordWords + i] = xs[h].l[i];
-      e[2 * kMsmCoordWords + h * kMsmCoordWords + i] = ys[h].l[i];
-    }
-    e[h * kMsmCoordWords + 14] = 0;
-    e[h * kMsmCoordWords + 15] = p.inf ? 1 : 0;
-    e[2 * kMsmCoordWords + h * kMsmCoordWords + 14] = 0;
-    e[2 * kMsmCoordWords + h * kMsmCoordWords + 15] = 0;
-  }
-#endif
-}
-TC_HD Fq msm_load_fq(const int32_t* w) {
-  Fq r;
-  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = w[i];
-  r.set_range(-0.001f, 1.001f);
-  r.set_val(2.1f);
-  return r;
-}
-TC_HD G2Affine msm_load_entry(const int32_t* e) {
-  G2Affine p;
-#if TC_PAIR
-  const int o = pair_odd() * kMsmCoordWords;
-  p.x = Fq2{msm_load_fq(e + o)};
-  p.y = Fq2{msm_load_fq(e + 2 * kMsmCoordWords + o)};
-  p.inf = e[o + 15] != 0;
-#else
-  p.x = Fq2::make(msm_load_fq(e), msm_load_fq(e + kMsmCoordWords));
-  p.y = Fq2::make(msm_load_fq(e + 2 * kMsmCoordWords), msm_load_fq(e + 3 * kMsmCoordWords));
-  p.inf = e[15] != 0;
-#endif
-  return p;
-}
+// table entries in the layout of tc_table.h (the single-point ladders of tc_gls.h keep theirs the same way)
+TC_HD void msm_store_entry(int32_t* e, const G2Affine& p) { tbl_store_g2((tbl_word*)e, p); }
+TC_HD G2Affine msm_load_entry(const int32_t* e) { return tbl_load_g2((const tbl_word*)e); }
 
 // Stage T for the chunk `c` of job data: points (n x 192 B), scalars (n x 8 canonical words).
 //   tbl    this job's tables: (4 * chunks) shares x 8 entries x 64 words
