@@ -16,7 +16,7 @@ for line in open(src):
     if len(f) == 5 and f[1] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_LDS",
                                 "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
         vals[(f[0].replace("void ", "").strip(), f[1])] = float(f[3])     # avg per launch
-out = {"static_mad_share": {"fq2p_mul_call": round(588 / 790, 3), "fq2p_sqr_call": round(392 / 577, 3), "fq_mul_call": round(392 / 505, 3),
+out = {"static_mad_share": {"fq2p_mul_call": round(588 / 732, 3), "fq2p_sqr_call": round(392 / 522, 3), "fq_mul_call": round(392 / 479, 3),
                             "is": "v_mad / all instructions of the out-of-line multiplier bodies (llvm-objdump of the shipped code object)"}}
 for key, names in KERNELS.items():
     for name in names:
