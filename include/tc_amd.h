@@ -36,7 +36,9 @@
  * 8-byte aligned, and nothing crosses PCIe.
  *
  * Threading: a context is bound to one GPU and one HIP stream and is thread-compatible (one
- * thread at a time); distinct contexts may be used concurrently (one per GPU / per process).
+ * thread at a time); distinct contexts may be used concurrently (one per GPU, or several on one GPU
+ * from several host threads).  Besides its staging buffers a context holds 256 MB of device memory
+ * for the per-job ladder tables of the G2 kernels, allocated by the first call that needs them.
  */
 #ifndef TC_AMD_H
 #define TC_AMD_H
