@@ -73,45 +73,59 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange_all(const uint
 }
 
 // ---- grouping jobs by denominator class (tc_jobs.h combine_divide) -----------------------------------
-// Three tiny kernels turn the batch into a permutation in which every class occupies a run of whole
+// Two small kernels turn the batch into a permutation in which every class occupies a run of whole
 // waves (runs padded to kCombinePad jobs with the marker 0xffffffff), so that the lanes of a wave take
 // the same branch of combine_divide.  Correctness does not depend on it: a mixed wave runs every
 // branch its lanes need.
-//   counters[c]      jobs of class c            (k_combine_classify)
-//   counters[4 + c]  next free slot of class c  (k_combine_offsets, k_combine_scatter)
+//   counters[c]      jobs of class c                               (k_combine_classify)
+//   counters[4 + c]  slots of class c handed out so far            (k_combine_scatter)
+// 256-lane workgroups: the four waves add their ballot counts up in LDS and the workgroup issues ONE atomic per
+// class (768 same-address atomics for 65 536 jobs instead of 3072: they serialise).
 constexpr uint32_t kCombinePad = 64;
-__global__ void k_combine_classify(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
-                                   uint8_t* __restrict__ cls, uint32_t* __restrict__ counters) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+constexpr int kGroupBlock = 256;
+__global__ __launch_bounds__(kGroupBlock) void k_combine_classify(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
+                                                              uint8_t* __restrict__ cls, uint32_t* __restrict__ counters) {
+  __shared__ uint32_t wg_count[kCombineClasses];
+  if (threadIdx.x < kCombineClasses) wg_count[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t j = (size_t)blockIdx.x * kGroupBlock + threadIdx.x;
   const int c = (j < B) ? combine_job_class(idx + j * n_per_job, (int)t) : -1;
   if (j < B) cls[j] = (uint8_t)c;
-  // one atomic per wave and class (tens of thousands of same-address atomics would serialise)
   for (int k = 0; k < kCombineClasses; k++) {
     const uint64_t m = __builtin_amdgcn_ballot_w64(c == k);
-    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&counters[k], (uint32_t)__builtin_popcountll(m));
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&wg_count[k], (uint32_t)__builtin_popcountll(m));
   }
+  __syncthreads();
+  if (threadIdx.x < kCombineClasses && wg_count[threadIdx.x]) atomicAdd(&counters[threadIdx.x], wg_count[threadIdx.x]);
 }
-__global__ void k_combine_offsets(uint32_t* counters) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t base = 0;
-  for (int c = 0; c < kCombineClasses; c++) {
-    counters[4 + c] = base;
-    base += (counters[c] + kCombinePad - 1) / kCombinePad * kCombinePad;
-  }
-}
-__global__ void k_combine_scatter(const uint8_t* __restrict__ cls, size_t B, uint32_t* __restrict__ counters,
-                                  uint32_t* __restrict__ perm) {
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kGroupBlock) void k_combine_scatter(const uint8_t* __restrict__ cls, size_t B, uint32_t* __restrict__ counters,
+                                                             uint32_t* __restrict__ perm) {
+  __shared__ uint32_t wave_count[kGroupBlock / 64][kCombineClasses];
+  __shared__ uint32_t wg_base[kCombineClasses];
+  const size_t j = (size_t)blockIdx.x * kGroupBlock + threadIdx.x;
   const int c = (j < B) ? (int)cls[j] : -1;
-  const unsigned lane = threadIdx.x & 63;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t mine = 0;
   for (int k = 0; k < kCombineClasses; k++) {
     const uint64_t m = __builtin_amdgcn_ballot_w64(c == k);
-    if (!m) continue;
-    const unsigned leader = (unsigned)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&counters[4 + k], (uint32_t)__builtin_popcountll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-    if (c == k) perm[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)j;
+    if (lane == 0) wave_count[wave][k] = (uint32_t)__builtin_popcountll(m);
+    if (c == k) mine = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < kCombineClasses) {
+    // where the class's run starts: the padded sizes of the classes before it (all counts are final: the
+    // classification kernel has completed), then this workgroup's share of the run
+    const int k = (int)threadIdx.x;
+    uint32_t start = 0, total = 0;
+    for (int cc = 0; cc < k; cc++) start += (counters[cc] + kCombinePad - 1) / kCombinePad * kCombinePad;
+    for (int w = 0; w < kGroupBlock / 64; w++) total += wave_count[w][k];
+    wg_base[k] = total ? start + atomicAdd(&counters[4 + k], total) : 0;
+  }
+  __syncthreads();
+  if (c >= 0) {
+    uint32_t pos = wg_base[c];
+    for (unsigned w = 0; w < wave; w++) pos += wave_count[w][c];
+    perm[pos + (uint32_t)__builtin_popcountll(mine & ((1ull << lane) - 1ull))] = (uint32_t)j;
   }
 }
 
@@ -250,9 +264,9 @@ void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job
       slots = combine_group_slots(B);
       (void)hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st);
       (void)hipMemsetAsync(perm, 0xff, slots * sizeof(uint32_t), st);
-      hipLaunchKernelGGL(k_combine_classify, dim3(grid_for(B)), dim3(kBlock), 0, st, idx, n_per_job, t, B, cls, counters);
-      hipLaunchKernelGGL(k_combine_offsets, dim3(1), dim3(64), 0, st, counters);
-      hipLaunchKernelGGL(k_combine_scatter, dim3(grid_for(B)), dim3(kBlock), 0, st, cls, B, counters, perm);
+      const unsigned gb = (unsigned)((B + kGroupBlock - 1) / kGroupBlock);
+      hipLaunchKernelGGL(k_combine_classify, dim3(gb), dim3(kGroupBlock), 0, st, idx, n_per_job, t, B, cls, counters);
+      hipLaunchKernelGGL(k_combine_scatter, dim3(gb), dim3(kGroupBlock), 0, st, cls, B, counters, perm);
     }
     hipLaunchKernelGGL(k_combine_fast<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots, ta);
   }
