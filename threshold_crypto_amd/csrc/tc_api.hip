@@ -39,6 +39,7 @@ struct tc_ctx {
   // per-job ladder tables of the G2 kernels (tc_table.h): 256 MB + one flag word per wave slot, allocated on first use
   int32_t* tbl_mem = nullptr;
   uint32_t* tbl_flags = nullptr;
+  bool tbl_reset = false;  // a call failed: a kernel may have died holding slots, clear the flags before the next use
   int cus = 0;
 };
 
@@ -83,6 +84,10 @@ struct Call {
       if (check(hipMalloc((void**)&c->tbl_mem, tc::kTableArenaWords * sizeof(int32_t)), "hipMalloc") &&
           check(hipMalloc((void**)&c->tbl_flags, tc::kTableArenaFlags * sizeof(uint32_t)), "hipMalloc"))
         check(hipMemsetAsync(c->tbl_flags, 0, tc::kTableArenaFlags * sizeof(uint32_t), c->stream), "memset");
+    }
+    if (c->tbl_flags && c->tbl_reset && !failed) {
+      // stream-ordered after whatever ran before; nothing of this context is in flight beyond the stream
+      if (check(hipMemsetAsync(c->tbl_flags, 0, tc::kTableArenaFlags * sizeof(uint32_t), c->stream), "memset")) c->tbl_reset = false;
     }
     return tc::TableArena{c->tbl_mem, c->tbl_flags};
   }
@@ -176,6 +181,7 @@ struct Call {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     }
+    if (failed && !arg_error) c->tbl_reset = true;
     return failed ? (arg_error ? TC_ERR_INVALID_ARG : TC_ERR_HIP) : TC_OK;
   }
 };

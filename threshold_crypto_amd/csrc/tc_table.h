@@ -42,7 +42,12 @@ __device__ __forceinline__ uint32_t table_slot_acquire(const TableArena& ta) {
   uint32_t slot = 0;
   if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {  // first active lane
     uint32_t i = (blockIdx.x >> 3) & (kSlotsPerXcc - 1);
-    while (atomicCAS(ta.flags + xcc * kSlotsPerXcc + i, 0u, 1u) != 0u) i = (i + 1) & (kSlotsPerXcc - 1);
+    uint32_t probes = 0;
+    while (atomicCAS(ta.flags + xcc * kSlotsPerXcc + i, 0u, 1u) != 0u) {
+      i = (i + 1) & (kSlotsPerXcc - 1);
+      // cannot happen (more slots than resident waves); a corrupted flag array must fail the launch, not hang the GPU
+      if (++probes > (64u << 20)) __builtin_trap();
+    }
     slot = xcc * kSlotsPerXcc + i;
     tc_wave_tables = (tbl_word*)(ta.mem + (size_t)slot * kWaveTableWords);
   }
