@@ -42,7 +42,7 @@ TC_MILLER_ATTR LineCoeffs miller_doubling_step(G2Jac& r) {
   l.c0 = H;
   l.c1 = -(J.dbl() + J).dbl();
   l.c2 = (B - E).dbl().norm();
-  r.x = (XY * (B - F)).dbl().reduce_value();
+  r.x = (XY * (B - F)).dbl().norm();
   const Fq2 e4 = E.sqr().dbl().dbl().norm();  // 4 E^2
   r.y = ((B + F).sqr() - (e4.dbl() + e4)).norm();
   r.z = (B * H).dbl().dbl().norm();
@@ -190,13 +190,20 @@ TC_EXPX_ATTR Fq12 cyclotomic_exp_by_x(const Fq12& f, uint64_t x_arg) {
   {
     CycloCompressed c = CycloCompressed::from(f);
     int ns = 0;
+    int since = 0;  // squarings since the value was last pulled back (tc_tower.h CycloCompressed::sqr_t)
     TC_NOUNROLL for (;; bit++) {
       tc_fair();
       if ((x >> bit) & 1ull) {
-        saved[ns++] = c;
+        saved[ns++] = since ? c.reduced() : c;
         if (ns == 3) break;
       }
-      c = c.sqr();
+      if (since + 1 == kCycloReduceEvery) {
+        c = c.sqr_t<true>();
+        since = 0;
+      } else {
+        c = c.sqr_t<false>();
+        since++;
+      }
     }
   }
   Fq12 pw[3];

@@ -265,7 +265,7 @@ struct Fq12 {
     Fq12 r;
     r.c1 = (c0 + c1).norm() * (l.c0 + l.c1).norm() - t0 - t1;
     r.c0 = t0 + t1.mul_by_v();
-    return r.reduce_value();
+    return r.norm();
   }
   // a^(q^k), k in {1,2,3}
   TC_HD_NOINLINE Fq12 frobenius(int k) const {
@@ -326,7 +326,11 @@ struct Fq12 {
 struct CycloCompressed {
   Fq2 z2, z3, z4, z5;
   TC_HD static CycloCompressed from(const Fq12& f) { return CycloCompressed{f.c1.c0, f.c0.c2, f.c0.c1, f.c1.c2}; }
-  TC_CYCLO_ATTR CycloCompressed sqr() const {
+  // REDUCE = false leaves the outputs carry-normalised only: z' = 3 t -+ 2 z doubles the VALUE per squaring, so the
+  // chain of tc_pairing.h pulls it back (reduce_value, ~105 instructions per coefficient) every kCycloReduceEvery-th
+  // squaring instead of every time -- as often as the interval analysis (tests/hostsim -DTC_BOUND_CHECK) demands
+  template <bool REDUCE>
+  TC_CYCLO_ATTR CycloCompressed sqr_t() const {
     Fq2 t0, t1, t2, t3;
     {
       Fq2 a2 = z2.sqr(), b2 = z3.sqr();
@@ -340,12 +344,25 @@ struct CycloCompressed {
     }
     const Fq2 t3x = t3.mul_xi().norm();
     CycloCompressed r;
-    r.z4 = ((t0 - z4).dbl() + t0).reduce_value();
-    r.z5 = ((t1 + z5).dbl() + t1).reduce_value();
-    r.z2 = ((t3x + z2).dbl() + t3x).reduce_value();
-    r.z3 = ((t2 - z3).dbl() + t2).reduce_value();
+    r.z4 = (t0 - z4).dbl() + t0;
+    r.z5 = (t1 + z5).dbl() + t1;
+    r.z2 = (t3x + z2).dbl() + t3x;
+    r.z3 = (t2 - z3).dbl() + t2;
+    if (REDUCE) {
+      r.z4 = r.z4.reduce_value(); r.z5 = r.z5.reduce_value(); r.z2 = r.z2.reduce_value(); r.z3 = r.z3.reduce_value();
+    } else {
+      r.z4 = r.z4.norm(); r.z5 = r.z5.norm(); r.z2 = r.z2.norm(); r.z3 = r.z3.norm();
+    }
     return r;
   }
+  TC_HD CycloCompressed sqr() const { return sqr_t<true>(); }
+  TC_HD CycloCompressed reduced() const {
+    return CycloCompressed{z2.reduce_value(), z3.reduce_value(), z4.reduce_value(), z5.reduce_value()};
+  }
 };
+#ifndef TC_CYCLO_REDUCE_EVERY
+#define TC_CYCLO_REDUCE_EVERY 3
+#endif
+constexpr int kCycloReduceEvery = TC_CYCLO_REDUCE_EVERY;
 
 }  // namespace tc
