@@ -37,6 +37,14 @@ struct Jac {
   }
 };
 
+TC_HD bool maybe_zero56(const Fq& a) { return a.maybe_zero56(); }
+TC_HD bool maybe_zero56(const Fq2& a) {
+#if TC_PAIR
+  return pair_all(a.m.maybe_zero56());  // zero <=> both coefficients zero
+#else
+  return a.c0.maybe_zero56() && a.c1.maybe_zero56();
+#endif
+}
 // The 28-bit limbs leave three bits of headroom in an int32 (|limb| < 8 * 2^28) and a
 // multiplication wants B_a * B_b <= 8 (tc_field.h), so the formulas below keep small multiples
 // AFTER the products they scale and pass sums through norm() (one carry pass) where the interval
@@ -84,6 +92,27 @@ TC_JAC_ATTR Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q) {
   r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (p.y * j).dbl().dbl()).norm().dbl());
   r.z = coord_norm((p.z + h).norm().sqr() - z1z1 - hh);
   if (p_inf) r = Jac<F>{q.x, q.y, F::one()};
+  return r;
+}
+
+// The same addition for ladder loops: the generic case only, no branch.  A lane whose operands MAY hit a special case
+// (p or q at infinity, p = +-q; two-limb zero tests, never missed, wrongly raised with probability ~2^-46) sets `exc`;
+// its result is then meaningless and the caller redoes that ladder with jac_add_mixed.
+template <class F>
+TC_JAC_ATTR Jac<F> jac_add_mixed_generic(const Jac<F>& p, const Affine<F>& q, bool& exc) {
+  F z1z1 = p.z.sqr();
+  F u2 = q.x * z1z1;
+  F s2 = q.y * p.z * z1z1;
+  F h = u2 - p.x;
+  F rr = s2 - p.y;
+  exc = exc || q.inf || maybe_zero56(h) || maybe_zero56(p.z);
+  F hh = h.sqr();
+  F j = h * hh;
+  F v = p.x * hh;
+  Jac<F> r;
+  r.x = coord_norm((rr.sqr() - j - v.dbl()).norm().dbl().dbl());
+  r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (p.y * j).dbl().dbl()).norm().dbl());
+  r.z = coord_norm((p.z + h).norm().sqr() - z1z1 - hh);
   return r;
 }
 

@@ -396,6 +396,13 @@ struct Fq {
     const uint32_t t = ((uint32_t)l[0] * FQL_INV) & (uint32_t)FQ_MASK;  // = -k mod 2^26
     return ((t + 300u) & (uint32_t)FQ_MASK) <= 600u;
   }
+  // the same test on the low TWO limbs (56 bits of k p): no call needed afterwards, false positives ~2^-46
+  TC_HD bool maybe_zero56() const {
+    const uint64_t mask = (1ull << 56) - 1;
+    const uint64_t v = (uint64_t)((int64_t)l[0] + ((int64_t)l[1] << FQ_RADIX));
+    const uint64_t t = (v * FQ_INV56) & mask;
+    return ((t + 300u) & mask) <= 600u;
+  }
   TC_HD_NOINLINE bool is_zero_full() const;
   TC_HD bool is_zero() const { return maybe_zero() && is_zero_full(); }
   TC_HD bool operator==(const Fq& b) const { return (*this - b).is_zero(); }

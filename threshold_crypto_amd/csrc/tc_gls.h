@@ -116,11 +116,10 @@ TC_HD void g2_sac_table(const G2Affine* base, G2SacTable& t) {
   tbl_store_g2(t.mem, affine_scale_z(base[0], zc2, zc3));
   TC_NOUNROLL for (int m = 1; m < 8; m++) tbl_store_g2(t.mem + m * kTblEntryWords, sums_aff[m - 1]);
 }
-TC_HD G2Jac g2_sac_ladder(const G2SacTable& t, const uint64_t* d) {
-  const SacDigits sd = sac_recode4(d);
+// the ladder with every special case of the addition handled (the slow path of g2_sac_ladder)
+TC_HD_NOINLINE G2Jac g2_sac_ladder_safe(const G2SacTable& t, const SacDigits& sd) {
   G2Jac acc = G2Jac::from_affine(t.entry(sd.top));
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
-    tc_fair();
     acc = jac_dbl(acc);
     const uint32_t m = (uint32_t)((sd.u[0] >> bit) & 1) | ((uint32_t)((sd.u[1] >> bit) & 1) << 1) |
                        ((uint32_t)((sd.u[2] >> bit) & 1) << 2);
@@ -128,6 +127,22 @@ TC_HD G2Jac g2_sac_ladder(const G2SacTable& t, const uint64_t* d) {
     e.y = Fq2::select((sd.neg >> bit) & 1, -e.y, e.y);
     acc = jac_add_mixed(acc, e);
   }
+  return acc;
+}
+TC_HD G2Jac g2_sac_ladder(const G2SacTable& t, const uint64_t* d) {
+  const SacDigits sd = sac_recode4(d);
+  G2Jac acc = G2Jac::from_affine(t.entry(sd.top));
+  bool exc = acc.is_inf();
+  TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
+    tc_fair();
+    acc = jac_dbl(acc);
+    const uint32_t m = (uint32_t)((sd.u[0] >> bit) & 1) | ((uint32_t)((sd.u[1] >> bit) & 1) << 1) |
+                       ((uint32_t)((sd.u[2] >> bit) & 1) << 2);
+    G2Affine e = t.entry(m);
+    e.y = Fq2::select((sd.neg >> bit) & 1, -e.y, e.y);
+    acc = jac_add_mixed_generic(acc, e, exc);
+  }
+  if (wave_any(exc)) acc = G2Jac::select(exc, g2_sac_ladder_safe(t, sd), acc);
   if (wave_any(sd.fix)) {
     G2Affine e = t.entry(0);
     e.y = -e.y;

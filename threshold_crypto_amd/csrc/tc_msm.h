@@ -93,12 +93,12 @@ TC_HD bool job_msm_tables(size_t n, size_t c, const uint8_t* points, const uint3
   return ok;
 }
 
-// Stage L: sum over the (4 * chunks) shares of one job from its tables and digit codes
-TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits = 64) {
+// Stage L: sum over the (4 * chunks) shares of one job from its tables and digit codes -- every special case of the
+// addition handled (the slow path of job_msm_ladder below, and the g++ reference of the fast one)
+TC_HD_NOINLINE G2Jac job_msm_ladder_safe(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G2Jac acc = G2Jac::infinity();
   TC_NOUNROLL for (int col = nbits; col >= 0; col--) {
-    tc_fair();
     if (col != nbits) acc = jac_dbl(acc);
     const uint8_t* cc = codes + (size_t)col * shares4;
     TC_NOUNROLL for (size_t s = 0; s < shares4; s++) {
@@ -110,6 +110,35 @@ TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, i
       acc = jac_add_mixed(acc, e);
     }
   }
+  return acc;
+}
+// The fast form: the accumulator starts from the first share's top entry, the padding shares (entries at infinity,
+// s >= n) are not visited, and the additions are the branch-free generic ones (tc_curve.h jac_add_mixed_generic); a
+// job that may have met a special case (an operand at infinity, P = +-Q) is redone by job_msm_ladder_safe.
+TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits = 64) {
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  bool exc = false;
+  G2Jac acc;
+  TC_NOUNROLL for (int col = nbits; col >= 0; col--) {
+    tc_fair();
+    const uint8_t* cc = codes + (size_t)col * shares4;
+    size_t s = 0;
+    if (col != nbits) {
+      acc = jac_dbl(acc);
+    } else {
+      const G2Affine e0 = msm_load_entry(tbl + (size_t)(cc[0] & 7) * kMsmEntryWords);
+      acc = G2Jac::from_affine(e0);
+      exc = e0.inf;
+      s = 1;
+    }
+    TC_NOUNROLL for (; s < n; s++) {
+      const uint32_t code = cc[s];
+      G2Affine e = msm_load_entry(tbl + (s * 8 + (code & 7)) * kMsmEntryWords);
+      if (col != nbits) e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
+      acc = jac_add_mixed_generic(acc, e, exc);
+    }
+  }
+  if (wave_any(exc)) acc = G2Jac::select(exc, job_msm_ladder_safe(n, tbl, codes, nbits), acc);
   return acc;
 }
 
