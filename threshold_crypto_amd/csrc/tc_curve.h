@@ -168,6 +168,29 @@ TC_JAC_ATTR Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   return r;
 }
 
+// add-2007-bl for ladder loops: the generic case only (see jac_add_mixed_generic); p at infinity is the CALLER's
+// business (ladders that start from the identity carry a `started` flag instead of testing Z)
+template <class F>
+TC_JAC_ATTR Jac<F> jac_add_generic(const Jac<F>& p, const Jac<F>& q, bool& exc) {
+  F z1z1 = p.z.sqr();
+  F z2z2 = q.z.sqr();
+  F u1 = p.x * z2z2;
+  F u2 = q.x * z1z1;
+  F s1 = p.y * q.z * z2z2;
+  F s2 = q.y * p.z * z1z1;
+  F h = u2 - u1;
+  F rr = s2 - s1;
+  exc = exc || maybe_zero56(h) || maybe_zero56(p.z) || maybe_zero56(q.z);
+  F hh = h.sqr();
+  F j = h * hh;
+  F v = u1 * hh;
+  Jac<F> r;
+  r.x = coord_norm((rr.sqr() - j - v.dbl()).norm().dbl().dbl());
+  r.y = coord_norm((rr * (v.dbl().dbl() - r.x) - (s1 * j).dbl().dbl()).norm().dbl());
+  r.z = coord_norm(((p.z + q.z).sqr() - z1z1 - z2z2) * h);
+  return r;
+}
+
 template <class F>
 TC_HD Jac<F> jac_neg(const Jac<F>& p) {
   return Jac<F>{p.x, (-p.y), p.z};
@@ -245,6 +268,32 @@ TC_HD Jac<F> jac_mul_affine_uniform(const Affine<F>& p, SC word, int nbits) {
     acc = jac_dbl(acc);
     if ((word(i >> 5) >> (i & 31)) & 1u) acc = jac_add_mixed(acc, p);
   }
+  return acc;
+}
+
+// [k] pa for a WAVE-UNIFORM 64-bit k whose leading one is bit `top` (fixed scalars: |x|, the cofactor constants):
+// top doublings, a mixed addition per further one bit.  The loop adds with the branch-free generic formula; a lane
+// that may have met a special case (pa at infinity or of small order: P = +-Q can then happen) redoes its ladder with
+// jac_add_mixed.  The caller multiplies Z by the base's when pa is (X, Y) of a Jacobian point.
+template <class F>
+TC_HD_NOINLINE Jac<F> jac_ladder_uniform_safe(const Affine<F>& pa, uint64_t k, int top) {
+  Jac<F> acc = Jac<F>::from_affine(pa);
+  TC_NOUNROLL for (int bit = top - 1; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    if ((k >> bit) & 1ull) acc = jac_add_mixed(acc, pa);
+  }
+  return acc;
+}
+template <class F>
+TC_HD Jac<F> jac_ladder_uniform(const Affine<F>& pa, uint64_t k, int top) {
+  Jac<F> acc = Jac<F>::from_affine(pa);
+  bool exc = pa.inf;
+  TC_NOUNROLL for (int bit = top - 1; bit >= 0; bit--) {
+    tc_fair();
+    acc = jac_dbl(acc);
+    if ((k >> bit) & 1ull) acc = jac_add_mixed_generic(acc, pa, exc);
+  }
+  if (wave_any(exc)) acc = Jac<F>::select(exc, jac_ladder_uniform_safe(pa, k, top), acc);
   return acc;
 }
 

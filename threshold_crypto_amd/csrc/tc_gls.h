@@ -222,12 +222,7 @@ TC_HD G2Jac g2_mul_gls(const G2Jac& p, const uint32_t* k) {
 // additions are mixed ones; the result's Z is multiplied by the base's)
 TC_HD_NOINLINE G2Jac g2_mul_by_x_abs(const G2Jac& p) {
   const G2Affine pa{p.x, p.y, p.is_inf()};
-  G2Jac acc = G2Jac::from_affine(pa);
-  TC_NOUNROLL for (int bit = 62; bit >= 0; bit--) {
-    tc_fair();
-    acc = jac_dbl(acc);
-    if ((BLS_X_ABS >> bit) & 1ull) acc = jac_add_mixed(acc, pa);
-  }
+  G2Jac acc = jac_ladder_uniform(pa, BLS_X_ABS, 63);
   acc.z = coord_norm(acc.z * p.z);
   return acc;
 }
@@ -262,12 +257,7 @@ TC_HD G2Jac g2_clear_cofactor(const G2Affine& pa, bool fix = true) {
   // (X, Y) of s is an AFFINE point of the isomorphic curve y^2 = x^3 + b Z^6 (tc_curve.h
   // jac_batch_to_common_z): the ladder adds it with mixed additions and its result gets Z back
   const G2Affine sa{s.x, s.y, s.is_inf()};
-  G2Jac acc = G2Jac::from_affine(sa);
-  TC_NOUNROLL for (int bit = 61; bit >= 0; bit--) {  // bit 62 is the leading one
-    tc_fair();
-    acc = jac_dbl(acc);
-    if ((G2_COFACTOR_FIX_SHORT >> bit) & 1ull) acc = jac_add_mixed(acc, sa);
-  }
+  G2Jac acc = jac_ladder_uniform(sa, G2_COFACTOR_FIX_SHORT, 62);  // bit 62 is the leading one
   acc.z = coord_norm(acc.z * s.z);
   return acc;
 }
@@ -341,12 +331,7 @@ TC_HD G1Jac g1_mul_glv(const G1Jac& p, const uint32_t* k) {
 // [|x|] P on G1 by the 64-bit ladder
 TC_HD_NOINLINE G1Jac g1_mul_by_x_abs(const G1Jac& p) {
   const G1Affine pa{p.x, p.y, p.is_inf()};
-  G1Jac acc = G1Jac::from_affine(pa);
-  TC_NOUNROLL for (int bit = 62; bit >= 0; bit--) {
-    tc_fair();
-    acc = jac_dbl(acc);
-    if ((BLS_X_ABS >> bit) & 1ull) acc = jac_add_mixed(acc, pa);
-  }
+  G1Jac acc = jac_ladder_uniform(pa, BLS_X_ABS, 63);
   acc.z = coord_norm(acc.z * p.z);
   return acc;
 }

@@ -243,12 +243,7 @@ TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
     TC_NOUNROLL for (int i = 0; i < 15; i++) base = G2Jac::select(i < pre, jac_dbl(base), base);
     const uint64_t s = BLS_X_ABS >> 16;
     const G2Affine ba{base.x, base.y, base.is_inf()};  // affine on the curve scaled by base.z (tc_gls.h)
-    G2Jac acc = G2Jac::from_affine(ba);
-    TC_NOUNROLL for (int bit = 46; bit >= 0; bit--) {  // bit 47 is the leading one
-      tc_fair();
-      acc = jac_dbl(acc);
-      if ((s >> bit) & 1ull) acc = jac_add_mixed(acc, ba);
-    }
+    G2Jac acc = jac_ladder_uniform(ba, s, 47);  // bit 47 is the leading one
     acc.z = coord_norm(acc.z * base.z);
     r = G2Jac::select(cls == kCombineClassPow2, acc, r);
   }

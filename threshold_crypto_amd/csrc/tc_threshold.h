@@ -372,7 +372,22 @@ TC_HD uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
-// sum_k c_k * P_k for K <= 4 points and 64-bit scalars
+// sum_k c_k * P_k for K <= 4 points and 64-bit scalars: the joint ladder over the subset-sum table, with every special
+// case of the addition handled (the slow path of straus_small below)
+template <class F, int K>
+TC_HD_NOINLINE Jac<F> straus_small_safe(const Jac<F>* tbl, const uint64_t* c, uint32_t bits) {
+  Jac<F> acc = Jac<F>::infinity();
+  TC_NOUNROLL for (int bit = (int)bits - 1; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    uint32_t m = 0;
+    TC_UNROLL for (int k = 0; k < K; k++) m |= (uint32_t)((c[k] >> bit) & 1ull) << k;
+    if (m) acc = jac_add(acc, tbl[m]);
+  }
+  return acc;
+}
+// The fast form: a `started` flag instead of tests for the identity, the branch-free generic addition
+// (tc_curve.h jac_add_generic), and a second pass through straus_small_safe for the lanes that may have met a special
+// case (an input or a subset sum at infinity, P = +-Q).
 template <class F, int K>
 TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   Jac<F> tbl[1 << K];
@@ -390,13 +405,23 @@ TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   bits = wave_max_u32(bits);
   if (bits > 64) bits = 64;  // lanes that left for the general path contribute undefined values
   Jac<F> acc = Jac<F>::infinity();
+  bool started = false, exc = false;
   TC_NOUNROLL for (int bit = (int)bits - 1; bit >= 0; bit--) {
     tc_fair();
-    acc = jac_dbl(acc);
+    acc = jac_dbl(acc);  // the identity (0 : 1 : 0) doubles to itself
     uint32_t m = 0;
     TC_UNROLL for (int k = 0; k < K; k++) m |= (uint32_t)((c[k] >> bit) & 1ull) << k;
-    if (m) acc = jac_add(acc, tbl[m]);
+    if (wave_any(m != 0)) {
+      const Jac<F> e = tbl[m];
+      bool hit = false;
+      const Jac<F> sum = jac_add_generic(acc, e, hit);
+      const bool take = m != 0;
+      exc = exc || (take && (started ? hit : maybe_zero56(e.z)));
+      acc = Jac<F>::select(take, Jac<F>::select(started, sum, e), acc);
+      started = started || take;
+    }
   }
+  if (wave_any(exc)) acc = Jac<F>::select(exc, straus_small_safe<F, K>(tbl, c, bits), acc);
   return acc;
 }
 
