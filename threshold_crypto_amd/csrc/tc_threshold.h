@@ -130,6 +130,17 @@ TC_HD uint8_t lagrange_finish(int n, const uint32_t* xm, const uint32_t* den, ui
 // One shared doubling chain for the K points; control flow is lane-uniform except the
 // "all K bits are zero" skip.  sc[k] points at 8 little-endian u32 words (canonical, < r).
 template <class F, int K>
+TC_HD_NOINLINE Jac<F> straus_chunk_ladder_safe(const Affine<F>* tbl, const uint32_t (*sc)[8]) {
+  Jac<F> acc = Jac<F>::infinity();
+  TC_NOUNROLL for (int bit = 254; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    uint32_t m = 0;
+    TC_UNROLL for (int k = 0; k < K; k++) m |= ((sc[k][bit >> 5] >> (bit & 31)) & 1u) << k;
+    if (m) acc = jac_add_mixed(acc, tbl[m]);
+  }
+  return acc;
+}
+template <class F, int K>
 TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
   // subset sums by mixed additions, then one common Z for the whole table (tc_curve.h
   // jac_batch_to_common_z, no inversion) so that the 255-step ladder also runs on mixed additions
@@ -158,13 +169,24 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
       tbl[m] = (slot[m] >= 0) ? sums_aff[slot[m]] : affine_scale_z(pts[__builtin_ctz((unsigned)m)], zc2, zc3);
   }
   Jac<F> acc = Jac<F>::infinity();
+  bool started = false, exc = false;
   TC_NOUNROLL for (int bit = 254; bit >= 0; bit--) {
     tc_fair();
-    acc = jac_dbl(acc);
+    acc = jac_dbl(acc);  // the identity doubles to itself
     uint32_t m = 0;
     TC_UNROLL for (int k = 0; k < K; k++) m |= ((sc[k][bit >> 5] >> (bit & 31)) & 1u) << k;
-    if (m) acc = jac_add_mixed(acc, tbl[m]);
+    if (wave_any(m != 0)) {
+      // generic-case addition + a `started` flag (tc_curve.h jac_add_mixed_generic); special cases go to the safe ladder
+      const Affine<F> e = tbl[m ? m : 1];
+      bool hit = false;
+      const Jac<F> sum = jac_add_mixed_generic(acc, e, hit);
+      const bool take = m != 0;
+      exc = exc || (take && (started ? hit : e.inf));
+      acc = Jac<F>::select(take, Jac<F>::select(started, sum, Jac<F>::from_affine(e)), acc);
+      started = started || take;
+    }
   }
+  if (wave_any(exc)) acc = Jac<F>::select(exc, straus_chunk_ladder_safe<F, K>(tbl, sc), acc);
   acc.z = coord_norm(acc.z * zc);
   return acc;
 }
@@ -174,6 +196,21 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
 // common Z, and ONE chain of 64 doublings serves all sixteen 64-bit digits: per point 64 mixed
 // additions + 16 doublings instead of the 64 + 64 of the 255-bit Straus ladder above.
 // An even scalar runs as r - k on the negated point (gls_decompose_odd), so first digits are odd.
+TC_HD_NOINLINE G2Jac straus_gls4_ladder_safe(const G2Affine* tbl, const SacDigits* sd) {
+  G2Jac acc = G2Jac::infinity();
+  TC_NOUNROLL for (int k = 0; k < 4; k++) acc = jac_add_mixed(acc, tbl[8 * k + sd[k].top]);
+  TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    TC_NOUNROLL for (int k = 0; k < 4; k++) {
+      const uint32_t m = (uint32_t)((sd[k].u[0] >> bit) & 1) | ((uint32_t)((sd[k].u[1] >> bit) & 1) << 1) |
+                         ((uint32_t)((sd[k].u[2] >> bit) & 1) << 2);
+      G2Affine e = tbl[8 * k + m];
+      e.y = Fq2::select((sd[k].neg >> bit) & 1, -e.y, e.y);
+      acc = jac_add_mixed(acc, e);
+    }
+  }
+  return acc;
+}
 TC_HD G2Jac straus_chunk_gls4(const G2Affine* pts, const uint32_t (*sc)[8]) {
   G2Affine tbl[32];  // entries 8k .. 8k+7 belong to point k
   SacDigits sd[4];
@@ -204,8 +241,11 @@ TC_HD G2Jac straus_chunk_gls4(const G2Affine* pts, const uint32_t (*sc)[8]) {
       TC_NOUNROLL for (int m = 1; m < 8; m++) tbl[8 * k + m] = sums_aff[7 * k + m - 1];
     }
   }
-  G2Jac acc = G2Jac::infinity();
-  TC_NOUNROLL for (int k = 0; k < 4; k++) acc = jac_add_mixed(acc, tbl[8 * k + sd[k].top]);  // column 64: all positive
+  // generic-case additions (tc_curve.h jac_add_mixed_generic); a lane that may have met a special case redoes the
+  // ladder below with jac_add_mixed
+  G2Jac acc = G2Jac::from_affine(tbl[sd[0].top]);  // column 64: all positive
+  bool exc = tbl[sd[0].top].inf;
+  TC_NOUNROLL for (int k = 1; k < 4; k++) acc = jac_add_mixed_generic(acc, tbl[8 * k + sd[k].top], exc);
   TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
     tc_fair();
     acc = jac_dbl(acc);
@@ -214,9 +254,10 @@ TC_HD G2Jac straus_chunk_gls4(const G2Affine* pts, const uint32_t (*sc)[8]) {
                          ((uint32_t)((sd[k].u[2] >> bit) & 1) << 2);
       G2Affine e = tbl[8 * k + m];
       e.y = Fq2::select((sd[k].neg >> bit) & 1, -e.y, e.y);
-      acc = jac_add_mixed(acc, e);
+      acc = jac_add_mixed_generic(acc, e, exc);
     }
   }
+  if (wave_any(exc)) acc = G2Jac::select(exc, straus_gls4_ladder_safe(tbl, sd), acc);
   acc.z = coord_norm(acc.z * zc);
   return acc;
 }
