@@ -106,3 +106,50 @@ def test_identity_operands_through_the_arena(engine, wl):
         for s in range(3):
             assert bytes(out[j, s]) == oracle_mul(k[s], pts[j]), (j, s)
     assert bytes(out[5, 2]) == bytes(inf) and bytes(out[0, 0]) == bytes(inf)
+
+
+def test_ladder_special_cases_take_the_safe_path(engine, wl):
+    """The ladder loops add with the generic formula and redo a ladder on the fully guarded path when a lane may have
+    met P = +-Q or the identity (csrc/tc_curve.h jac_add_mixed_generic).  Scalars and point sets built to hit those
+    cases -- single multiplications, the chunked (n < 8) and the two-stage (n >= 8) linear combination, the
+    small-index combine -- against Oracle A's textbook affine group law."""
+    import tc_oracle as o
+    R = o.R
+    X = 0xd201000000010000
+    P = o.g2_from_uncompressed(bytes(wl.hashes[0]))
+    Q = o.g2_from_uncompressed(bytes(wl.hashes[1]))
+    enc = lambda pt: u8(o.g2_uncompressed(pt))
+    frb = lambda k: u8((k % R).to_bytes(32, "little"))
+    # single multiplications: tiny scalars, r - small, powers of |x| (one-digit decompositions), 2^64 neighbours
+    ks = [0, 1, 2, 3, 4, 7, R - 1, R - 2, R - 3, X, X + 1, X - 1, X * X, X * X + 1, X ** 3, X ** 3 + X, (1 << 64) - 1, 1 << 64,
+          (R - 1) // 2, (R + 1) // 2]
+    out, st = engine.g2_mul(np.stack([frb(k) for k in ks]), np.stack([enc(P), enc(Q)]))
+    assert not st.any()
+    for j, pt in enumerate((P, Q)):
+        for s, k in enumerate(ks):
+            assert bytes(out[j, s]) == o.g2_uncompressed(o.E2.mul(pt, k % R)), (j, k)
+    # linear combinations whose partial sums collide or vanish
+    negP = o.E2.neg(P)
+    P2 = o.E2.dbl(P)
+    for n, pts, sc in (
+        (4, [P, P, negP, P], [1, 1, 1, 2]),
+        (4, [P, negP, Q, Q], [5, 5, 7, R - 7]),
+        (8, [P, P, negP, P, None, P, P2, Q], [1, 1, 1, 2, 5, R - 1, 1, 3]),
+        (8, [P, negP, P, negP, P, negP, P, negP], [9, 9, 9, 9, 9, 9, 9, 9]),
+        (9, [Q, Q, Q, Q, Q, Q, Q, Q, Q], [1, 2, 4, 8, 16, 32, 64, 128, R - 255]),
+    ):
+        pts_b = np.stack([enc(p) for p in pts])[None]
+        sc_b = np.stack([frb(k) for k in sc])[None]
+        got, st = engine.lincomb_g2(np.ascontiguousarray(sc_b), np.ascontiguousarray(pts_b))
+        assert not st.any()
+        want = None
+        for p, k in zip(pts, sc):
+            want = o.E2.add(want, o.E2.mul(p, k % R))
+        assert bytes(got[0]) == o.g2_uncompressed(want), (n, sc)
+    # small-index combine of four EQUAL shares (every subset sum of the short ladder is a multiple of one point)
+    idx = np.array([[0, 1, 2, 3], [1, 4, 6, 9]], dtype=np.uint64)
+    shares = np.stack([np.stack([enc(P)] * 4), np.stack([enc(Q)] * 4)])
+    got, st = engine.combine_g2(3, idx, shares)
+    assert not st.any()
+    # sum_i lambda_i = 1: interpolating the constant polynomial gives the point back
+    assert bytes(got[0]) == o.g2_uncompressed(P) and bytes(got[1]) == o.g2_uncompressed(Q)
