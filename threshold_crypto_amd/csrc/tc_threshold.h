@@ -466,4 +466,8 @@ TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   return acc;
 }
 
+// out-of-line form: the short ladder gets its own register allocation instead of sharing the caller's
+template <class F, int K>
+TC_HD_NOINLINE Jac<F> straus_small_call(const Affine<F>* pts, const uint64_t* c) { return straus_small<F, K>(pts, c); }
+
 }  // namespace tc
