@@ -159,6 +159,27 @@ def test_point_mul(L, rnd):
     assert L.hs_g2_mul(o.fr_to_bytes(5), bytes(bad), out) == 3
 
 
+def test_gls_digits_by_reciprocal_division(L, rnd):
+    """k = d0 + d1 |x| + d2 |x|^2 + d3 |x|^3 (csrc/tc_gls.h gls_decompose: 2-by-1 divisions through the reciprocal of
+    |x|) against Python's divmod -- random scalars and the values around every correction branch of the division."""
+    X = 0xd201000000010000
+    ks = [0, 1, X - 1, X, X + 1, X * X - 1, X * X, X ** 3 - 1, X ** 3, o.R - 1, o.R - 2, (1 << 255) - 19, (1 << 64) - 1, 1 << 64,
+          (1 << 128) - 1, 1 << 128, (X - 1) * (1 + X + X * X + X ** 3) % (X ** 4)]
+    ks += [rnd.getrandbits(255) % o.R for _ in range(400)] + [(rnd.getrandbits(64) * X + rnd.choice([0, 1, X - 1])) % o.R for _ in range(200)]
+    for k in ks:
+        if k >= X ** 4:
+            continue
+        w = (ctypes.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        d = (ctypes.c_uint64 * 4)()
+        L.hs_gls_decompose(w, d)
+        want, n = [], k
+        for _ in range(3):
+            n, r = divmod(n, X)
+            want.append(r)
+        want.append(n)
+        assert list(d) == want, hex(k)
+
+
 def test_g2_mul_several_scalars_share_one_table(L, rnd):
     """tc_jobs.h job_g2_mul_shared: the S signers of tc_g2_mul_batch over one hash point."""
     Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))

@@ -31,27 +31,36 @@ TC_HD_NOINLINE G2Jac g2_psi(const G2Jac& p) {
   return G2Jac{(p.x.conj() * psi_cx()), (p.y.conj() * psi_cy()), p.z.conj().norm()};
 }
 
-// k (8 little-endian u32 words, < r < |x|^4) -> four base-|x| digits.  Binary long division on
-// 64-bit words: ~600 scalar-free iterations of shift/compare/subtract, negligible next to the
-// thousands of field multiplications it saves.
+// (u1 : u0) / |x| for u1 < |x|: quotient and remainder by multiplication with the precomputed reciprocal
+// (Moeller-Granlund, "Improved division by invariant integers", 2-by-1 division; |x| has its top bit set)
+TC_HD uint64_t div_by_x_abs(uint64_t u1, uint64_t u0, uint64_t* rem) {
+  typedef unsigned __int128 u128;
+  const uint64_t X = BLS_X_ABS;
+  const u128 q = (u128)BLS_X_RECIP * u1 + (((u128)u1 << 64) | u0);
+  uint64_t q1 = (uint64_t)(q >> 64) + 1;
+  const uint64_t q0 = (uint64_t)q;
+  uint64_t r = u0 - q1 * X;
+  if (r > q0) {
+    q1--;
+    r += X;
+  }
+  if (r >= X) {
+    q1++;
+    r -= X;
+  }
+  *rem = r;
+  return q1;
+}
+// k (8 little-endian u32 words, < r < |x|^4) -> four base-|x| digits: three long divisions by the 64-bit |x|, a word at
+// a time (12 reciprocal divisions; the bit-serial form this replaces took ~770 shift/compare/subtract iterations,
+// 2-3 % of a G2 scalar multiplication).
 TC_HD void gls_decompose(const uint32_t* k, uint64_t* d) {
   uint64_t n[4] = {(uint64_t)k[0] | ((uint64_t)k[1] << 32), (uint64_t)k[2] | ((uint64_t)k[3] << 32),
                    (uint64_t)k[4] | ((uint64_t)k[5] << 32), (uint64_t)k[6] | ((uint64_t)k[7] << 32)};
-  const uint64_t X = BLS_X_ABS;
-  TC_NOUNROLL for (int digit = 0; digit < 3; digit++) {
-    // n = q * X + rem
-    uint64_t q[4] = {0, 0, 0, 0};
-    uint64_t rem = 0;
-    TC_NOUNROLL for (int bit = 255; bit >= 0; bit--) {
-      const uint64_t top = rem >> 63;
-      rem = (rem << 1) | ((n[bit >> 6] >> (bit & 63)) & 1ull);
-      if (top || rem >= X) {
-        rem -= X;
-        q[bit >> 6] |= 1ull << (bit & 63);
-      }
-    }
+  TC_UNROLL for (int digit = 0; digit < 3; digit++) {
+    uint64_t rem = 0;  // n = q * |x| + rem, the quotient replaces n
+    TC_UNROLL for (int i = 3; i >= 0; i--) n[i] = div_by_x_abs(rem, n[i], &rem);
     d[digit] = rem;
-    n[0] = q[0]; n[1] = q[1]; n[2] = q[2]; n[3] = q[3];
   }
   d[3] = n[0];  // k < r < |x|^4  =>  the last quotient fits one word
 }
@@ -273,21 +282,13 @@ TC_HD G1Affine g1_phi(const G1Affine& p) {
 
 typedef unsigned __int128 tc_u128;
 
-// k (8 LE u32 words, < r) -> (k1, k2) with k = k1 + k2 * x^2; binary long division
+// k (8 LE u32 words, < r) -> (k1, k2) with k = k1 + k2 * x^2: from the base-|x| digits of k (gls_decompose above),
+// k1 = d0 + d1 |x|, k2 = d2 + d3 |x|
 TC_HD void glv_decompose(const uint32_t* k, tc_u128* k1, tc_u128* k2) {
-  const tc_u128 X2 = ((tc_u128)BLS_X2_HI << 64) | BLS_X2_LO;
-  tc_u128 rem = 0, q = 0;
-  TC_NOUNROLL for (int bit = 255; bit >= 0; bit--) {
-    const bool top = (rem >> 127) != 0;
-    rem = (rem << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
-    q <<= 1;  // quotient < 2^128 because k < r < x^4
-    if (top || rem >= X2) {
-      rem -= X2;
-      q |= 1;
-    }
-  }
-  *k1 = rem;
-  *k2 = q;
+  uint64_t d[4];
+  gls_decompose(k, d);
+  *k1 = (tc_u128)d[1] * BLS_X_ABS + d[0];
+  *k2 = (tc_u128)d[3] * BLS_X_ABS + d[2];
 }
 
 // [k] P for P in G1, k < r: joint 128-step ladder over the affine table {P, -phi(P), P - phi(P)}

@@ -343,11 +343,18 @@ TC_HD void fr_inverse_of_small(uint64_t d_abs, bool d_neg, uint32_t* out_words) 
   TC_UNROLL for (int i = 0; i < 4; i++) rl[i] = (uint64_t)FR_P[2 * i] | ((uint64_t)FR_P[2 * i + 1] << 32);
   uint64_t q[5] = {1, 0, 0, 0, 0};  // D = 1
   if (d_abs > 1) {
+    // D below 2^32 in every lane of the wave (node numbers: always, in practice): both long divisions run on 32-bit
+    // words with the 64-bit divide; otherwise bit by bit
+    const bool small = !wave_any((d_abs >> 32) != 0);
     // r mod D
     uint64_t r1 = 0;
-    TC_NOUNROLL for (int bit = 254; bit >= 0; bit--) {
-      r1 = (r1 << 1) | ((rl[bit >> 6] >> (bit & 63)) & 1ull);
-      if (r1 >= d_abs) r1 -= d_abs;
+    if (small) {
+      TC_UNROLL for (int i = 7; i >= 0; i--) r1 = ((r1 << 32) | FR_P[i]) % d_abs;
+    } else {
+      TC_NOUNROLL for (int bit = 254; bit >= 0; bit--) {
+        r1 = (r1 << 1) | ((rl[bit >> 6] >> (bit & 63)) & 1ull);
+        if (r1 >= d_abs) r1 -= d_abs;
+      }
     }
     // r1^-1 mod D (gcd = 1: r is prime and D < r)
     int64_t t = 0, newt = 1;
@@ -377,11 +384,20 @@ TC_HD void fr_inverse_of_small(uint64_t d_abs, bool d_neg, uint32_t* out_words) 
     // Q = N / D
     uint64_t rem = 0;
     TC_UNROLL for (int i = 0; i < 5; i++) q[i] = 0;
-    TC_NOUNROLL for (int bit = 319; bit >= 0; bit--) {
-      rem = (rem << 1) | ((n[bit >> 6] >> (bit & 63)) & 1ull);
-      if (rem >= d_abs) {
-        rem -= d_abs;
-        q[bit >> 6] |= 1ull << (bit & 63);
+    if (small) {
+      TC_UNROLL for (int i = 9; i >= 0; i--) {
+        const uint64_t cur = (rem << 32) | (uint32_t)(n[i >> 1] >> (32 * (i & 1)));
+        const uint64_t qq = cur / d_abs;  // < 2^32 because rem < D
+        rem = cur - qq * d_abs;
+        q[i >> 1] |= qq << (32 * (i & 1));
+      }
+    } else {
+      TC_NOUNROLL for (int bit = 319; bit >= 0; bit--) {
+        rem = (rem << 1) | ((n[bit >> 6] >> (bit & 63)) & 1ull);
+        if (rem >= d_abs) {
+          rem -= d_abs;
+          q[bit >> 6] |= 1ull << (bit & 63);
+        }
       }
     }
   }
