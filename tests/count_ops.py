@@ -46,6 +46,17 @@ L.hs_g2_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g2_uncompressed(P2), buf(192));
 L.hs_g1_mul(o.fr_to_bytes(rnd.randrange(o.R)), o.g1_uncompressed(P1), buf(96)); res["g1_mul"] = (cnt(), 1)
 L.hs_g2_mul_shared(b"".join(o.fr_to_bytes(rnd.randrange(o.R)) for _ in range(4)), 4, o.g2_uncompressed(P2), buf(768), buf(4))
 res["g2_mul_4_scalars_per_point"] = (tuple(x // 4 for x in cnt()), 2)
+# share generation (k_g2_mul_gather): 68 signers of a message in tables of kGatherShare scalars -- full tables + the remainder
+_g = L.hs_gather_share()
+_sk = b"".join(o.fr_to_bytes(rnd.randrange(o.R)) for _ in range(_g))
+_idx = (ctypes.c_uint64 * _g)(*range(_g))
+L.hs_g2_mul_gather(_sk, _g, _idx, _g, o.g2_uncompressed(P2), buf(192 * _g), buf(_g)); _full = cnt()
+_rem = 68 % _g
+if _rem:
+    L.hs_g2_mul_gather(_sk, _g, _idx, _rem, o.g2_uncompressed(P2), buf(192 * _g), buf(_g)); _part = cnt()
+else:
+    _part = tuple(0 for _ in _full)
+res["g2_mul_gather_68_signers"] = (tuple(((68 // _g) * a + b) // 68 for a, b in zip(_full, _part)), 2)
 poly = [rnd.randrange(o.R) for _ in range(4)]
 shares_g2 = {i: o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in range(10)}
 shares_g1 = {i: o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in range(10)}

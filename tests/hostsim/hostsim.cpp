@@ -88,6 +88,11 @@ void hs_gls_decompose(const uint32_t* k, uint64_t* d) { gls_decompose(k, d); }
 void hs_g2_mul_shared(const uint8_t* fr, int n, const uint8_t* pt, uint8_t* out, uint8_t* status) {
   job_g2_mul_shared(fr, n, pt, out, status, true);
 }
+// out[s] = sk[idx[s]] * pt, n <= kGatherShare signers over one table (the share-generation kernel's job body)
+void hs_g2_mul_gather(const uint8_t* sk, size_t N, const uint64_t* idx, int n, const uint8_t* pt, uint8_t* out, uint8_t* status) {
+  job_g2_mul_gather(sk, N, idx, n, pt, out, status, true);
+}
+int hs_gather_share() { return kGatherShare; }
 int hs_lagrange(const uint64_t* idx, int t, int i, uint8_t* out32le) {
   uint32_t w[8];
   int st = job_lagrange(idx, t, i, w);

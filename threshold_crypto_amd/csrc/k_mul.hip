@@ -41,18 +41,18 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_shared(const uin
   table_slot_release(ta, tslot);
 }
 
-// shares of B messages by per-message signer subsets: a lane pair takes one hash point and up to kMulShare of the
+// shares of B messages by per-message signer subsets: a lane pair takes one hash point and up to kGatherShare of the
 // n selected signers (chunk-major lane order as above); out[(j * n + k)] = sk[idx[j * n + k]] * pts[j]
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_gather(const uint8_t* __restrict__ sk, size_t N, const uint64_t* __restrict__ idx,
                                                                      const uint8_t* __restrict__ pts, size_t n, size_t B,
                                                                      uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
   const uint32_t tslot = table_slot_acquire(ta);
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
-  const size_t chunks = (n + kMulShare - 1) / kMulShare;
+  const size_t chunks = (n + kGatherShare - 1) / kGatherShare;
   if (tid < chunks * B) {
     const size_t c = tid / B, j = tid % B;
-    const size_t s0 = c * kMulShare;
-    const int cnt = (int)((n - s0 < (size_t)kMulShare) ? n - s0 : (size_t)kMulShare);
+    const size_t s0 = c * kGatherShare;
+    const int cnt = (int)((n - s0 < (size_t)kGatherShare) ? n - s0 : (size_t)kGatherShare);
     const size_t o = j * n + s0;
     job_g2_mul_gather(sk, N, idx + o, cnt, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
   }
@@ -114,7 +114,7 @@ void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8
 void launch_g2_mul_gather(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
                           uint8_t* out, uint8_t* status) {
   if (!(n * B) || !ta.mem || !ta.flags) return;
-  const size_t chunks = (n + kMulShare - 1) / kMulShare;
+  const size_t chunks = (n + kGatherShare - 1) / kGatherShare;
   hipLaunchKernelGGL(k_g2_mul_gather, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, sk, N, idx, pts, n, B, out, status, ta);
 }
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {

@@ -100,7 +100,8 @@ TC_HD void job_g2_mul_shared(const uint8_t* fr_le32, int n, const uint8_t* pt, u
   }
 }
 
-// out[s] = sk[idx[s]] * pt for n <= kMulShare signer indices into a table of N secret key shares: the shares of
+constexpr int kGatherShare = 8;  // scalars per table in the gather kernel (68 signers: 9 tables per message instead of 17)
+// out[s] = sk[idx[s]] * pt for n <= kGatherShare signer indices into a table of N secret key shares: the shares of
 // ONE message by the signers of its subset (SecretKeyShare::sign_g2, src/lib.rs:442-444, for every selected
 // signer), generated on the device so that a (t, N, batch) workload needs only the key set and the hash points.
 // An index >= N fails its own output.
@@ -113,8 +114,8 @@ TC_HD void job_g2_mul_gather(const uint8_t* sk_table, size_t N, const uint64_t* 
   g2_gls_bases(p, base);
   G2SacTable tb;
   g2_sac_table_call(base, tb);
-  G2Jac res[kMulShare];
-  bool ok[kMulShare];
+  G2Jac res[kGatherShare];
+  bool ok[kGatherShare];
   TC_NOUNROLL for (int s = 0; s < n; s++) {
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t i = idx[s];
@@ -126,8 +127,8 @@ TC_HD void job_g2_mul_gather(const uint8_t* sk_table, size_t N, const uint64_t* 
     r.y = Fq2::select(flip, -r.y, r.y);
     res[s] = G2Jac::select(ok[s], r, G2Jac::infinity());
   }
-  G2Affine aff[kMulShare];
-  jac_batch_to_affine<Fq2, kMulShare>(res, aff, n);
+  G2Affine aff[kGatherShare];
+  jac_batch_to_affine<Fq2, kGatherShare>(res, aff, n);
   TC_NOUNROLL for (int s = 0; s < n; s++) {
     g2_encode_uncompressed(aff[s], out + (size_t)s * 192);
     if (status && leader) status[s] = ok[s] ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
