@@ -6,7 +6,10 @@
 --config 2 (default; BASELINE "t=3, N=10, batch=65 536 threshold signatures on 1xMI355X"): a "step" is
 one pass of PublicKeySet::combine_signatures (src/lib.rs:608-615) over `batch` independent
 (message, share-set) jobs through the C ABI (tc_combine_g2_batch) with every input already resident in
-HBM.  The same batch is then verified (PublicKey::verify_g2, src/lib.rs:108-110; every 16th signature
+HBM.  The K timed steps are issued without host synchronisation and alternate between two contexts (--in-flight, one
+HIP stream each), so consecutive launches overlap at their ends -- each step is still a full pass over the batch; the
+JSON line also carries the one-context, host-waits-every-step figure (`sequential`), and the roofline's per-launch
+kernel time is measured on that leg.  The same batch is then verified (PublicKey::verify_g2, src/lib.rs:108-110; every 16th signature
 replaced by its neighbour's, so the expected ok-vector is known), re-signed, verified with hashing on the
 device, and run through the threshold-decryption path (BASELINE configs 3 and 4); each of those legs
 carries its own roofline object and ANY failing leg fails the run.
@@ -120,6 +123,9 @@ def main():
     ap.add_argument("--signers", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="contexts (one HIP stream each) the timed steps of config 2 alternate between; 1 = one context, "
+                         "the host waits for every step")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (configs 3 and 4, PCIe-inclusive rate)")
     args = ap.parse_args()
 
@@ -184,16 +190,31 @@ def run_config2(args, eng, dev, rank, world, peak):
             dist.barrier()
             torch.cuda.synchronize()
 
-    eng.set_timing(True)
     # ---- headline: combine_signatures ----------------------------------------------------
-    for _ in range(args.warmup):
-        sig, st = eng.combine_g2(t, d_idx, d_shares)
+    # The timed region issues its K steps WITHOUT host synchronisation, alternating between `--in-flight` contexts (one
+    # HIP stream each, the same device-resident operands, separate outputs): every step is a full pass over the batch,
+    # and the tail of one launch -- the 65 536-job batch is a single resident round that ends with a third of the SIMDs
+    # idle -- overlaps the head of the next.  This is how a caller with a stream of batches drives the
+    # library; `sequential` below is the same work on one context with the host waiting for each step,
+    # and the per-launch kernel time of the roofline comes from that leg (un-overlapped launches).
+    from threshold_crypto_amd.engine import Engine
+    in_flight = max(1, int(args.in_flight))
+    engines = [eng] + [Engine(dev.index if dev.index is not None else 0) for _ in range(in_flight - 1)]
+    for e in engines:
+        e.set_timing(False)
+        for _ in range(max(1, args.warmup)):
+            sig, st = e.combine_g2(t, d_idx, d_shares)
+    for e in engines:
+        e.sync()
     sync()
-    kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sig, st = eng.combine_g2(t, d_idx, d_shares)
-        kernel_ms.append(eng.last_kernel_ms())
+    outs = []
+    for i in range(args.steps):
+        outs.append(engines[i % in_flight].combine_g2(t, d_idx, d_shares))
+        if len(outs) > 2 * in_flight:
+            outs.pop(0)
+    for e in engines:
+        e.sync()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -202,7 +223,29 @@ def run_config2(args, eng, dev, rank, world, peak):
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
+    for o_sig, o_st in outs:
+        assert int(o_st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
+    # the same steps one at a time (host waits for each): per-launch kernel times for the roofline
+    eng.set_timing(True)
+    seq_steps = min(args.steps, 10)
+    kernel_ms = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(seq_steps):
+        sig, st = eng.combine_g2(t, d_idx, d_shares)
+        kernel_ms.append(eng.last_kernel_ms())
+    sync()
+    seq_dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([seq_dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        seq_dt = float(tt.item())
     assert int(st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
+    for o_sig, _ in outs:
+        assert bool((o_sig == sig).all().item()), "steps in flight and the sequential step disagree"
+    del outs
+    for e in engines[1:]:
+        e.close()
 
     # ---- config 3: verify the combined signatures; every 16th one replaced by its neighbour's ------------
     bad = sig.clone()
@@ -297,6 +340,9 @@ def run_config2(args, eng, dev, rank, world, peak):
                         "combine_g2", t, B, avg_kernel_ms, peak, traffic_key="combine_g2_t3",
                         extra={"frac_slowest_class": round(EXECUTED_MACS["combine_g2_t3_fast_general_denominator"] * B
                                                            / (avg_kernel_ms * 1e-3) / 1e12 / peak["tmacs"], 4),
+                               "frac_timed_region": round(EXECUTED_MACS[unit_key] * B / (ms_per_step * 1e-3) / 1e12 / peak["tmacs"], 4),
+                               "frac_timed_region_is": "executed multiply-adds of the K timed steps / their wall time / peak: the "
+                                                       "machine's utilisation with steps in flight (frac is per launch)",
                                "frac_is": "average job over the 4-of-10 subsets; the 65 536-job batch is ONE resident round "
                                           "of 2048 waves and lasts as long as its slowest denominator class, whose waves run "
                                           "at frac_slowest_class (DESIGN.md 5.2)"})
@@ -312,7 +358,13 @@ def run_config2(args, eng, dev, rank, world, peak):
         "data": "synthetic",
         "config": {"workload": "t=%d,N=%d,batch=%d threshold signatures (combine_signatures, G2), per GPU" % (t, N, B),
                    "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world,
-                   "fast_path": fast},
+                   "fast_path": fast, "steps_in_flight": in_flight,
+                   "steps_in_flight_is": "the K timed steps alternate between this many contexts (one HIP stream each) and are "
+                                         "not synchronised with the host inside the timed region; each is a full pass over "
+                                         "the batch (bench.py --in-flight 1: one context, host waits for every step)"},
+        "sequential": {"value": round(B * world / (seq_dt / seq_steps), 1), "ms_per_step": round(seq_dt / seq_steps * 1e3, 3),
+                       "steps": seq_steps, "is": "the same step on ONE context, the host waiting for each step; the roofline's "
+                                                 "per-launch kernel time is measured here (launches do not overlap)"},
         "pairing_verifies_per_s": round(B * world / verify_dt, 1),
         "pairing_verify_kernel_ms": round(verify_kernel_ms, 3),
         "pairing_verify_valid_count_all_ranks": n_valid,
