@@ -115,7 +115,7 @@ def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traf
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="default: 20 (config 2), 6 (config 5)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=[2, 5])
     ap.add_argument("--batch", type=int, default=None)
@@ -128,6 +128,8 @@ def main():
                          "the host waits for every step")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (configs 3 and 4, PCIe-inclusive rate)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.config == 2 else 6
 
     import numpy as np
     import torch
