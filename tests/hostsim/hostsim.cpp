@@ -53,7 +53,8 @@ int hs_fq_addsub(const uint8_t* a, const uint8_t* b, uint8_t* sum, uint8_t* diff
   return 0;
 }
 // zero test on k*p + delta built as a LAZY value: x - y with x = a + (k+1) p-ish pieces.  Returns
-// bit0 = maybe_zero(), bit1 = is_zero_full(), for value  a - b + k*p  (a, b canonical inputs).
+// bit0 = maybe_zero(), bit1 = is_zero_full(), bit2 = is_zero(), bit3 = maybe_zero56() (the two-limb hint of the
+// branch-free ladder additions), for value  a - b + k*p  (a, b canonical inputs).
 int hs_fq_zero_probe(const uint8_t* a, const uint8_t* b, int k) {
   Fq x, y;
   fq_from_be48(a, false, x);
@@ -64,7 +65,7 @@ int hs_fq_zero_probe(const uint8_t* a, const uint8_t* b, int k) {
     v = (k < 0) ? v - p : v + p;
     if ((i & 3) == 3) v = v.norm();  // keep the lazy limbs inside int32
   }
-  return (v.maybe_zero() ? 1 : 0) | (v.is_zero_full() ? 2 : 0) | (v.is_zero() ? 4 : 0);
+  return (v.maybe_zero() ? 1 : 0) | (v.is_zero_full() ? 2 : 0) | (v.is_zero() ? 4 : 0) | (v.maybe_zero56() ? 8 : 0);
 }
 int hs_fq_legendre(const uint8_t* a) {
   Fq x;

@@ -65,12 +65,13 @@ def test_zero_filter_never_misses_a_zero(L, rnd):
     # 4-instruction filter in front of the full zero test; non-zero values must never be reported zero
     a = rnd.randrange(o.Q)
     for k in list(range(-297, 298, 7)) + [-297, -1, 0, 1, 297]:  # (x - y carries a value bound of 2 itself)
-        assert L.hs_fq_zero_probe(be(a), be(a), k) == 7, k
+        assert L.hs_fq_zero_probe(be(a), be(a), k) == 15, k   # ... and the two-limb hint of the ladder additions (bit 3)
     rejected = 0
     for _ in range(300):
         a, b = rnd.randrange(o.Q), rnd.randrange(o.Q)
         r = L.hs_fq_zero_probe(be(a), be(b), rnd.randrange(-50, 50))
         assert a != b and not (r & 2) and not (r & 4)
+        assert not (r & 8)      # 56 bits: a false alarm has probability ~2^-46
         rejected += not (r & 1)
     assert rejected >= 295  # the filter does its job
 
