@@ -142,9 +142,10 @@ TC_D bool combine_fast(size_t t, const uint64_t* idx, bool live, IO& io, uint8_t
 //                      common denominator (tc_threshold.h lagrange_small_coeffs); leaves other jobs alone.
 //                      Shares and results move through LDS a wave at a time (tc_stage.h): coalesced HBM access
 //                      instead of one strided byte gather per lane.
-//   k_combine_general  everything else (t = 0, 4 <= t < 7, large or repeated indices): Lagrange coefficients
-//                      from k_lagrange + Straus / GLS chunks; leaves at once when *need_general == 0
-//                      (t + 1 >= 8 goes through the two-stage kernels of k_msm.hip instead)
+//   k_combine_general  G1: everything else (t = 0, t >= 4, large or repeated indices): Lagrange coefficients from
+//                      k_lagrange + Straus chunks; leaves at once when *need_general == 0.  G2: t = 0 only -- every other
+//                      general job goes through the two-stage kernels of k_msm.hip, whose private segment is 10 KB
+//                      instead of the 15.6 KB of the chunked psi ladders (concurrent contexts: INTEGRATION.md)
 template <class F>
 __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine_fast(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                     const uint8_t* __restrict__ shares, size_t B,
@@ -215,10 +216,6 @@ void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const u
                        uint8_t* status, bool shared_points) {
   if (B) hipLaunchKernelGGL(k_lincomb<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 96, B, out, status, TableArena{nullptr, nullptr});
 }
-void launch_lincomb_g2(hipStream_t st, TableArena ta, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                       uint8_t* status, bool shared_points) {
-  if (B && ta.mem && ta.flags) hipLaunchKernelGGL(k_lincomb<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, scalars, points, shared_points ? (size_t)0 : n * 192, B, out, status, ta);
-}
 
 void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam,
                      uint8_t* status, uint32_t* need_general) {
@@ -270,7 +267,10 @@ void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job
     }
     hipLaunchKernelGGL(k_combine_fast<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots, ta);
   }
-  hipLaunchKernelGGL(k_combine_general<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, ta);
+  // t >= 1: the jobs the fast path leaves go through the two-stage kernels of k_msm.hip (the caller launches them);
+  // t = 0 (the first sample is the result) is all that is left for the general kernel in G2
+  if (t == 0)
+    hipLaunchKernelGGL(k_combine_general<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, ta);
 }
 
 }  // namespace tc

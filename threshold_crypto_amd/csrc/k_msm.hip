@@ -1,19 +1,27 @@
-// gfx950 kernels: large G2 linear combinations in two stages (tc_msm.h) -- the share combiner of the
-// general path for t + 1 >= 8 samples (BASELINE config "t=67, N=200") and tc_g2_lincomb_batch for n >= 8.
+// gfx950 kernels: G2 linear combinations in two stages (tc_msm.h) -- the share combiner of the general path (every
+// job the small-index fast path does not take; BASELINE config "t=67, N=200") and tc_g2_lincomb_batch.
 #include "tc_msm.h"
 #include "tc_launch.h"
 
 namespace tc {
 
+// which jobs of the batch are this path's: all of them, or (share combination with t <= 3) those the small-index fast
+// path of k_combine_fast leaves alone; *need counts them (k_lagrange) and zero ends the kernel at once
+__device__ __forceinline__ bool msm_job_taken(const MsmFilter& f, size_t j) {
+  return !(f.idx && f.t >= 1 && f.t <= 3 && combine_small_applies(f.idx + j * f.n_per_job, (int)f.t));
+}
+
 // stage T: one lane pair per (job, chunk of 4 shares)
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_tables(size_t n, size_t pts_stride, const uint8_t* __restrict__ points,
                                                                   const uint32_t* __restrict__ scalars, size_t B,
                                                                   int32_t* __restrict__ tbl, uint8_t* __restrict__ codes,
-                                                                  uint8_t* __restrict__ status, int nbits) {
+                                                                  uint8_t* __restrict__ status, int nbits, MsmFilter f) {
+  if (f.need && *f.need == 0) return;
   const size_t chunks = msm_chunks(n);
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (tid >= B * chunks) return;
   const size_t j = tid / chunks, c = tid % chunks;
+  if (!msm_job_taken(f, j)) return;
   const size_t shares4 = chunks * kMsmChunk;
   const bool ok = job_msm_tables(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + j * shares4 * 8 * kMsmEntryWords,
                                  codes + j * kMsmColumns * shares4, pair_leader(), nbits);
@@ -23,9 +31,11 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_tables(size_t n, si
 // stage L: one lane pair per job
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder(size_t n, size_t B, const int32_t* __restrict__ tbl,
                                                                   const uint8_t* __restrict__ codes, uint8_t* __restrict__ out,
-                                                                  const uint8_t* __restrict__ status, int nbits) {
+                                                                  const uint8_t* __restrict__ status, int nbits, MsmFilter f) {
+  if (f.need && *f.need == 0) return;
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
   if (j >= B) return;
+  if (!msm_job_taken(f, j)) return;
   if (status[j] != TC_JOB_OK) {
     g2_encode_uncompressed(G2Affine::infinity(), out + j * 192);
     return;
@@ -41,12 +51,12 @@ size_t msm_code_bytes(size_t n, size_t B) { return B * kMsmColumns * msm_chunks(
 // nbits = 64: any scalars below r.  nbits < 64: odd scalars whose four base-|x| digits are below 2^nbits (a job with
 // another scalar fails): nbits doublings instead of 64.
 void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
-                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits) {
+                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits, MsmFilter f) {
   if (!B || !n) return;
   const size_t lanes = B * msm_chunks(n) * kG2Lanes;
-  hipLaunchKernelGGL(k_msm_tables, dim3(grid_for(lanes)), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status, nbits);
+  hipLaunchKernelGGL(k_msm_tables, dim3(grid_for(lanes)), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status, nbits, f);
   hipLaunchKernelGGL(k_msm_ladder, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                     (const uint8_t*)status, nbits);
+                     (const uint8_t*)status, nbits, f);
 }
 
 }  // namespace tc

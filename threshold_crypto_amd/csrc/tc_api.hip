@@ -211,7 +211,7 @@ bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
 // orders a tile's ladder before the next tile's table stage).
 constexpr size_t kMsmTableBudget = (size_t)24 << 30;
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
-            uint8_t* d_st, int nbits = 64) {
+            uint8_t* d_st, int nbits = 64, tc::MsmFilter filter = tc::MsmFilter()) {
   const size_t per_job = tc::msm_table_bytes(n, 1);
   size_t tile = kMsmTableBudget / (per_job ? per_job : 1);
   if (tile < 1) tile = 1;
@@ -220,8 +220,10 @@ void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const ui
   uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, tile));
   for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
     const size_t cnt = (B - lo < tile) ? B - lo : tile;
+    tc::MsmFilter f = filter;
+    if (f.idx) f.idx += lo * f.n_per_job;
     tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 192,
-                      d_st + lo, nbits);
+                      d_st + lo, nbits, f);
   }
 }
 
@@ -496,8 +498,20 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
     } else if (t > 0) {
       tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
     }
-    if (g2 && t + 1 >= tc::kMsmMinPoints) msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds
-    else if (g2) tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+    if (g2 && t + 1 >= tc::kMsmMinPoints) {
+      msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds: every job, coefficients from the one-inversion kernels
+    } else if (g2) {
+      // t <= 3: small-index fast path first; then (t >= 1) the jobs it left, through the two-stage kernels
+      tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+      if (t >= 1) {
+        tc::MsmFilter f;
+        f.need = d_need;
+        f.idx = d_idx;
+        f.n_per_job = n;
+        f.t = t;
+        msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st, 64, f);
+      }
+    }
     else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st,
                                t + 1 >= tc::kMsmMinPoints ? nullptr : d_need);  // (k_lagrange_all does not count: every job is general)
     k.apply_checks(B, d_st, d_pt, PB, nullptr);
@@ -544,12 +558,16 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
   k.begin_timing();
   k.check_points(g2, d_pt, PB, n, n, B, 1);
   if (!k.failed) {
-    if (g2 && n >= tc::kMsmMinPoints) {
+    if (g2 && n == 0) {
+      // the empty sum: the identity (flag byte 0x40, then zeros) for every job
+      k.check(hipMemsetAsync(d_out, 0, B * PB, ctx->stream), "memset");
+      k.check(hipMemset2DAsync(d_out, PB, 0x40, 1, B, ctx->stream), "memset");
+      if (d_st) k.check(hipMemsetAsync(d_st, 0, B, ctx->stream), "memset");
+    } else if (g2) {
       uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
       if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
       msm_g2(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
-    } else if (g2) tc::launch_lincomb_g2(ctx->stream, k.tables(), n, d_sc, d_pt, B, d_out, d_st);
-    else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
+    } else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
   }
   k.apply_checks(B, d_st, d_out, PB, nullptr);
   k.end_timing();
@@ -707,12 +725,9 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
   std::vector<uint8_t> h_okmsg(B);
   if (!k.failed) {
     tc::launch_rlc_scalars(ctx->stream, d_seed, B * N, d_r);
-    if (N >= 2) {  // (the two-stage kernels' short-scalar mode: 16 doublings for the 64-bit random scalars)
-      k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
-      msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16);  // short scalars
-    } else {
-      tc::launch_lincomb_g2(ctx->stream, k.tables(), N, d_r, d_sig, B, d_S, d_stS);
-    }
+    // (the two-stage kernels' short-scalar mode: 16 doublings for the 64-bit random scalars)
+    k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
+    msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16);
     tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     // e(P, [c] Q') == e(g1, S)  <=>  e(P, Q') == e([1/c] g1, S)   (the folded hash constant of tc_verify_sig_batch)

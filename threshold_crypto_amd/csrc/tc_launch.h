@@ -50,8 +50,6 @@ void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job
 // shared_points: every job combines the SAME n points (points holds n of them) with its own n scalars
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status, bool shared_points = false);
-void launch_lincomb_g2(hipStream_t st, TableArena ta, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                       uint8_t* status, bool shared_points = false);
 // random-linear-combination share validation (k_check.hip): 64-bit scalars from a ChaCha20 stream keyed
 // by the caller's seed; row gather / byte scatter for the per-share fallback of failed messages
 void launch_rlc_scalars(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr);
@@ -61,11 +59,18 @@ void launch_scatter_bytes(hipStream_t st, const uint8_t* src, const uint32_t* ma
 // large G2 linear combinations in two stages (k_msm.hip): per-share affine psi tables + digit codes in HBM
 // (tbl: msm_table_bytes, codes: msm_code_bytes), then one 64-step ladder per job.  status: B bytes, jobs with
 // status != TC_JOB_OK are skipped (identity out); undecodable operands set TC_JOB_INVALID_ENCODING.
-constexpr size_t kMsmMinPoints = 8;
+constexpr size_t kMsmMinPoints = 8;  // from here on the Lagrange coefficients come from the one-inversion kernels
+// jobs of a share combination that belong to the two-stage path: all of them (null members), or the ones the
+// small-index fast path leaves alone -- need: the count k_lagrange made of them (zero: the kernels leave at once)
+struct MsmFilter {
+  const uint32_t* need = nullptr;
+  const uint64_t* idx = nullptr;
+  size_t n_per_job = 0, t = 0;
+};
 size_t msm_table_bytes(size_t n, size_t B);
 size_t msm_code_bytes(size_t n, size_t B);
 void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
-                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits = 64);
+                   int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits = 64, MsmFilter f = MsmFilter());
 
 // opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
 // records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an
