@@ -106,6 +106,7 @@ void hs_fr_inverse_of_small(uint64_t d_abs, int d_neg, uint8_t* out32le) {
   memcpy(out32le, w, 32);
 }
 static int hs_combine_g2_large(int t, const uint64_t* idx, const uint8_t* shares, uint32_t* lam, uint8_t* out);
+int hs_msm_g2(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out192);
 static int g_force_general = 0;
 void hs_force_general_combine(int on) { g_force_general = on; }
 static int combine(int g2, int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) {
@@ -132,7 +133,9 @@ static int combine(int g2, int t, const uint64_t* idx, const uint8_t* shares, ui
     int st = job_lagrange(idx, t, i, lam + 8 * i);
     if (st) return st;
   }
-  return g2 ? job_combine<Fq2>(t, shares, lam, out) : job_combine<Fq>(t, shares, lam, out);
+  // G2, t >= 1: the general jobs go through the two-stage kernels (tc_api.hip combine()); t = 0: the first sample
+  if (g2) return t >= 1 ? hs_msm_g2((size_t)t + 1, shares, lam, out) : job_first_sample<Fq2>(shares, out);
+  return job_combine<Fq>(t, shares, lam, out);
 }
 int hs_combine_g2(int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) { return combine(1, t, idx, shares, out); }
 int hs_combine_g1(int t, const uint64_t* idx, const uint8_t* shares, uint8_t* out) { return combine(0, t, idx, shares, out); }

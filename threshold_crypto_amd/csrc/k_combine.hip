@@ -186,7 +186,9 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
     if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
       PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
     } else {
-      const uint8_t st = job_combine<F>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
+      // G2: only t = 0 reaches this kernel (launch_combine_g2)
+      const uint8_t st = (L > 1) ? job_first_sample<F>(shares + j * n_per_job * PB, out + j * PB)
+                                 : job_combine<Fq>((int)t, shares + j * n_per_job * PB, lam + j * (t + 1) * 8, out + j * PB);
       if (status && (L == 1 || pair_leader())) status[j] = st;
     }
   }

@@ -339,18 +339,21 @@ TC_HD bool combine_small_applies(const uint64_t* idx, int t) {
 
 // out = sum_{i <= t} lambda_i * share_i over the FIRST t+1 samples of the job
 // (interpolate, src/lib.rs:719-767).  lam: (t+1) x 8 canonical words from job_lagrange.
+// t == 0: the first sample is returned unchanged (src/lib.rs:735-737) -- decoded and encoded again, so a bad encoding fails
+template <class F>
+TC_HD uint8_t job_first_sample(const uint8_t* shares, uint8_t* out) {
+  Affine<F> p;
+  if (!PointIO<F>::decode(shares, p)) {
+    PointIO<F>::encode(Affine<F>::infinity(), out);
+    return TC_JOB_INVALID_ENCODING;
+  }
+  PointIO<F>::encode(p, out);
+  return TC_JOB_OK;
+}
+// (G1; the G2 general jobs with t >= 1 run through the two-stage kernels of k_msm.hip)
 template <class F>
 TC_HD uint8_t job_combine(int t, const uint8_t* shares, const uint32_t* lam, uint8_t* out) {
-  if (t == 0) {
-    // t == 0: the first sample is returned unchanged (src/lib.rs:735-737)
-    Affine<F> p;
-    if (!PointIO<F>::decode(shares, p)) {
-      PointIO<F>::encode(Affine<F>::infinity(), out);
-      return TC_JOB_INVALID_ENCODING;
-    }
-    PointIO<F>::encode(p, out);
-    return TC_JOB_OK;
-  }
+  if (t == 0) return job_first_sample<F>(shares, out);
   return job_lincomb<F>(t + 1, shares, lam, out);
 }
 

@@ -7,10 +7,9 @@
 //   stage L  one lane pair per job: ONE chain of 64 doublings for all t+1 shares; per column and share one
 //            table look-up (a single coalesced 64-byte row per coordinate and lane) and one MIXED addition.
 //
-// Per share that is 64 mixed additions + 7 table additions + 1/4 inversion, against 64 + 7 + 16 doublings + the
-// chunk sums for the 4-share ladders of tc_threshold.h straus_chunk_gls4 (whose tables live in per-lane
-// scratch and share one Z only inside a chunk).  Same group element, same bytes as interpolate's
-// sum_i lambda_i S_i (/root/reference/src/lib.rs:764).
+// Per share that is 64 mixed additions + 7 table additions + 1/4 inversion (a chunked ladder with its tables in per-lane
+// scratch -- the form this replaced for every G2 combination -- needs 16 more doublings per share and 15.6 KB of private
+// segment per lane).  Same group element, same bytes as interpolate's sum_i lambda_i S_i (/root/reference/src/lib.rs:764).
 #pragma once
 #include "tc_jobs.h"
 

@@ -191,79 +191,8 @@ TC_HD Jac<F> straus_chunk(const Affine<F>* pts, const uint32_t (*sc)[8]) {
   return acc;
 }
 
-// The same sum for FOUR G2 points with every scalar split into base-|x| digits (tc_gls.h): each
-// point brings its own 8-entry sign-aligned table of psi-images, the 4 x 7 proper sums share ONE
-// common Z, and ONE chain of 64 doublings serves all sixteen 64-bit digits: per point 64 mixed
-// additions + 16 doublings instead of the 64 + 64 of the 255-bit Straus ladder above.
-// An even scalar runs as r - k on the negated point (gls_decompose_odd), so first digits are odd.
-TC_HD_NOINLINE G2Jac straus_gls4_ladder_safe(const G2Affine* tbl, const SacDigits* sd) {
-  G2Jac acc = G2Jac::infinity();
-  TC_NOUNROLL for (int k = 0; k < 4; k++) acc = jac_add_mixed(acc, tbl[8 * k + sd[k].top]);
-  TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
-    acc = jac_dbl(acc);
-    TC_NOUNROLL for (int k = 0; k < 4; k++) {
-      const uint32_t m = (uint32_t)((sd[k].u[0] >> bit) & 1) | ((uint32_t)((sd[k].u[1] >> bit) & 1) << 1) |
-                         ((uint32_t)((sd[k].u[2] >> bit) & 1) << 2);
-      G2Affine e = tbl[8 * k + m];
-      e.y = Fq2::select((sd[k].neg >> bit) & 1, -e.y, e.y);
-      acc = jac_add_mixed(acc, e);
-    }
-  }
-  return acc;
-}
-TC_HD G2Jac straus_chunk_gls4(const G2Affine* pts, const uint32_t (*sc)[8]) {
-  G2Affine tbl[32];  // entries 8k .. 8k+7 belong to point k
-  SacDigits sd[4];
-  Fq2 zc;
-  {
-    G2Jac sums[28];
-    G2Affine sums_aff[28];
-    G2Affine b0[4];
-    TC_NOUNROLL for (int k = 0; k < 4; k++) {
-      uint64_t d[4];
-      const bool flip = gls_decompose_odd(sc[k], d);
-      sd[k] = sac_recode4(d);
-      G2Affine base[4];
-      g2_gls_bases(pts[k], base);
-      TC_NOUNROLL for (int j = 0; j < 4; j++) base[j].y = Fq2::select(flip, -base[j].y, base[j].y).norm();
-      b0[k] = base[0];
-      TC_NOUNROLL for (int m = 1; m < 8; m++) {
-        const int low = __builtin_ctz((unsigned)m);
-        const int rest = m & (m - 1);
-        sums[7 * k + m - 1] = rest ? jac_add_mixed(sums[7 * k + rest - 1], base[low + 1]) : jac_add_affine(base[0], base[low + 1]);
-      }
-    }
-    zc = jac_batch_to_common_z<Fq2, 28>(sums, sums_aff, 28);
-    const Fq2 zc2 = zc.sqr();
-    const Fq2 zc3 = zc2 * zc;
-    TC_NOUNROLL for (int k = 0; k < 4; k++) {
-      tbl[8 * k] = affine_scale_z(b0[k], zc2, zc3);
-      TC_NOUNROLL for (int m = 1; m < 8; m++) tbl[8 * k + m] = sums_aff[7 * k + m - 1];
-    }
-  }
-  // generic-case additions (tc_curve.h jac_add_mixed_generic); a lane that may have met a special case redoes the
-  // ladder below with jac_add_mixed
-  G2Jac acc = G2Jac::from_affine(tbl[sd[0].top]);  // column 64: all positive
-  bool exc = tbl[sd[0].top].inf;
-  TC_NOUNROLL for (int k = 1; k < 4; k++) acc = jac_add_mixed_generic(acc, tbl[8 * k + sd[k].top], exc);
-  TC_NOUNROLL for (int bit = 63; bit >= 0; bit--) {
-    tc_fair();
-    acc = jac_dbl(acc);
-    TC_NOUNROLL for (int k = 0; k < 4; k++) {
-      const uint32_t m = (uint32_t)((sd[k].u[0] >> bit) & 1) | ((uint32_t)((sd[k].u[1] >> bit) & 1) << 1) |
-                         ((uint32_t)((sd[k].u[2] >> bit) & 1) << 2);
-      G2Affine e = tbl[8 * k + m];
-      e.y = Fq2::select((sd[k].neg >> bit) & 1, -e.y, e.y);
-      acc = jac_add_mixed_generic(acc, e, exc);
-    }
-  }
-  if (wave_any(exc)) acc = G2Jac::select(exc, straus_gls4_ladder_safe(tbl, sd), acc);
-  acc.z = coord_norm(acc.z * zc);
-  return acc;
-}
-// chunk of a linear combination: G1 through the subset-sum ladder, G2 through the psi digits
+// chunk of a G1 linear combination (G2 combinations run through tc_msm.h: per-share psi tables in HBM, one ladder)
 TC_HD G1Jac lincomb_chunk4(const G1Affine* pts, const uint32_t (*sc)[8]) { return straus_chunk<Fq, 4>(pts, sc); }
-TC_HD G2Jac lincomb_chunk4(const G2Affine* pts, const uint32_t (*sc)[8]) { return straus_chunk_gls4(pts, sc); }
 
 // ---- small-index fast path ------------------------------------------------------------------
 // Share indices are node numbers, so the abscissae x_i = idx_i + 1 are small integers and the
