@@ -57,6 +57,12 @@ if _rem:
 else:
     _part = tuple(0 for _ in _full)
 res["g2_mul_gather_68_signers"] = (tuple(((68 // _g) * a + b) // 68 for a, b in zip(_full, _part)), 2)
+# the same 68 shares through the per-message comb (k_comb_tables + k_comb_sign: what n >= 24 signers run)
+_sk68 = b"".join(o.fr_to_bytes(rnd.randrange(o.R)) for _ in range(68))
+_idx68 = (ctypes.c_uint64 * 68)(*range(68))
+cnt()
+L.hs_comb_sign(_sk68, 68, _idx68, 68, o.g2_uncompressed(P2), buf(192 * 68), buf(68))
+res["g2_sign_comb_68_signers"] = (tuple(x // 68 for x in cnt()), 2)
 poly = [rnd.randrange(o.R) for _ in range(4)]
 shares_g2 = {i: o.g2_uncompressed(o.E2.mul(P2, o.secret_key_share(poly, i))) for i in range(10)}
 shares_g1 = {i: o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly, i))) for i in range(10)}

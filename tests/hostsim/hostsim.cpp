@@ -4,6 +4,7 @@
 #include "tc_jobs.h"
 #include "tc_dkg.h"
 #include "tc_msm.h"
+#include "tc_comb.h"
 #include <vector>
 #include <string.h>
 using namespace tc;
@@ -94,6 +95,15 @@ void hs_g2_mul_gather(const uint8_t* sk, size_t N, const uint64_t* idx, int n, c
   job_g2_mul_gather(sk, N, idx, n, pt, out, status, true);
 }
 int hs_gather_share() { return kGatherShare; }
+// the same shares through the per-message comb (tc_comb.h): stage T once, stage S in chunks of kCombShare signers
+void hs_comb_sign(const uint8_t* sk, size_t N, const uint64_t* idx, int n, const uint8_t* pt, uint8_t* out, uint8_t* status) {
+  std::vector<int32_t> tbl(kCombTableWords);
+  const bool ok = job_comb_tables(pt, (tbl_word*)tbl.data());
+  for (int s0 = 0; s0 < n; s0 += kCombShare) {
+    const int cnt = (n - s0 < kCombShare) ? n - s0 : kCombShare;
+    job_comb_sign(sk, N, idx + s0, cnt, (const tbl_word*)tbl.data(), ok, out + (size_t)s0 * 192, status + s0, true);
+  }
+}
 int hs_lagrange(const uint64_t* idx, int t, int i, uint8_t* out32le) {
   uint32_t w[8];
   int st = job_lagrange(idx, t, i, w);

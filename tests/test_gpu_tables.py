@@ -153,3 +153,37 @@ def test_ladder_special_cases_take_the_safe_path(engine, wl):
     assert not st.any()
     # sum_i lambda_i = 1: interpolating the constant polynomial gives the point back
     assert bytes(got[0]) == o.g2_uncompressed(P) and bytes(got[1]) == o.g2_uncompressed(Q)
+
+
+def test_comb_signing_many_signers_vs_oracle(engine, wl):
+    """tc_sign_shares_g2_batch with n >= 24 signers per message runs through the per-message comb (csrc/tc_comb.h):
+    every share of a few messages against Oracle B, plus a bad signer index, an identity point and an undecodable point."""
+    c.load()
+    rng = random.Random(31)
+    N, n, B = 40, 30, 96
+    sk = np.stack([u8(rng.getrandbits(250).to_bytes(32, "little")) for _ in range(N)])
+    sk[0] = u8((1).to_bytes(32, "little"))
+    sk[1] = u8((2).to_bytes(32, "little"))
+    idx = np.stack([np.array(sorted(rng.sample(range(N), n)), dtype=np.uint64) for _ in range(B)])
+    idx[3, 0], idx[3, 1] = 0, 1                      # tiny scalars: the guarded fallback ladder
+    idx[4, 7] = N + 9                                # out of range: fails its own share only
+    pts = np.ascontiguousarray(wl.hashes[:B]).copy()
+    inf = np.zeros(192, dtype=np.uint8)
+    inf[0] = 0x40
+    pts[5] = inf
+    pts[6, 100] ^= 1                                 # not on the curve any more
+    out, st = engine.sign_shares_g2(sk, idx, pts)
+    assert st.shape == (B, n) and out.shape == (B, n, 192)
+    for j in (0, 1, 2, 3, 4, 5, 95):
+        for s in range(n):
+            if j == 4 and s == 7:
+                assert st[j, s] == 3 and bytes(out[j, s]) == bytes(inf)
+                continue
+            assert st[j, s] == 0, (j, s)
+            assert bytes(out[j, s]) == oracle_mul(sk[int(idx[j, s])], pts[j]), (j, s)
+    assert (st[6] == 3).all() and all(bytes(out[6, s]) == bytes(inf) for s in range(n))
+    assert not st[7:].any()
+    # the comb and the per-chunk ladders agree on a whole batch: n = 23 (ladders) and n = 24 (comb) share 23 signers
+    out23, st23 = engine.sign_shares_g2(sk, np.ascontiguousarray(idx[:, :23]), pts)
+    out24, st24 = engine.sign_shares_g2(sk, np.ascontiguousarray(idx[:, :24]), pts)
+    assert (out24[:, :23] == out23).all() and (st24[:, :23] == st23).all()

@@ -160,6 +160,30 @@ def test_point_mul(L, rnd):
     assert L.hs_g2_mul(o.fr_to_bytes(5), bytes(bad), out) == 3
 
 
+def test_comb_signing_equals_per_scalar_ladders(L, rnd):
+    """Many signers of one message (csrc/tc_comb.h): a comb of the message's psi table (affine doublings, shared
+    inversions), then 65 doubling-free additions per signer -- byte-identical to the per-scalar multiplications of the
+    oracle, for random and edge scalars (1, 2, r-1: the guarded fallback ladder), a bad signer index, an identity and
+    an undecodable point."""
+    Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    ks = [1, 2, 3, o.R - 1, o.R - 2, 0xd201000000010000, (1 << 64), 0] + [rnd.randrange(o.R) for _ in range(11)]
+    N = len(ks)
+    sk = b"".join(o.fr_to_bytes(k) for k in ks)
+    ids = list(range(N)) + [N + 5]            # the last index is out of range: fails its own share only
+    idx = (ctypes.c_uint64 * len(ids))(*ids)
+    out, st = buf(192 * len(ids)), buf(len(ids))
+    L.hs_comb_sign(sk, N, idx, len(ids), o.g2_uncompressed(Q2), out, st)
+    for s, k in enumerate(ks):
+        assert st.raw[s] == 0 and out.raw[192 * s:192 * s + 192] == o.g2_uncompressed(o.E2.mul(Q2, k)), (s, hex(k))
+    assert st.raw[N] == 3 and out.raw[192 * N:192 * N + 192] == o.g2_uncompressed(None)
+    # identity point: every share is the identity; undecodable point: every share fails
+    L.hs_comb_sign(sk, N, idx, 4, o.g2_uncompressed(None), out, st)
+    assert st.raw[:4] == bytes(4) and out.raw[:192 * 4] == o.g2_uncompressed(None) * 4
+    bad = bytearray(o.g2_uncompressed(Q2)); bad[100] ^= 1
+    L.hs_comb_sign(sk, N, idx, 4, bytes(bad), out, st)
+    assert st.raw[:4] == bytes([3]) * 4 and out.raw[:192 * 4] == o.g2_uncompressed(None) * 4
+
+
 def test_gls_digits_by_reciprocal_division(L, rnd):
     """k = d0 + d1 |x| + d2 |x|^2 + d3 |x|^3 (csrc/tc_gls.h gls_decompose: 2-by-1 divisions through the reciprocal of
     |x|) against Python's divmod -- random scalars and the values around every correction branch of the division."""

@@ -22,7 +22,7 @@ BUILD = os.path.join(HERE, "_build")
 EXTRA_FLAGS = os.environ.get("TC_BUILD_FLAGS", "").split()
 SUFFIX = os.environ.get("TC_BUILD_SUFFIX", "")
 LIB = os.path.join(HERE, "libtc_amd%s.so" % SUFFIX)
-UNITS = ["tc_api", "tc_group", "k_mul", "k_combine", "k_pairing", "k_hash", "k_check", "k_dkg", "k_msm"]
+UNITS = ["tc_api", "tc_group", "k_mul", "k_combine", "k_pairing", "k_hash", "k_check", "k_dkg", "k_msm", "k_comb"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-Wno-unused-result"] + EXTRA_FLAGS
 

@@ -407,7 +407,24 @@ int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, cons
   uint8_t* d_st = k.out(status, B * n);
   k.begin_timing();
   k.check_points(true, d_h, 192, 1, 1, B, n);
-  if (!k.failed) tc::launch_g2_mul_gather(ctx->stream, k.tables(), d_sk, N, d_idx, d_h, n, B, d_out, d_st);
+  if (!k.failed && n >= tc::kCombMinSigners) {
+    // many signers per message: the doublings are done once per message, on a comb of its table (k_comb.hip); the combs
+    // (133 KB per message) live in one HBM buffer, messages run through it in tiles
+    const size_t per_msg = tc::comb_table_bytes(1);
+    size_t tile = kMsmTableBudget / per_msg;
+    if (tile < 1) tile = 1;
+    if (tile > B) tile = B;
+    int32_t* d_tbl = k.temp<int32_t>(tc::comb_table_bytes(tile) / sizeof(int32_t));
+    uint8_t* d_ok = k.temp<uint8_t>(tile);
+    const tc::TableArena ta = k.tables();
+    for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
+      const size_t cnt = (B - lo < tile) ? B - lo : tile;
+      tc::launch_comb_sign(ctx->stream, ta, d_sk, N, d_idx + lo * n, d_h + lo * 192, n, cnt, d_tbl, d_ok, d_out + lo * n * 192,
+                           d_st ? d_st + lo * n : nullptr);
+    }
+  } else if (!k.failed) {
+    tc::launch_g2_mul_gather(ctx->stream, k.tables(), d_sk, N, d_idx, d_h, n, B, d_out, d_st);
+  }
   k.apply_checks(B * n, d_st, d_out, 192, nullptr);
   k.end_timing();
   return k.finish();

@@ -28,6 +28,12 @@ void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8
 // out[j*n + k] = sk[idx[j*n + k]] * pts[j]: the shares of message j by its n selected signers out of N
 void launch_g2_mul_gather(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
                           uint8_t* out, uint8_t* status);
+// many signers per message (n >= kCombMinSigners): a per-message comb in HBM (tbl: comb_table_bytes(B), ok: B bytes), then
+// doubling-free multiplications (k_comb.hip)
+constexpr size_t kCombMinSigners = 24;
+size_t comb_table_bytes(size_t B);
+void launch_comb_sign(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
+                      int32_t* tbl, uint8_t* ok, uint8_t* out, uint8_t* status);
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
