@@ -375,7 +375,8 @@ def run_config2(args, eng, dev, rank, world, peak):
     legs["pairing_check"] = roofline("k_pairing_check", "verify_g2", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
                                      traffic_key="pairing_check")
     legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak)
-    cpu = None if args.no_cpu_baseline else cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
+    # the CPU leg runs on rank 0 of a one-GPU run only (N ranks would time N oracles against each other on one host)
+    cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
     return {
         "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

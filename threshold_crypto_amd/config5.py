@@ -162,7 +162,7 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
                                "g2_sign_comb_68_signers" if t + 1 >= 24 else "g2_mul_gather_68_signers", "g2_mul", "g2_mul", t, (t + 1) * B, float(ms[0]), peak),
         "pairing_check": roofline("k_pairing_check", "verify_g2", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
     }
-    cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline) else None
+    cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline and world == 1) else None
     return {
         "metric": "threshold signatures (sign t+1 shares + combine + verify)/sec", "value": round(B * world / step_s, 1),
         "unit": "threshold_signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
