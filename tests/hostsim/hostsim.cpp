@@ -321,7 +321,7 @@ int hs_lagrange_split(const uint64_t* idx, int t, uint32_t* out) {  // k_lagrang
     for (int w = 0; w < 8; w++) xm[i * 8 + w] = x.v.l[w];
   }
   for (int i = 0; i < n; i++) {
-    const Fr d = lagrange_denominator((const uint32_t*)xm.data(), idx, n, i);
+    const Fr d = lagrange_denominator(idx, n, i);
     for (int w = 0; w < 8; w++) den[i * 8 + w] = d.v.l[w];
   }
   return lagrange_finish(n, xm.data(), den.data(), pre.data(), out);

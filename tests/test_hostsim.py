@@ -659,7 +659,8 @@ def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
     """tc_threshold.h lagrange_all_at_zero == the reference's per-coefficient construction (src/lib.rs:739-763),
     including repeated indices (filtered by VALUE out of the denominator, :758) and u64 edge values."""
     cases = [sorted(rnd.sample(range(200), 68)), [5, 9, 5, 7, 9, 11, 2, 40, 41], [0, 2 ** 64 - 1, 2 ** 63, 1, 3, 9, 27, 81, 243],
-             list(range(10))]
+             list(range(10)), [rnd.getrandbits(64) for _ in range(30)], [rnd.getrandbits(33) for _ in range(21)] + [7, 7, 2 ** 64 - 2],
+             [rnd.randrange(70000) for _ in range(90)]]
     for ids in cases:
         t = len(ids) - 1
         out = (ctypes.c_uint32 * (8 * (t + 1)))()

@@ -25,32 +25,24 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t
 
 // Large thresholds (no job takes the small-index fast path): all t+1 coefficients of a job with ONE inversion
 // (tc_threshold.h), in two kernels.
-//   k_lagrange_den     one lane per (job, i): the O(t^2) part.  A 256-lane workgroup takes floor(256 / (t+1)) jobs;
-//                      their abscissae x_i = idx_i + 1 go to LDS in Montgomery form (one conversion per lane, every
-//                      lane then reads all t+1 of its job: broadcast reads, no bank conflicts), the denominators
-//                      and the abscissae to HBM for the second kernel.
+//   k_lagrange_den     one lane per (job, i): the O(t^2) part.  A 256-lane workgroup takes floor(256 / (t+1)) jobs; the
+//                      denominators (integer chunk products, tc_threshold.h) and the abscissae x_i = idx_i + 1 in
+//                      Montgomery form go to HBM for the second kernel.
 //   k_lagrange_finish  one lane per job: prefix products, the inversion, lambda_i.
 constexpr int kLagBlock = 256;
 constexpr int kLagMaxN = 256;  // t + 1 above this falls back to one lane per job (k_lagrange_all)
 __global__ __launch_bounds__(kLagBlock) void k_lagrange_den(const uint64_t* __restrict__ idx, size_t n_per_job, size_t t, size_t B,
                                                           uint32_t* __restrict__ xm, uint32_t* __restrict__ den) {
-  __shared__ uint32_t xs[kLagMaxN * 8];
   const int n = (int)t + 1;
   const int jobs_per_block = kLagBlock / n;
   const int jl = (int)threadIdx.x / n, i = (int)threadIdx.x % n;
   const size_t j = (size_t)blockIdx.x * jobs_per_block + jl;
-  const bool live = jl < jobs_per_block && j < B;
-  if (live) {
-    const Fr x = fr_from_u64(idx[j * n_per_job + i]) + Fr::one();
-    TC_UNROLL for (int w = 0; w < 8; w++) {
-      xs[(jl * n + i) * 8 + w] = x.v.l[w];
-      xm[(j * n + i) * 8 + w] = x.v.l[w];
-    }
-  }
-  __syncthreads();
-  if (live) {
-    const Fr d = lagrange_denominator((const uint32_t*)(xs + jl * n * 8), idx + j * n_per_job, n, i);
-    TC_UNROLL for (int w = 0; w < 8; w++) den[(j * n + i) * 8 + w] = d.v.l[w];
+  if (jl >= jobs_per_block || j >= B) return;
+  const Fr x = fr_from_u64(idx[j * n_per_job + i]) + Fr::one();
+  const Fr d = lagrange_denominator(idx + j * n_per_job, n, i);
+  TC_UNROLL for (int w = 0; w < 8; w++) {
+    xm[(j * n + i) * 8 + w] = x.v.l[w];
+    den[(j * n + i) * 8 + w] = d.v.l[w];
   }
 }
 __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange_finish(size_t t, size_t B, const uint32_t* __restrict__ xm,

@@ -33,6 +33,7 @@ TC_HD bool lagrange_coeff_at_zero(const uint64_t* idx, int t, int i, Fr& out) {
 // ws: 4 (t+1) x 8 words of scratch (x, denominators, their prefix products, prefix products of x), Montgomery form.
 // out: (t+1) x 8 canonical words.  Equal abscissae are filtered BY VALUE (src/lib.rs:758), so a denominator is
 // never zero and DuplicateEntry stays unreachable, as in the reference.
+TC_HD Fr lagrange_denominator(const uint64_t* idx, int n, int i);  // below
 TC_HD uint8_t lagrange_all_at_zero(const uint64_t* idx, int t, uint32_t* out, uint32_t* ws) {
   const int n = t + 1;
   uint32_t* xm = ws;
@@ -51,12 +52,7 @@ TC_HD uint8_t lagrange_all_at_zero(const uint64_t* idx, int t, uint32_t* out, ui
   }
   Fr accd = one;
   TC_NOUNROLL for (int i = 0; i < n; i++) {
-    const Fr xi = get(xm + (size_t)i * 8);
-    const uint64_t vi = idx[i];
-    Fr d = one;
-    TC_NOUNROLL for (int j = 0; j < n; j++) {
-      if (idx[j] != vi) d = d * (get(xm + (size_t)j * 8) - xi);  // x_j != x_i  <=>  idx_j != idx_i  (u64 + 1 is injective mod r)
-    }
+    const Fr d = lagrange_denominator(idx, n, i);  // x_j != x_i  <=>  idx_j != idx_i  (u64 + 1 is injective mod r)
     put(den + (size_t)i * 8, d);
     put(pre + (size_t)i * 8, accd);  // prod_{k < i} den_k
     accd = accd * d;
@@ -80,17 +76,33 @@ TC_HD uint8_t lagrange_all_at_zero(const uint64_t* idx, int t, uint32_t* out, ui
 // The same computation split for the device (k_combine.hip k_lagrange_den / k_lagrange_finish): the O(t^2)
 // denominators are one lane per (job, i) with the job's abscissae staged in LDS; the prefix products, the single
 // inversion and the coefficients are one lane per job.
-//   den_i = prod_{j : idx_j != idx_i} (x_j - x_i), x in Montgomery form (xs: n x 8 words, any address space)
-template <class XS>
-TC_HD Fr lagrange_denominator(XS xs, const uint64_t* idx, int n, int i) {
-  auto get = [&](int k) { Fr v; TC_UNROLL for (int w = 0; w < 8; w++) v.v.l[w] = xs[k * 8 + w]; return v; };
-  const Fr xi = get(i);
+//   den_i = prod_{j : idx_j != idx_i} (x_j - x_i)  in Montgomery form.
+// x_j - x_i = idx_j - idx_i as INTEGERS (the + 1 of into_fr_plus_1 cancels; |difference| < 2^64), so the product is
+// gathered in 64-bit chunks -- eight factors below 2^8 at N = 200 -- and only a full chunk costs field multiplications
+// (its conversion and the product: 2 instead of 8); the sign is applied at the end.  A chunk is closed for the whole
+// wave as soon as one lane's would overflow, so the lanes keep one control flow.
+TC_HD Fr lagrange_denominator(const uint64_t* idx, int n, int i) {
   const uint64_t vi = idx[i];
   Fr d = Fr::one();
+  uint64_t chunk = 1;
+  bool neg = false;
   TC_NOUNROLL for (int j = 0; j < n; j++) {
-    if (idx[j] != vi) d = d * (get(j) - xi);
+    const uint64_t vj = idx[j];
+    const bool lt = vj < vi;
+    const uint64_t diff = lt ? vi - vj : vj - vi;
+    const uint64_t m = diff ? diff : 1;  // equal abscissae are filtered by value (src/lib.rs:758): factor 1
+    neg = neg != (lt && diff != 0);
+    // bits(chunk) + bits(m) <= 64  =>  chunk * m < 2^64
+    const bool full = __builtin_clzll(chunk) + __builtin_clzll(m) < 64;
+    if (wave_any(full)) {
+      d = d * fr_from_u64(chunk);
+      chunk = m;
+    } else {
+      chunk *= m;
+    }
   }
-  return d;
+  d = d * fr_from_u64(chunk);
+  return neg ? Fr::zero() - d : d;
 }
 //   xm, den: n x 8 words (Montgomery) as written by the denominator stage; pre: n x 8 words of scratch
 TC_HD uint8_t lagrange_finish(int n, const uint32_t* xm, const uint32_t* den, uint32_t* pre, uint32_t* out) {
