@@ -312,6 +312,25 @@ int hs_msm_g2_nbits(size_t n, const uint8_t* points, const uint32_t* scalars, ui
   g2_encode_uncompressed(jac_to_affine(job_msm_ladder(n, tbl.data(), codes.data(), nbits)), out192);
   return TC_JOB_OK;
 }
+// stage L split over `parts` lane pairs (k_msm_ladder_split): the parts one after the other, then the same
+// butterfly of additions the lane pairs of a wave run
+int hs_msm_g2_split(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out192, size_t parts) {
+  const size_t chunks = msm_chunks(n), shares4 = chunks * kMsmChunk;
+  std::vector<int32_t> tbl(shares4 * 8 * kMsmEntryWords);
+  std::vector<uint8_t> codes(kMsmColumns * shares4);
+  bool ok = true;
+  for (size_t c = 0; c < chunks; c++) ok &= job_msm_tables(n, c, points, scalars, tbl.data(), codes.data(), true, 64);
+  if (!ok) return TC_JOB_INVALID_ENCODING;
+  std::vector<G2Jac> r(parts);
+  for (size_t g = 0; g < parts; g++) r[g] = job_msm_ladder_part<true>(n, tbl.data(), codes.data(), 64, msm_part(n, g, parts));
+  for (size_t d = 1; d < parts; d <<= 1) {
+    std::vector<G2Jac> nx(parts);
+    for (size_t g = 0; g < parts; g++) nx[g] = jac_add(r[g], r[g ^ d]);
+    r = nx;
+  }
+  g2_encode_uncompressed(jac_to_affine(r[0]), out192);
+  return TC_JOB_OK;
+}
 
 int hs_lagrange_split(const uint64_t* idx, int t, uint32_t* out) {  // k_lagrange_den + k_lagrange_finish, lane by lane
   const int n = t + 1;

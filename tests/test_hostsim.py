@@ -650,6 +650,12 @@ def test_two_stage_msm_matches_oracle(L, rnd):
         out = buf(192)
         assert L.hs_msm_g2(n, b"".join(o.g2_uncompressed(p) for p in pts), words, out) == 0
         assert out.raw == o.g2_uncompressed(want), n
+        # stage L split over several lane pairs (small batches): ranges of shares, masked last look-up, partial sums added
+        L.hs_msm_g2_split.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        for parts in (2, 4, 8):
+            out = buf(192)
+            assert L.hs_msm_g2_split(n, b"".join(o.g2_uncompressed(p) for p in pts), words, out, parts) == 0
+            assert out.raw == o.g2_uncompressed(want), (n, parts)
     bad = bytearray(b"".join(o.g2_uncompressed(p) for p in pts))
     bad[192 * 5 + 100] ^= 1
     assert L.hs_msm_g2(n, bytes(bad), words, buf(192)) == 3

@@ -44,6 +44,36 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder(size_t n, si
   const G2Jac r = job_msm_ladder(n, tbl + j * shares4 * 8 * kMsmEntryWords, codes + j * kMsmColumns * shares4, nbits);
   g2_encode_uncompressed(jac_to_affine(r), out + j * 192);
 }
+// stage L for batches that would not fill the GPU with one lane pair per job: `parts` (a power of two, 2 .. 32) lane
+// pairs per job, each over a range of the job's shares (tc_msm.h msm_part); the partial sums are added across the lane
+// pairs of the job (they sit in one wave) in log2(parts) rounds, the first one writes the result.
+__device__ __forceinline__ Fq2 msm_from_partner(const Fq2& v, int lanes) {
+  Fq2 r = v;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = __shfl_xor(v.m.l[i], lanes, 64);
+  return r;
+}
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder_split(size_t n, size_t B, const int32_t* __restrict__ tbl,
+                                                                        const uint8_t* __restrict__ codes, uint8_t* __restrict__ out,
+                                                                        const uint8_t* __restrict__ status, int nbits, MsmFilter f,
+                                                                        size_t parts) {
+  if (f.need && *f.need == 0) return;
+  const size_t lp = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const size_t j = lp / parts, g = lp % parts;
+  if (j >= B) return;
+  if (!msm_job_taken(f, j)) return;
+  if (status[j] != TC_JOB_OK) {
+    if (g == 0) g2_encode_uncompressed(G2Affine::infinity(), out + j * 192);
+    return;
+  }
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  G2Jac r = job_msm_ladder_part<true>(n, tbl + j * shares4 * 8 * kMsmEntryWords, codes + j * kMsmColumns * shares4, nbits, msm_part(n, g, parts));
+  TC_NOUNROLL for (size_t d = 1; d < parts; d <<= 1) {
+    const int lanes = (int)(d * kG2Lanes);
+    const G2Jac o{msm_from_partner(r.x, lanes), msm_from_partner(r.y, lanes), msm_from_partner(r.z, lanes)};
+    r = jac_add(r, o);
+  }
+  if (g == 0) g2_encode_uncompressed(jac_to_affine(r), out + j * 192);
+}
 
 size_t msm_table_bytes(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWords * sizeof(int32_t); }
 size_t msm_code_bytes(size_t n, size_t B) { return B * kMsmColumns * msm_chunks(n) * kMsmChunk; }
@@ -55,8 +85,16 @@ void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* p
   if (!B || !n) return;
   const size_t lanes = B * msm_chunks(n) * kG2Lanes;
   hipLaunchKernelGGL(k_msm_tables, dim3(grid_for(lanes)), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status, nbits, f);
-  hipLaunchKernelGGL(k_msm_ladder, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                     (const uint8_t*)status, nbits, f);
+  // lane pairs per job in stage L: 1 when the batch fills the GPU's 2048 wave slots by itself (65 536 lane pairs), else
+  // the power of two that does, with at least four shares per part
+  size_t parts = 1;
+  while (parts < 32 && B * parts * 2 <= 65536 && parts * 2 * 4 <= n) parts *= 2;
+  if (parts == 1)
+    hipLaunchKernelGGL(k_msm_ladder, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
+                       (const uint8_t*)status, nbits, f);
+  else
+    hipLaunchKernelGGL(k_msm_ladder_split, dim3(grid_for(B * parts * kG2Lanes)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl,
+                       (const uint8_t*)codes, out, (const uint8_t*)status, nbits, f, parts);
 }
 
 }  // namespace tc

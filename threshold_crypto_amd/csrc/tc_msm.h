@@ -92,53 +92,78 @@ TC_HD bool job_msm_tables(size_t n, size_t c, const uint8_t* points, const uint3
   return ok;
 }
 
-// Stage L: sum over the (4 * chunks) shares of one job from its tables and digit codes -- every special case of the
+// Stage L can split a job over `parts` lane pairs (small batches: k_msm.hip): part g sums the shares
+// [g n / parts, (g + 1) n / parts) -- never empty for parts <= n --, every part runs ceil(n / parts) look-ups per column
+// (the last one masked in the shorter parts, so that the lanes of a wave keep one trip count), and the caller adds the
+// partial sums.  parts = 1: the whole job.
+struct MsmPart {
+  size_t s0, s1, trips;
+};
+TC_HD MsmPart msm_part(size_t n, size_t g = 0, size_t parts = 1) { return MsmPart{g * n / parts, (g + 1) * n / parts, (n + parts - 1) / parts}; }
+
+// Stage L: sum over the shares of one part from the job's tables and digit codes -- every special case of the
 // addition handled (the slow path of job_msm_ladder below, and the g++ reference of the fast one)
-TC_HD_NOINLINE G2Jac job_msm_ladder_safe(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits) {
+TC_HD_NOINLINE G2Jac job_msm_ladder_safe(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits, MsmPart part) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G2Jac acc = G2Jac::infinity();
   TC_NOUNROLL for (int col = nbits; col >= 0; col--) {
     if (col != nbits) acc = jac_dbl(acc);
     const uint8_t* cc = codes + (size_t)col * shares4;
-    TC_NOUNROLL for (size_t s = 0; s < shares4; s++) {
+    TC_NOUNROLL for (size_t t = 0; t < part.trips; t++) {
+      const bool take = part.s0 + t < part.s1;
+      const size_t s = take ? part.s0 + t : part.s0;
       const uint32_t code = cc[s];
       G2Affine e = msm_load_entry(tbl + (s * 8 + (code & 7)) * kMsmEntryWords);
       // (the top column adds every entry as it is: no sign select there, so that the accumulator starts from a
       // carry-normalised y -- the lazy-limb budget of the first real addition depends on it)
       if (col != nbits) e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
-      acc = jac_add_mixed(acc, e);
+      acc = G2Jac::select(take, jac_add_mixed(acc, e), acc);
     }
   }
   return acc;
 }
-// The fast form: the accumulator starts from the first share's top entry, the padding shares (entries at infinity,
-// s >= n) are not visited, and the additions are the branch-free generic ones (tc_curve.h jac_add_mixed_generic); a
-// job that may have met a special case (an operand at infinity, P = +-Q) is redone by job_msm_ladder_safe.
-TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits = 64) {
+// The fast form: the accumulator starts from the part's first share's top entry, the padding shares (entries at
+// infinity, s >= n) are not visited, and the additions are the branch-free generic ones (tc_curve.h
+// jac_add_mixed_generic); a part that may have met a special case (an operand at infinity, P = +-Q) is redone by
+// job_msm_ladder_safe.  SPLIT = false: the part is the whole job (no masked look-ups).
+template <bool SPLIT>
+TC_HD G2Jac job_msm_ladder_part(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits, MsmPart part) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   bool exc = false;
   G2Jac acc;
   TC_NOUNROLL for (int col = nbits; col >= 0; col--) {
     tc_fair();
     const uint8_t* cc = codes + (size_t)col * shares4;
-    size_t s = 0;
+    size_t t = 0;
     if (col != nbits) {
       acc = jac_dbl(acc);
     } else {
-      const G2Affine e0 = msm_load_entry(tbl + (size_t)(cc[0] & 7) * kMsmEntryWords);
+      const G2Affine e0 = msm_load_entry(tbl + (part.s0 * 8 + (size_t)(cc[part.s0] & 7)) * kMsmEntryWords);
       acc = G2Jac::from_affine(e0);
       exc = e0.inf;
-      s = 1;
+      t = 1;
     }
-    TC_NOUNROLL for (; s < n; s++) {
+    TC_NOUNROLL for (; t < part.trips; t++) {
+      const bool take = !SPLIT || part.s0 + t < part.s1;
+      const size_t s = take ? part.s0 + t : part.s0;
       const uint32_t code = cc[s];
       G2Affine e = msm_load_entry(tbl + (s * 8 + (code & 7)) * kMsmEntryWords);
       if (col != nbits) e.y = Fq2::select((code >> 3) & 1, -e.y, e.y);
-      acc = jac_add_mixed_generic(acc, e, exc);
+      if (SPLIT) {
+        bool hit = false;
+        const G2Jac sum = jac_add_mixed_generic(acc, e, hit);
+        exc = exc || (take && hit);
+        acc = G2Jac::select(take, sum, acc);
+      } else {
+        acc = jac_add_mixed_generic(acc, e, exc);
+      }
     }
   }
-  if (wave_any(exc)) acc = G2Jac::select(exc, job_msm_ladder_safe(n, tbl, codes, nbits), acc);
+  if (wave_any(exc)) acc = G2Jac::select(exc, job_msm_ladder_safe(n, tbl, codes, nbits, part), acc);
   return acc;
+}
+TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, int nbits = 64) {
+  return job_msm_ladder_part<false>(n, tbl, codes, nbits, msm_part(n));
 }
 
 }  // namespace tc
