@@ -160,21 +160,22 @@ def test_comb_signing_many_signers_vs_oracle(engine, wl):
     every share of a few messages against Oracle B, plus a bad signer index, an identity point and an undecodable point."""
     c.load()
     rng = random.Random(31)
-    N, n, B = 40, 30, 96
+    N, n, B = 40, 30, 8192       # the comb runs from 24 signers and 8192 messages on (csrc/tc_launch.h)
     sk = np.stack([u8(rng.getrandbits(250).to_bytes(32, "little")) for _ in range(N)])
     sk[0] = u8((1).to_bytes(32, "little"))
     sk[1] = u8((2).to_bytes(32, "little"))
-    idx = np.stack([np.array(sorted(rng.sample(range(N), n)), dtype=np.uint64) for _ in range(B)])
+    sets = [np.array(sorted(rng.sample(range(N), n)), dtype=np.uint64) for _ in range(96)]
+    idx = np.stack([sets[j % 96] for j in range(B)])
     idx[3, 0], idx[3, 1] = 0, 1                      # tiny scalars: the guarded fallback ladder
     idx[4, 7] = N + 9                                # out of range: fails its own share only
-    pts = np.ascontiguousarray(wl.hashes[:B]).copy()
+    pts = np.ascontiguousarray(np.tile(wl.hashes, ((B + wl.B - 1) // wl.B, 1))[:B]).copy()
     inf = np.zeros(192, dtype=np.uint8)
     inf[0] = 0x40
     pts[5] = inf
     pts[6, 100] ^= 1                                 # not on the curve any more
     out, st = engine.sign_shares_g2(sk, idx, pts)
     assert st.shape == (B, n) and out.shape == (B, n, 192)
-    for j in (0, 1, 2, 3, 4, 5, 95):
+    for j in (0, 1, 2, 3, 4, 5, 95, B - 1):
         for s in range(n):
             if j == 4 and s == 7:
                 assert st[j, s] == 3 and bytes(out[j, s]) == bytes(inf)
@@ -187,3 +188,6 @@ def test_comb_signing_many_signers_vs_oracle(engine, wl):
     out23, st23 = engine.sign_shares_g2(sk, np.ascontiguousarray(idx[:, :23]), pts)
     out24, st24 = engine.sign_shares_g2(sk, np.ascontiguousarray(idx[:, :24]), pts)
     assert (out24[:, :23] == out23).all() and (st24[:, :23] == st23).all()
+    # a small batch of the same jobs takes the ladders with fewer signers per lane pair: same bytes
+    outs, sts = engine.sign_shares_g2(sk, np.ascontiguousarray(idx[:200]), np.ascontiguousarray(pts[:200]))
+    assert (outs == out[:200]).all() and (sts == st[:200]).all()

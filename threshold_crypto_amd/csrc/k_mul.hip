@@ -45,14 +45,15 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_shared(const uin
 // n selected signers (chunk-major lane order as above); out[(j * n + k)] = sk[idx[j * n + k]] * pts[j]
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_g2_mul_gather(const uint8_t* __restrict__ sk, size_t N, const uint64_t* __restrict__ idx,
                                                                      const uint8_t* __restrict__ pts, size_t n, size_t B,
-                                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
+                                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta,
+                                                                     size_t share) {
   const uint32_t tslot = table_slot_acquire(ta);
   const size_t tid = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
-  const size_t chunks = (n + kGatherShare - 1) / kGatherShare;
+  const size_t chunks = (n + share - 1) / share;  // share <= kGatherShare signers per lane pair (launch_g2_mul_gather)
   if (tid < chunks * B) {
     const size_t c = tid / B, j = tid % B;
-    const size_t s0 = c * kGatherShare;
-    const int cnt = (int)((n - s0 < (size_t)kGatherShare) ? n - s0 : (size_t)kGatherShare);
+    const size_t s0 = c * share;
+    const int cnt = (int)((n - s0 < share) ? n - s0 : share);
     const size_t o = j * n + s0;
     job_g2_mul_gather(sk, N, idx + o, cnt, pts + j * 192, out + o * 192, status ? status + o : nullptr, pair_leader());
   }
@@ -114,8 +115,9 @@ void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8
 void launch_g2_mul_gather(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
                           uint8_t* out, uint8_t* status) {
   if (!(n * B) || !ta.mem || !ta.flags) return;
-  const size_t chunks = (n + kGatherShare - 1) / kGatherShare;
-  hipLaunchKernelGGL(k_g2_mul_gather, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, sk, N, idx, pts, n, B, out, status, ta);
+  const size_t share = signers_per_lane_pair(n, B, kGatherShare);
+  const size_t chunks = (n + share - 1) / share;
+  hipLaunchKernelGGL(k_g2_mul_gather, dim3(grid_for(chunks * B * kG2Lanes)), dim3(kBlock), 0, st, sk, N, idx, pts, n, B, out, status, ta, share);
 }
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_compress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);

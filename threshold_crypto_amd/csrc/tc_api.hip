@@ -407,7 +407,7 @@ int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, cons
   uint8_t* d_st = k.out(status, B * n);
   k.begin_timing();
   k.check_points(true, d_h, 192, 1, 1, B, n);
-  if (!k.failed && n >= tc::kCombMinSigners) {
+  if (!k.failed && n >= tc::kCombMinSigners && B >= tc::kCombMinBatch) {
     // many signers per message: the doublings are done once per message, on a comb of its table (k_comb.hip); the combs
     // (133 KB per message) live in one HBM buffer, messages run through it in tiles
     const size_t per_msg = tc::comb_table_bytes(1);

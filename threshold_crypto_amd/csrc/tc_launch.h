@@ -31,6 +31,16 @@ void launch_g2_mul_gather(hipStream_t st, TableArena ta, const uint8_t* sk, size
 // many signers per message (n >= kCombMinSigners): a per-message comb in HBM (tbl: comb_table_bytes(B), ok: B bytes), then
 // doubling-free multiplications (k_comb.hip)
 constexpr size_t kCombMinSigners = 24;
+// ... and enough messages: a comb is built by ONE lane pair per message in 64 dependent column steps (~15 ms whatever the
+// batch), which only pays from a few thousand messages on; below, the per-chunk ladders of k_g2_mul_gather
+constexpr size_t kCombMinBatch = 8192;
+// signers a lane pair of the share-generation kernels takes: `most` (one table / one inversion shared by eight) when the
+// batch fills the GPU that way, fewer when that is what it takes to reach its 2048 wave slots (two rounds at most)
+inline size_t signers_per_lane_pair(size_t n, size_t B, size_t most) {
+  size_t share = most;
+  while (share > 1 && ((n + share - 1) / share) * B < 65536 && ((n + share / 2 - 1) / (share / 2)) * B <= 131072) share /= 2;
+  return share;
+}
 size_t comb_table_bytes(size_t B);
 void launch_comb_sign(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
                       int32_t* tbl, uint8_t* ok, uint8_t* out, uint8_t* status);
