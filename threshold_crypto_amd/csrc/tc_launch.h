@@ -35,11 +35,12 @@ constexpr size_t kCombMinSigners = 24;
 // batch), which only pays from a few thousand messages on; below, the per-chunk ladders of k_g2_mul_gather
 constexpr size_t kCombMinBatch = 8192;
 // signers a lane pair of the share-generation kernels takes: `most` (one table / one inversion shared by eight) when the
-// batch fills the GPU that way, fewer when that is what it takes to reach its 2048 wave slots (two rounds at most)
+// batch fills the GPU that way; for a smaller batch the smallest number that keeps the launch within ONE round of the
+// 2048 wave slots (65 536 lane pairs) -- more, shorter lane pairs, no second round with a handful of waves
 inline size_t signers_per_lane_pair(size_t n, size_t B, size_t most) {
-  size_t share = most;
-  while (share > 1 && ((n + share - 1) / share) * B < 65536 && ((n + share / 2 - 1) / (share / 2)) * B <= 131072) share /= 2;
-  return share;
+  for (size_t share = 1; share < most; share++)
+    if (((n + share - 1) / share) * B <= 65536) return share;
+  return most;
 }
 size_t comb_table_bytes(size_t B);
 void launch_comb_sign(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N, const uint64_t* idx, const uint8_t* pts, size_t n, size_t B,
