@@ -98,7 +98,9 @@ def test_hash_g2_stream_position_after_a_rejected_point(L, rnd):
 
 def test_legendre_symbol_by_binary_jacobi(L, rnd):
     # the squareness test inside hash_g2's retry loop (tc_sqrt.h fq_legendre) against Euler's criterion
-    vals = [0, 1, 2, 3, 4, o.Q - 1, o.Q - 2, (o.Q - 1) // 2, 1 << 380, (1 << 380) + 1] + [rnd.randrange(o.Q) for _ in range(300)]
+    vals = [0, 1, 2, 3, 4, o.Q - 1, o.Q - 2, (o.Q - 1) // 2, 1 << 380, (1 << 380) + 1] + [rnd.randrange(o.Q) for _ in range(1500)]
+    # long runs of trailing zeros: the 32-bit-word form strips at most 31 bits per step (and a zero low word counts as 31)
+    vals += [(2 * rnd.randrange(1 << 200) + 1) << k for k in (31, 32, 33, 63, 64, 65, 96, 127, 160)] + [3 << 379, 5 << 32, 7 << 31]
     for a in vals:
         e = pow(a, (o.Q - 1) // 2, o.Q)
         assert L.hs_fq_legendre(be(a)) == (0 if a == 0 else (1 if e == 1 else -1)), hex(a)
