@@ -199,3 +199,37 @@ def test_config5_two_rank_gloo_pipeline_sharding_broadcast_gather():
     for j in range(6):
         b = eng._buf(192)
         assert eng.L.hs_g2_mul(msk, bytes(single["hashes"][j]), b) == 0 and b.raw == single["sig"][j].tobytes()
+
+
+def test_committed_bench_lines_are_self_consistent():
+    """The bench lines kept under profiles/ (what DESIGN.md quotes) obey the arithmetic of the contract: value =
+    units / step time, frac = achieved / peak, achieved = executed multiply-adds x units / kernel time, every fraction a
+    utilisation, the kernels named in the line present in the rocprofv3 summary captured with it."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    macs = json.load(open(os.path.join(root, "profiles", "executed_macs.json")))
+    for tag in ("r02_i", "r02_j"):
+        line = [l for l in open(os.path.join(root, "profiles", tag + "_bench.txt")) if l.startswith("{")][-1]
+        d = json.loads(line)
+        B = d["config"]["batch_per_gpu"]
+        assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 and d["vs_baseline"] is None
+        assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+        assert abs(d["sequential"]["value"] - B / (d["sequential"]["ms_per_step"] * 1e-3)) / d["sequential"]["value"] < 2e-3
+        legs = [d["roofline"]] + list(d["secondary_rooflines"].values())
+        for r in legs:
+            assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+            want = r["executed_macs_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12
+            assert abs(r["achieved"] - want) / want < 2e-3
+            assert r["hbm_frac"] < 0.01                       # nowhere near the HBM roof: the bound is the integer multiplier
+        assert d["roofline"]["executed_macs_per_unit"] == macs["combine_g2_t3_fast"]
+        assert d["secondary_rooflines"]["pairing_check"]["executed_macs_per_unit"] == macs["verify_g2"]
+        assert 0 < d["roofline"]["frac_timed_region"] <= 1 and d["roofline"]["frac_slowest_class"] <= 1
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and d["value"] / c["value"] > 100
+        summary = open(os.path.join(root, "profiles", tag + "_rocprofv3_summary.csv")).read()
+        for k in ("k_combine_fast<tc::Fq2>", "k_pairing_check", "k_hash_g2", "k_g2_mul_shared", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+            assert k in summary, (tag, k)
+    c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r02_config5_1gpu_bench.txt")) if l.startswith("{")][-1])
+    assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True
+    assert abs(c5["value"] - c5["config"]["batch_per_gpu"] / (c5["ms_per_step"] * 1e-3)) / c5["value"] < 2e-3
+    assert abs(sum(c5["phase_kernel_ms"].values()) - c5["ms_per_step"]) / c5["ms_per_step"] < 0.02   # the step IS its three kernels' time
