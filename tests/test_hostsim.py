@@ -661,6 +661,24 @@ def test_two_stage_msm_matches_oracle(L, rnd):
     bad = bytearray(b"".join(o.g2_uncompressed(p) for p in pts))
     bad[192 * 5 + 100] ^= 1
     assert L.hs_msm_g2(n, bytes(bad), words, buf(192)) == 3
+    # colliding operands inside and across the parts of a split job (equal and opposite points, repeated scalars, zeros):
+    # the generic additions flag them and the part is redone on the guarded path
+    base = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(4)]
+    for n in (8, 16, 23):
+        pts, sc = [], []
+        for i in range(n):
+            r = rnd.random()
+            pts.append(None if r < 0.1 else (rnd.choice([pts[-1], o.E2.neg(pts[-1])]) if (r < 0.4 and pts and pts[-1] is not None) else rnd.choice(base)))
+            r = rnd.random()
+            sc.append(0 if r < 0.1 else (rnd.choice([1, 2, o.R - 1]) if r < 0.3 else (sc[-1] if (r < 0.5 and sc) else rnd.randrange(o.R))))
+        want = None
+        for p, k in zip(pts, sc):
+            want = o.E2.add(want, o.E2.mul(p, k))
+        words = (ctypes.c_uint32 * (8 * n))(*[(k >> (32 * i)) & 0xffffffff for k in sc for i in range(8)])
+        blob = b"".join(o.g2_uncompressed(p) for p in pts)
+        for parts in (1, 2, 4):
+            out = buf(192)
+            assert L.hs_msm_g2_split(n, blob, words, out, parts) == 0 and out.raw == o.g2_uncompressed(want), (n, parts)
 
 
 def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
