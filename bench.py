@@ -3,30 +3,43 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|5] [--batch B] [--t T] [--signers N]
 
---config 2 (default; BASELINE "t=3, N=10, batch=65 536 threshold signatures on 1xMI355X"): a "step" is
-one pass of PublicKeySet::combine_signatures (src/lib.rs:608-615) over `batch` independent
-(message, share-set) jobs through the C ABI (tc_combine_g2_batch) with every input already resident in
-HBM.  The K timed steps are issued without host synchronisation and alternate between two contexts (--in-flight, one
-HIP stream each), so consecutive launches overlap at their ends -- each step is still a full pass over the batch; the
-JSON line also carries the one-context, host-waits-every-step figure (`sequential`), and the roofline's per-launch
-kernel time is measured on that leg.  The same batch is then verified (PublicKey::verify_g2, src/lib.rs:108-110; every 16th signature
-replaced by its neighbour's, so the expected ok-vector is known), re-signed, verified with hashing on the
-device, and run through the threshold-decryption path (BASELINE configs 3 and 4); each of those legs
-carries its own roofline object and ANY failing leg fails the run.
+--gpus N with N > 1 STARTS N ranks: when the process was not itself started by torch.distributed.run (no
+WORLD_SIZE in the environment) it re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU over RCCL, after checking that the node has N GPUs; the
+JSON line's `n_gpus` is the world size the ranks really joined (dist.get_world_size()), with the RCCL version and
+every rank's device identity next to it.
 
---config 5 (BASELINE "t=67, N=200, batch=1 048 576 mixed sign+combine+verify sharded across 8 GPUs"):
-one step = sign the t+1 selected shares of every job ON the device, combine them, verify the result;
-131 072 jobs per GPU (weak scaling: --gpus 8 is the BASELINE batch), nothing larger than the key set
-crosses PCIe or xGMI.
+--config 2 (default; BASELINE "t=3, N=10, batch=65 536 threshold signatures on 1xMI355X"): a "step" is one pass of
+PublicKeySet::combine_signatures (src/lib.rs:608-615) over `batch` independent (message, share-set) jobs through
+the C ABI (tc_combine_g2_batch) with every input already resident in HBM.  The K timed steps are queued on ONE
+context (one HIP stream: launches do not overlap) and bracketed by barrier + synchronize: `value` / `ms_per_step`.
+The per-launch kernel time of the roofline comes from K more steps timed with HIP events on that stream
+(`roofline.kernel_ms` <= `ms_per_step`).  `streaming` is the same step with TWO contexts in flight (two streams:
+consecutive launches overlap at their ends, "overlapped": true), `sustained` the one-context rate over >= 1 s,
+`general_path` the same batch with share indices the small-index fast path does not take.  The batch is then
+verified (config 3: PublicKey::verify_g2, src/lib.rs:108-110; every 16th signature replaced by its neighbour's, so
+the expected ok-vector is known), re-signed, verified with hashing on the device, and run through the
+threshold-decryption path (config 4: Ciphertext::verify + PublicKeySet::decrypt); each leg carries its own roofline
+object and ANY failing leg fails the run.
 
-One process per GPU; for N > 1 the batch is per-rank (weak scaling), the key-set parameters are broadcast
-from rank 0 over RCCL and the per-rank valid counts are all-reduced; there is no data-path collective
-(jobs are independent).  Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the
-cpu_baseline leg and to check the GPU output of the timed batch bit-for-bit.
+--config 5 (BASELINE "t=67, N=200, batch=1 048 576 mixed sign+combine+verify sharded across 8 GPUs"): one step =
+sign the t+1 selected shares of every job ON the device, combine them, verify the result; 131 072 jobs per GPU (weak
+scaling: --gpus 8 is the BASELINE batch), nothing larger than the key set crosses PCIe or xGMI.
+
+One process per GPU; for N > 1 the batch is per-rank (weak scaling), the key-set parameters are broadcast from rank 0
+over RCCL and the per-rank valid counts are all-reduced; there is no data-path collective (jobs are independent).
+Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline leg and to check the GPU
+output of the timed batch bit-for-bit.
+
+--backend gloo --test-engine hostsim (tests/test_host_logic.py): the same rank start-up, rendezvous, broadcast,
+sharding and line bookkeeping on CPU ranks with tests/hostsim (the g++ build of the device source) standing in for
+the GPU -- a TEST HARNESS for the N-rank path in the GPU-less container; its line is marked "test_harness" and is
+not a measurement.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -38,7 +51,7 @@ sys.path.insert(0, ROOT)
 # Oracle B's counter (oracle/c/tc_oracle.c or_fq_mul_count; DESIGN.md "Work constants"); 1 Fq-mul = 300
 # 32-bit multiply-adds (12x12 product + 12x12 reduction + 12 quotient digits, CIOS: SURVEY 8d)
 W_FQMUL = {"combine_g2_t3": 31148, "g2_mul": 7771, "verify_g2": 41226, "hash_g2": 19604, "combine_g1_t3": 12800,
-           "combine_g2_t67": 530000}
+           "combine_g2_t67": 530000, "ciphertext_verify": 41226 + 19604}
 MAC_PER_FQMUL = 300
 # what the kernels execute per unit, in v_mad_i64_i32 lane-instructions (one 14x14 limb product or one
 # Montgomery reduction = 196): counted by running the same per-lane job bodies in the host build
@@ -47,10 +60,11 @@ MAC_PER_FQMUL = 300
 EXECUTED_MACS = json.load(open(os.path.join(ROOT, "profiles", "executed_macs.json")))
 # algorithmic bytes per unit (canonical uncompressed affine I/O)
 ALG_BYTES = {"combine_g2": lambda t: (t + 1) * (192 + 8) + 192, "verify_g2": lambda t: 385, "g2_mul": lambda t: 192,
-             "hash_g2": lambda t: 207, "combine_g1": lambda t: (t + 1) * (96 + 8) + 96 + 32}
+             "hash_g2": lambda t: 207, "combine_g1": lambda t: (t + 1) * (96 + 8) + 96 + 32,
+             "ciphertext_verify": lambda t: 96 + 32 + 192 + 1}
 # Roofline peak: the issue rate of the multiplier's own instruction (v_mad_i64_i32) with every SIMD full,
-# measured LIVE by tools/ubench_clock --peak when that binary is present (sustained ~25 ms launches, clock
-# read from s_memtime / s_memrealtime); otherwise the value recorded in profiles/r02_ubench_clock.txt.
+# measured LIVE by tools/ubench_chain --peak when that binary is present (sustained ~40 ms launches, clock
+# read from s_memtime / s_memrealtime); otherwise the recorded value.
 PEAK_RECORDED = {"tmacs": 37.5, "clock_ghz": 2.1, "source": "profiles/r02_ubench_chain.txt (v_mad_i64_i32 chains, >= 2 waves/SIMD)"}
 HBM_PEAK_GBPS = 8000.0
 # L2<->fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes, FETCH doubled per the
@@ -79,19 +93,22 @@ def measure_peak():
     return dict(PEAK_RECORDED)
 
 
-def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traffic_key=None, extra=None):
+def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traffic_key=None, extra=None, executed=None):
     """frac = the kernel's OWN multiply-add count / time / peak (utilisation of the integer multiplier);
     algorithmic_speedup = reference-algorithm work / executed work (what the smarter algorithm buys)."""
+    if not kernel_ms or kernel_ms < 1e-6:
+        return None     # (test harness: nothing was timed)
     sec = kernel_ms * 1e-3
-    executed = EXECUTED_MACS[unit_key] * units
+    per_unit = executed if executed is not None else EXECUTED_MACS[unit_key]
+    executed_total = per_unit * units
     ref = W_FQMUL[ref_key] * MAC_PER_FQMUL * units if ref_key else None
-    ach = executed / sec / 1e12
+    ach = executed_total / sec / 1e12
     alg_bytes = ALG_BYTES[alg_key](t) * units
     prof = PROFILE.get(traffic_key or "", {})
     r = {"bound": "valu_int32_mac", "kernel": kernel, "kernel_ms": round(kernel_ms, 3), "units_per_launch": units,
          "achieved": round(ach, 3), "peak": peak["tmacs"], "unit": "TMAC/s", "frac": round(ach / peak["tmacs"], 4),
          "peak_clock_GHz": peak["clock_ghz"], "peak_source": peak["source"],
-         "executed_macs_per_unit": EXECUTED_MACS[unit_key],
+         "executed_macs_per_unit": per_unit,
          "achieved_is": "v_mad the kernel executes per unit (tests/count_ops.py) x units / HIP-event kernel time",
          "algorithmic_bytes_per_launch": alg_bytes,
          "hbm_achieved_GBps": round(alg_bytes / sec / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBPS,
@@ -100,19 +117,19 @@ def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traf
          "traffic_is": ("L2<->fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), %s" % prof.get("source")) if prof else None}
     if ref:
         r["reference_work_TMACs"] = round(ref / sec / 1e12, 3)
-        r["algorithmic_speedup"] = round(ref / executed, 3)
+        r["algorithmic_speedup"] = round(ref / executed_total, 3)
     if prof.get("sq_insts_valu") and units == prof.get("units"):
         lane_instr = prof["sq_insts_valu"] * 64
         r["executed_cross_check"] = {"sq_insts_valu_wave_instr_per_launch": prof["sq_insts_valu"],
-                                     "executed_v_mad_lane_instr_per_launch": executed,
-                                     "implied_v_mad_share_of_valu": round(executed / lane_instr, 3),
+                                     "executed_v_mad_lane_instr_per_launch": executed_total,
+                                     "implied_v_mad_share_of_valu": round(executed_total / lane_instr, 3),
                                      "static_v_mad_share_of_the_multiplier_bodies": PROFILE.get("static_mad_share")}
     if extra:
         r.update(extra)
     return r
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: 20 (config 2), 6 (config 5)")
@@ -124,35 +141,109 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2,
-                    help="contexts (one HIP stream each) the timed steps of config 2 alternate between; 1 = one context, "
-                         "the host waits for every step")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (configs 3 and 4, PCIe-inclusive rate)")
-    args = ap.parse_args()
+                    help="contexts (one HIP stream each) of the `streaming` leg of config 2; 1 = skip that leg")
+    ap.add_argument("--sustain-seconds", type=float, default=1.2, help="length of the `sustained` leg of config 2 (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (general path, configs 3 and 4, PCIe-inclusive rate)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks, only with --test-engine")
+    ap.add_argument("--test-engine", default=None, choices=[None, "hostsim"],
+                    help="TEST HARNESS: tests/hostsim (g++ build of the device source) instead of the GPU; needs --backend gloo")
+    args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = 20 if args.config == 2 else 6
+    if (args.backend == "gloo") != (args.test_engine is not None):
+        ap.error("--backend gloo and --test-engine go together (there is no CPU compute path in the product)")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
-    import numpy as np
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` started as a plain process: start N ranks (one per GPU) under torch.distributed.run and hand
+    their output through.  Fails loudly when the node has fewer than N GPUs."""
+    if args.test_engine is None:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but this node has %d visible GPU(s); refusing to report n_gpus=%d\n" % (args.gpus, have, args.gpus))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TC_BENCH_LAUNCHED_BY"] = "bench.py --gpus %d (self-spawn)" % args.gpus
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree" % (args.gpus, world))
+    harness = args.test_engine is not None
+    if harness:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d needs GPU %d, this node shows %d (no CPU path exists)" % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    ranks_info = {"world_size": 1, "backend": None, "launched_by": os.environ.get("TC_BENCH_LAUNCHED_BY", "direct")}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if harness:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        # every rank's device identity, gathered: N ranks on N DISTINCT GPUs, or the run is not an N-GPU run
+        ident = "cpu:%d" % rank if harness else _device_identity(torch, local_rank)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if not harness and len(set(idents)) != world:
+            raise SystemExit("bench.py: %d ranks but only %d distinct GPUs (%s)" % (world, len(set(idents)), idents))
+        rccl = None
+        if not harness:
+            try:
+                rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                rccl = "unknown"
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl, "devices": idents,
+                      "launched_by": os.environ.get("TC_BENCH_LAUNCHED_BY", "torch.distributed.run (external launcher)")}
 
-    from threshold_crypto_amd.engine import Engine
-    eng = Engine(local_rank)
-    peak = measure_peak() if rank == 0 else dict(PEAK_RECORDED)
+    if harness:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from hostsim_engine import HostSimEngine
+        eng = HostSimEngine()
+        peak = dict(PEAK_RECORDED)
+    else:
+        from threshold_crypto_amd.engine import Engine
+        eng = Engine(local_rank)
+        peak = measure_peak() if rank == 0 else dict(PEAK_RECORDED)
     if args.config == 5:
         from threshold_crypto_amd import config5
         result = config5.run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=cpu_baseline_config5)
     else:
         result = run_config2(args, eng, dev, rank, world, peak)
     if rank == 0:
+        result["n_gpus"] = ranks_info["world_size"]
+        result["ranks"] = ranks_info
+        if harness:
+            result["test_harness"] = eng.version() + ": rank start-up / sharding / collectives exercised, NOT a measurement"
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -161,13 +252,23 @@ def main():
     return result
 
 
+def _device_identity(torch, i):
+    p = torch.cuda.get_device_properties(i)
+    tag = getattr(p, "uuid", None)
+    if tag is None:
+        tag = "%s/%s/%s" % (getattr(p, "pci_domain_id", "?"), getattr(p, "pci_bus_id", "?"), getattr(p, "pci_device_id", "?"))
+    return "%s gpu%d %s" % (p.name, i, tag)
+
+
 def run_config2(args, eng, dev, rank, world, peak):
     import numpy as np
     import torch
     from threshold_crypto_amd.workload import ThresholdSigWorkload, ThresholdEncWorkload
-    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range, total_count
+    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range, total_count, max_over_ranks
     if world > 1:
         import torch.distributed as dist
+    harness = getattr(eng, "is_test_harness", False)
+    cuda = dev.type == "cuda"
 
     t = 3 if args.t is None else args.t
     N = 10 if args.signers is None else args.signers
@@ -187,70 +288,88 @@ def run_config2(args, eng, dev, rank, world, peak):
 
     def sync():
         eng.sync()
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if cuda:
+                torch.cuda.synchronize()
 
-    # ---- headline: combine_signatures ----------------------------------------------------
-    # The timed region issues its K steps WITHOUT host synchronisation, alternating between `--in-flight` contexts (one
-    # HIP stream each, the same device-resident operands, separate outputs): every step is a full pass over the batch,
-    # and the tail of one launch -- the 65 536-job batch is a single resident round that ends with a third of the SIMDs
-    # idle -- overlaps the head of the next.  This is how a caller with a stream of batches drives the
-    # library; `sequential` below is the same work on one context with the host waiting for each step,
-    # and the per-launch kernel time of the roofline comes from that leg (un-overlapped launches).
-    from threshold_crypto_amd.engine import Engine
-    in_flight = max(1, int(args.in_flight))
-    engines = [eng] + [Engine(dev.index if dev.index is not None else 0) for _ in range(in_flight - 1)]
-    for e in engines:
-        e.set_timing(False)
-        for _ in range(max(1, args.warmup)):
-            sig, st = e.combine_g2(t, d_idx, d_shares)
-    for e in engines:
-        e.sync()
-    sync()
-    t0 = time.perf_counter()
-    outs = []
-    for i in range(args.steps):
-        outs.append(engines[i % in_flight].combine_g2(t, d_idx, d_shares))
-        if len(outs) > 2 * in_flight:
-            outs.pop(0)
-    for e in engines:
-        e.sync()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(fn, steps):
+        """barrier + synchronize, `steps` calls of fn queued without host waits, barrier + synchronize; MAX over ranks"""
+        sync()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        sync()
+        return max_over_ranks(time.perf_counter() - t0, world, dev if cuda else None), out
+
+    # ---- headline: combine_signatures, K steps on ONE context (one stream: no overlap between launches) -------------
+    eng.set_timing(False)
+    for _ in range(max(1, args.warmup)):
+        sig, st = eng.combine_g2(t, d_idx, d_shares)
+    dt, (sig, st) = timed(lambda: eng.combine_g2(t, d_idx, d_shares), args.steps)
     ms_per_step = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
-    for o_sig, o_st in outs:
-        assert int(o_st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
-    # the same steps one at a time (host waits for each): per-launch kernel times for the roofline
+    assert int(st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
+    # per-launch kernel times for the roofline: the same step with HIP events around its kernels (the host waits for each)
     eng.set_timing(True)
-    seq_steps = args.steps
     kernel_ms = []
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(seq_steps):
-        sig, st = eng.combine_g2(t, d_idx, d_shares)
+    for _ in range(args.steps):
+        sig2, st2 = eng.combine_g2(t, d_idx, d_shares)
         kernel_ms.append(eng.last_kernel_ms())
     sync()
-    seq_dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([seq_dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        seq_dt = float(tt.item())
-    assert int(st.to(torch.int32).sum().item()) == 0, "combine reported per-job errors"
-    for o_sig, _ in outs:
-        assert bool((o_sig == sig).all().item()), "steps in flight and the sequential step disagree"
-    del outs
-    seq_ms_per_step = seq_dt / seq_steps * 1e3
-    if seq_ms_per_step < ms_per_step:
-        # (never observed with two contexts; with four or more, concurrent queues can start trading scratch reservations
-        # -- INTEGRATION.md -- and then the one-context region is the honest headline)
-        in_flight, ms_per_step, value = 1, seq_ms_per_step, B * world / (seq_dt / seq_steps)
+    assert bool((sig2 == sig).all().item()) and int(st2.to(torch.int32).sum().item()) == 0
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+
+    # ---- streaming: the same step with `--in-flight` contexts (one HIP stream each): launches overlap at their ends --
+    streaming = None
+    engines = [eng]
+    if not harness and args.in_flight > 1:
+        from threshold_crypto_amd.engine import Engine
+        engines = [eng] + [Engine(dev.index if dev.index is not None else 0) for _ in range(args.in_flight - 1)]
+        for e in engines:
+            e.set_timing(False)
+            e.combine_g2(t, d_idx, d_shares)
+        for e in engines:
+            e.sync()
+        outs = []
+        counter = [0]
+
+        def step_rr():
+            o = engines[counter[0] % len(engines)].combine_g2(t, d_idx, d_shares)
+            counter[0] += 1
+            outs.append(o)
+            if len(outs) > 2 * len(engines):
+                outs.pop(0)
+            return o
+
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_rr()
+        for e in engines:
+            e.sync()
+        sync()
+        sdt = max_over_ranks(time.perf_counter() - t0, world, dev)
+        for o_sig, o_st in outs:
+            assert bool((o_sig == sig).all().item()) and int(o_st.to(torch.int32).sum().item()) == 0, "steps in flight disagree with the one-stream step"
+        del outs
+        streaming = {"value": round(B * world / (sdt / args.steps), 1), "ms_per_step": round(sdt / args.steps * 1e3, 3), "steps": args.steps,
+                     "contexts": len(engines), "overlapped": True,
+                     "is": "the K steps alternate between %d contexts (one HIP stream each) and are not synchronised with the host "
+                           "inside the timed region: the tail of one launch overlaps the head of the next (DESIGN.md 5.2); each "
+                           "step is a full pass over the batch" % len(engines)}
+    # ---- sustained: the one-context step repeated for >= --sustain-seconds ------------------------------------------
+    sustained = None
+    if not harness and args.sustain_seconds > 0:
+        eng.set_timing(False)
+        n = max(args.steps, int(args.sustain_seconds / (ms_per_step * 1e-3)) + 1)
+        sdt, _ = timed(lambda: eng.combine_g2(t, d_idx, d_shares), n)
+        sustained = {"value": round(B * world / (sdt / n), 1), "ms_per_step": round(sdt / n * 1e3, 3), "steps": n, "seconds": round(sdt, 3),
+                     "is": "the headline step queued %d times on the one context (>= %.1f s of GPU time)" % (n, args.sustain_seconds)}
+    eng.set_timing(True)
 
     # ---- config 3: verify the combined signatures; every 16th one replaced by its neighbour's ------------
     bad = sig.clone()
@@ -267,8 +386,8 @@ def run_config2(args, eng, dev, rank, world, peak):
     sync()
     verify_dt = time.perf_counter() - v0
     assert bool((ok == expect_ok).all().item()), "verify_g2 ok-vector differs from the planted corruption pattern"
-    # the same check with calls in flight (as the headline): 8 steps alternating between the contexts
-    verify_if_dt = verify_dt
+    # the same check with calls in flight: 8 steps alternating between the contexts
+    verify_if_dt = None
     if len(engines) > 1:
         eng.set_timing(False)
         for e in engines:
@@ -288,7 +407,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         eng.set_timing(True)
     for e in engines[1:]:
         e.close()
-    n_valid = total_count(int(ok.to(torch.int64).sum().item()), world, dev)   # per-rank valid counts, summed over RCCL
+    n_valid = total_count(int(ok.to(torch.int64).sum().item()), world, dev if cuda else None)   # per-rank valid counts, summed over RCCL
     assert n_valid == int(expect_ok.sum().item()) * world
     s0 = time.perf_counter()
     _sh, _st = eng.g2_mul(d_sk, d_hashes)
@@ -301,7 +420,28 @@ def run_config2(args, eng, dev, rank, world, peak):
     assert bool((msig[:, 0] == sig).all().item()), "combine != master-key signature"
 
     extras, legs = {}, {}
-    if not args.no_extras:
+    general = config4 = None
+    if not args.no_extras and not harness:
+        # ---- the same batch through the GENERAL path: share indices the small-index fast path does not take ---------
+        # (signers OFFSET + i: abscissae above 65 535; Lagrange coefficients from k_lagrange, two-stage combination)
+        OFFSET = 1 << 20
+        wg = ThresholdSigWorkload(eng, t, N, B, start=start, index_offset=OFFSET, hashes=wl.hashes)
+        g_idx = torch.from_numpy(wg.idx.view(np.int64)).to(dev)
+        g_shares = torch.from_numpy(wg.shares).to(dev)
+        gsig, gst = eng.combine_g2(t, g_idx, g_shares)
+        sync()
+        g0 = time.perf_counter()
+        gsig, gst = eng.combine_g2(t, g_idx, g_shares)
+        general_kernel_ms = eng.last_kernel_ms()
+        sync()
+        g_dt = max_over_ranks(time.perf_counter() - g0, world, dev)
+        assert int(gst.to(torch.int32).sum().item()) == 0 and bool((gsig == sig).all().item()), "general-path combination differs from the fast path's"
+        general = {"value": round(B * world / g_dt, 1), "ms_per_step": round(g_dt * 1e3, 3),
+                   "is": "the same messages and key set with signer indices %d + i (outside the small-index fast path): "
+                         "k_lagrange + k_msm_tables + k_msm_ladder; result compared with the fast path's" % OFFSET,
+                   "roofline": roofline("k_lagrange + k_msm_tables + k_msm_ladder", "combine_g2_t3_general", "combine_g2_t3", "combine_g2", t, B,
+                                        general_kernel_ms, peak) if t == 3 else None}
+        del wg, g_idx, g_shares, gsig
         # ---- verify incl. hashing on the device, hash_g2 alone --------------------------------------------
         d_msgs = torch.from_numpy(wl.msg_flat).to(dev)
         d_off = torch.from_numpy(wl.msg_off.view(np.int64)).to(dev)
@@ -329,13 +469,14 @@ def run_config2(args, eng, dev, rank, world, peak):
         sync()
         e0 = time.perf_counter()
         okc = eng.ciphertext_verify(du, dv, doff, dw)
-        extras["ciphertext_verify_kernel_ms"] = round(eng.last_kernel_ms(), 3)
+        cv_kernel_ms = eng.last_kernel_ms()
         sync()
         e1 = time.perf_counter()
         out, dst = eng.decrypt(t, didx, dsh, dv, doff)
         dec_kernel_ms = eng.last_kernel_ms()
         sync()
         e2 = time.perf_counter()
+        extras["ciphertext_verify_kernel_ms"] = round(cv_kernel_ms, 3)
         extras["ciphertext_verifies_per_s"] = round(B * world / (e1 - e0), 1)
         extras["threshold_decrypts_per_s"] = round(B * world / (e2 - e1), 1)
         extras["threshold_decryptions_incl_ciphertext_verify_per_s"] = round(B * world / (e2 - e0), 1)
@@ -343,6 +484,16 @@ def run_config2(args, eng, dev, rank, world, peak):
         assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item()), "threshold decryption returned wrong plaintext"
         legs["threshold_decrypt"] = roofline("k_combine_fast<Fq> + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
                                              "combine_g1", t, B, dec_kernel_ms, peak)
+        cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS.get("hash_g1_g2", EXECUTED_MACS["hash_g2"])
+        legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_loop + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
+                                             cv_kernel_ms, peak, executed=cv_macs)
+        config4 = {"value": round(B * world / (e2 - e0), 1), "unit": "threshold_decryptions/s", "ms_per_step": round((e2 - e0) * 1e3, 3),
+                   "is": "BASELINE config 4: Ciphertext::verify (hash_g1_g2 + pairing check) then PublicKeySet::decrypt (G1 combine + "
+                         "keystream) over the batch; every plaintext compared with the workload's",
+                   "kernel_ms": {"ciphertext_verify": round(cv_kernel_ms, 3), "decrypt": round(dec_kernel_ms, 3)},
+                   "roofline": roofline("k_hash_g1_g2 + k_miller_loop + k_final_exp + k_combine_fast<Fq> + k_xor_with_hash", None, None,
+                                        "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
+                                        executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"])}
         # ---- the same combine with HOST buffers at the C ABI (pageable numpy memory): PCIe-inclusive ---------
         eng.combine_g2(t, wl.idx, wl.shares)
         best = 1e9
@@ -357,26 +508,33 @@ def run_config2(args, eng, dev, rank, world, peak):
 
     if rank != 0:
         return None
-    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     fast = 1 <= t <= 3
     unit_key = "combine_g2_t3_fast" if t == 3 else None
     head = None
-    if unit_key:
-        head = roofline("k_lagrange + 3 grouping kernels + k_combine_fast<Fq2> + k_combine_general<Fq2>", unit_key, "combine_g2_t3",
+    if unit_key and not harness:
+        head = roofline("k_lagrange + 3 grouping kernels + k_combine_fast<Fq2> + two-stage kernels (idle)", unit_key, "combine_g2_t3",
                         "combine_g2", t, B, avg_kernel_ms, peak, traffic_key="combine_g2_t3",
                         extra={"frac_slowest_class": round(EXECUTED_MACS["combine_g2_t3_fast_general_denominator"] * B
                                                            / (avg_kernel_ms * 1e-3) / 1e12 / peak["tmacs"], 4),
                                "frac_timed_region": round(EXECUTED_MACS[unit_key] * B / (ms_per_step * 1e-3) / 1e12 / peak["tmacs"], 4),
-                               "frac_timed_region_is": "executed multiply-adds of the K timed steps / their wall time / peak: the "
-                                                       "machine's utilisation with steps in flight (frac is per launch)",
+                               "frac_timed_region_is": "executed multiply-adds of the K timed steps / their wall time / peak (one context); "
+                                                       "with steps in flight: frac_streaming",
+                               "frac_streaming": round(EXECUTED_MACS[unit_key] * B / (streaming["ms_per_step"] * 1e-3) / 1e12 / peak["tmacs"], 4) if streaming else None,
                                "frac_is": "average job over the 4-of-10 subsets; the 65 536-job batch is ONE resident round "
                                           "of 2048 waves and lasts as long as its slowest denominator class, whose waves run "
                                           "at frac_slowest_class (DESIGN.md 5.2)"})
-    legs["pairing_check"] = roofline("k_pairing_check", "verify_g2", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
-                                     traffic_key="pairing_check")
-    legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak)
+    if not harness:
+        legs["pairing_check"] = roofline("k_miller_loop + k_final_exp", "verify_g2", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
+                                         traffic_key="pairing_check")
+        legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak)
     # the CPU leg runs on rank 0 of a one-GPU run only (N ranks would time N oracles against each other on one host)
-    cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
+    cpu = None if (args.no_cpu_baseline or world > 1 or harness) else cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
+    config3 = {"value": round(B * world / verify_dt, 1), "unit": "pairing_verifies/s", "ms_per_step": round(verify_dt * 1e3, 3),
+               "kernel_ms": round(verify_kernel_ms, 3),
+               "is": "BASELINE config 3: PublicKey::verify_g2 over the batch, one call, host waits; every 16th signature replaced, ok-vector checked",
+               "streaming": ({"value": round(B * world / verify_if_dt, 1), "ms_per_step": round(verify_if_dt * 1e3, 3), "overlapped": True}
+                             if verify_if_dt else None),
+               "roofline": legs.get("pairing_check")}
     return {
         "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -385,16 +543,15 @@ def run_config2(args, eng, dev, rank, world, peak):
         "data": "synthetic",
         "config": {"workload": "t=%d,N=%d,batch=%d threshold signatures (combine_signatures, G2), per GPU" % (t, N, B),
                    "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world,
-                   "fast_path": fast, "steps_in_flight": in_flight,
-                   "steps_in_flight_is": "the K timed steps alternate between this many contexts (one HIP stream each) and are "
-                                         "not synchronised with the host inside the timed region; each is a full pass over "
-                                         "the batch (bench.py --in-flight 1: one context, host waits for every step)"},
-        "sequential": {"value": round(B * world / (seq_dt / seq_steps), 1), "ms_per_step": round(seq_dt / seq_steps * 1e3, 3),
-                       "steps": seq_steps, "is": "the same step on ONE context, the host waiting for each step; the roofline's "
-                                                 "per-launch kernel time is measured here (launches do not overlap)"},
-        "pairing_verifies_per_s": round(B * world / min(verify_dt, verify_if_dt), 1),
-        "pairing_verifies_per_s_is": "verify_g2 over the batch, calls in flight over the same contexts as the headline (8 steps); "
-                                     "one call at a time: pairing_verifies_sequential_per_s",
+                   "fast_path": fast, "steps_in_flight": 1, "overlapped": False,
+                   "timed_region_is": "K steps queued on ONE context (one HIP stream: launches do not overlap), barrier + "
+                                      "synchronize on both sides, MAX over ranks"},
+        "streaming": streaming,
+        "sustained": sustained,
+        "general_path": general,
+        "config3": config3,
+        "config4": config4,
+        "pairing_verifies_per_s": round(B * world / min(verify_dt, verify_if_dt or verify_dt), 1),
         "pairing_verifies_sequential_per_s": round(B * world / verify_dt, 1),
         "pairing_verify_kernel_ms": round(verify_kernel_ms, 3),
         "pairing_verify_valid_count_all_ranks": n_valid,

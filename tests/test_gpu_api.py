@@ -238,26 +238,30 @@ def test_encrypt_and_public_key_shares_entry_points(engine, rnd):
 
 
 def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the contract's fields; the in-flight headline and the one-step-at-a-time
-    figure are both there and the roofline fraction is a utilisation (<= 1)."""
+    """bench.py prints ONE JSON line with the contract's fields: the headline is K steps on ONE context (launches do not
+    overlap, so the per-launch kernel time fits inside the step time), the two-contexts figure is the `streaming` object
+    marked overlapped, the roofline fraction is a utilisation (<= 1)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "1", "--batch", "8192",
-                          "--no-extras", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--no-extras", "--cpu-seconds", "1", "--sustain-seconds", "0.2"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "sequential"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "streaming", "sustained", "config3", "ranks"):
         assert k in d, k
     assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 and d["steps"] == 6 and d["higher_is_better"] is True
-    assert d["config"]["steps_in_flight"] in (1, 2) and "workload" in d["config"]
+    assert d["config"]["steps_in_flight"] == 1 and d["config"]["overlapped"] is False and "workload" in d["config"]
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     r = d["roofline"]
     assert r["bound"] == "valu_int32_mac" and 0 < r["frac"] <= 1 and 0 < r["frac_timed_region"] <= 1 and r["peak"] > 30
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.02          # one stream: a launch fits inside its step
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
-    assert d["sequential"]["value"] > 0 and d["sequential"]["ms_per_step"] > 0
+    s = d["streaming"]
+    assert s["overlapped"] is True and s["contexts"] == 2 and s["value"] > 0
+    assert d["sustained"]["seconds"] >= 0.2 and d["config3"]["kernel_ms"] > 0

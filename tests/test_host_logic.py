@@ -84,74 +84,7 @@ def test_two_rank_gloo_broadcast_and_sharding():
 
 
 # ---- BASELINE config 5 flow on two gloo ranks, the host-compiled device source standing in for the GPU -------
-class HostSimEngine:
-    """The engine methods threshold_crypto_amd/config5.py uses, executed by tests/hostsim (the SAME per-lane job
-    bodies the kernels run, compiled by g++).  Test harness only."""
-
-    def __init__(self):
-        import ctypes
-        import subprocess
-        here = os.path.dirname(os.path.abspath(__file__))
-        csrc = os.path.join(os.path.dirname(here), "threshold_crypto_amd", "csrc")
-        src = os.path.join(here, "hostsim", "hostsim.cpp")
-        lib = os.path.join(here, "hostsim", "libtc_hostsim.so")
-        newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(".h"))
-        if not os.path.exists(lib) or os.path.getmtime(lib) < max(newest, os.path.getmtime(src)):
-            subprocess.run(["g++", "-O2", "-std=c++17", "-DTC_TEST_HOOKS", "-shared", "-fPIC", "-I" + csrc, src, "-o", lib], check=True)
-        self.L = ctypes.CDLL(lib)
-        self.ct = ctypes
-        self.L.hs_hash_g2.restype = None
-
-    def last_kernel_ms(self):
-        return 0.0
-
-    def _buf(self, n):
-        return self.ct.create_string_buffer(n)
-
-    def g1_commitment(self, fr):
-        out = np.zeros((fr.shape[0], 96), np.uint8)
-        st = np.zeros(fr.shape[0], np.uint8)
-        for i in range(fr.shape[0]):
-            b = self._buf(96)
-            st[i] = self.L.hs_g1_fixed_base_mul(bytes(fr[i]), b)
-            out[i] = np.frombuffer(b.raw, np.uint8)
-        return out, st
-
-    def hash_g2(self, flat, off):
-        B = off.shape[0] - 1
-        out = np.zeros((B, 192), np.uint8)
-        for j in range(B):
-            m = bytes(flat[int(off[j]): int(off[j + 1])])
-            b = self._buf(192)
-            self.L.hs_hash_g2(m, self.ct.c_size_t(len(m)), b)
-            out[j] = np.frombuffer(b.raw, np.uint8)
-        return out
-
-    def sign_shares_g2(self, sk_table, idx, hashes):
-        B, n = idx.shape
-        out = np.zeros((B, n, 192), np.uint8)
-        st = np.zeros((B, n), np.uint8)
-        for j in range(B):
-            for k in range(n):
-                b = self._buf(192)
-                st[j, k] = self.L.hs_g2_mul(bytes(sk_table[int(idx[j, k])]), bytes(hashes[j]), b)
-                out[j, k] = np.frombuffer(b.raw, np.uint8)
-        return out, st
-
-    def combine_g2(self, t, idx, shares):
-        B, n = idx.shape
-        out = np.zeros((B, 192), np.uint8)
-        st = np.zeros(B, np.uint8)
-        for j in range(B):
-            b = self._buf(192)
-            ids = (self.ct.c_uint64 * n)(*[int(v) for v in idx[j]])
-            st[j] = self.L.hs_combine_g2(int(t), ids, shares[j].tobytes(), b)
-            out[j] = np.frombuffer(b.raw, np.uint8)
-        return out, st
-
-    def verify_g2(self, pk, sig, hashes):
-        g1 = api._G1_GEN
-        return np.array([self.L.hs_pairing_check(bytes(pk), bytes(hashes[j]), g1, bytes(sig[j])) for j in range(sig.shape[0])], np.uint8)
+from hostsim_engine import HostSimEngine  # noqa: E402  (tests/hostsim_engine.py: test harness)
 
 
 def _config5_worker(rank, world, port, q):
@@ -233,3 +166,51 @@ def test_committed_bench_lines_are_self_consistent():
     assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True
     assert abs(c5["value"] - c5["config"]["batch_per_gpu"] / (c5["ms_per_step"] * 1e-3)) / c5["value"] < 2e-3
     assert abs(sum(c5["phase_kernel_ms"].values()) - c5["ms_per_step"]) / c5["ms_per_step"] < 0.02   # the step IS its three kernels' time
+
+
+# ---- bench.py --gpus N starts N ranks itself ---------------------------------------------------------------------
+def _run_bench(*argv, timeout=900):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, [json.loads(l) for l in lines]
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun around it, no WORLD_SIZE in the environment) must
+    start two ranks, not run one and print n_gpus 1: the flow runs end to end on two gloo ranks with the host build of the
+    device source standing in for the GPU (bench.py --test-engine: a test harness, marked in the line), and the line's
+    n_gpus is the world size the ranks really joined."""
+    out, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "3", "--t", "1", "--signers", "3",
+                            "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1                                    # ONE JSON line, rank 0's
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["devices"] == ["cpu:0", "cpu:1"]
+    assert "self-spawn" in d["ranks"]["launched_by"] and d["ranks"]["backend"] == "gloo" and "test_harness" in d
+    assert d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["batch_per_gpu"] == 3 and d["verified_all"] is True
+    assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01        # whole-job rate: both ranks' jobs
+    assert d["pairing_verify_valid_count_all_ranks"] == 2 * 2                              # 3 jobs per rank, job 0 of each corrupted
+
+
+def test_bench_gpus_2_config5_on_two_ranks():
+    out, lines = _run_bench("--gpus", "2", "--config", "5", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "2", "--t", "8",
+                            "--signers", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = lines[0]
+    assert len(lines) == 1 and d["n_gpus"] == 2 and d["config"]["t"] == 8 and d["valid_total_all_ranks"] == 4
+    assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[0, 2, 2], [2, 2, 2]]
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """--gpus N on a node with fewer GPUs fails loudly instead of reporting an N-GPU number (this container has none)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two GPUs")
+    out, lines = _run_bench("--gpus", "2", "--steps", "1", timeout=300)
+    assert out.returncode != 0 and not lines and "refusing" in out.stderr
+    out, lines = _run_bench("--gpus", "2", "--backend", "gloo", timeout=60)          # gloo without the test engine: no CPU path
+    assert out.returncode != 0 and not lines

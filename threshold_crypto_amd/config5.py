@@ -133,27 +133,36 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
     N = 200 if args.signers is None else args.signers
     B = 131072 if args.batch is None else args.batch
 
+    harness = getattr(eng, "is_test_harness", False)   # bench.py --test-engine: CPU ranks on gloo (tests/hostsim_engine.py)
+    cuda = dev.type == "cuda"
+
     def sync():
         eng.sync()
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-            torch.cuda.synchronize()
+            if cuda:
+                torch.cuda.synchronize()
 
     eng.set_timing(True)
-    res = run_pipeline(eng, t, N, B, rank, world, device=dev, steps=args.steps, warmup=args.warmup, sync=sync)
+    res = run_pipeline(eng, t, N, B, rank, world, device=dev if cuda else None, steps=args.steps, warmup=args.warmup, sync=sync)
     assert res["status_errors"] == 0 and res["valid_local"] == B, "config 5: %d status errors, %d of %d verified" % (
         res["status_errors"], res["valid_local"], B)
     # size-independent property on every job of the rank: the combination equals the master key's own signature
     km = res["key_material"]
     if rank == 0:
         master_sk = res["secret_key_set"].poly[0]
-        msig, _ = eng.g2_mul(torch.from_numpy(np.frombuffer(master_sk.to_bytes(32, "little"), dtype=np.uint8)[None].copy()).to(dev), res["hashes"])
-        assert bool((msig[:, 0].cpu() == torch.from_numpy(res["sig"])).all().item()), "combine != master-key signature"
+        msk = torch.from_numpy(np.frombuffer(master_sk.to_bytes(32, "little"), dtype=np.uint8)[None].copy())
+        msig, _ = eng.g2_mul(msk.to(dev) if cuda else msk.numpy(), res["hashes"])
+        msig = msig.cpu() if hasattr(msig, "cpu") else torch.from_numpy(np.asarray(msig))
+        assert bool((msig[:, 0] == torch.from_numpy(res["sig"])).all().item()), "combine != master-key signature"
     if rank != 0:
         return None
     ms = np.array(res["phase_ms"], dtype=np.float64).mean(axis=0)
+    if harness:
+        ms = np.maximum(ms, 1e-9)   # nothing is timed per kernel in the test harness
     step_s = res["seconds"] / args.steps
     legs = {
         "combine": roofline("k_lagrange_all + k_msm_tables + k_msm_ladder", "combine_g2_t67_msm", "combine_g2_t67", "combine_g2", t, B,
@@ -162,9 +171,9 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
         "share_sign": roofline("k_comb_tables + k_comb_sign" if (t + 1 >= 24 and B >= 8192) else "k_g2_mul_gather",
                                "g2_sign_comb_68_signers" if (t + 1 >= 24 and B >= 8192) else "g2_mul_gather_68_signers", "g2_mul", "g2_mul", t,
                                (t + 1) * B, float(ms[0]), peak),
-        "pairing_check": roofline("k_pairing_check", "verify_g2", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
+        "pairing_check": roofline("k_miller_loop + k_final_exp", "verify_g2", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
     }
-    cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline and world == 1) else None
+    cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline and world == 1 and not harness) else None
     return {
         "metric": "threshold signatures (sign t+1 shares + combine + verify)/sec", "value": round(B * world / step_s, 1),
         "unit": "threshold_signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

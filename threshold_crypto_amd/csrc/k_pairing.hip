@@ -1,7 +1,9 @@
-// gfx950 kernel: batched pairing-product check  e(a,b) == e(c,d).
+// gfx950 kernels: batched pairing-product check  e(a,b) == e(c,d).
 #include "tc_jobs.h"
 #include "tc_launch.h"
 #include "tc_stage.h"
+
+#include <stdlib.h>
 
 namespace tc {
 
@@ -24,9 +26,72 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_check(const uin
   if (live && pair_leader()) ok[j] = r;
 }
 
+// ---- the same check as two kernels --------------------------------------------------------------------------
+// The Miller loop and the final exponentiation have disjoint live sets (point arithmetic + sparse products against a
+// running Fq12 / cyclotomic chains on three or four Fq12 values): compiled as ONE kernel the register allocator
+// serves the union (1 994 spilled registers, 9.6 KB of scratch per lane).  As two kernels each half gets its own
+// allocation; the Miller value travels through HBM in the lane-pair row layout: word w of lane l of wave v at
+// fbuf[(v * kFq12Words + w) * 64 + l] -- every store / load instruction moves one full 256-byte row.
+constexpr int kFq12Words = 6 * FQ_LIMBS;  // per lane: one coefficient of each of the six Fq2
+#if TC_PAIR
+__device__ __forceinline__ void fq12_store_rows(int32_t* __restrict__ rows, const Fq12& f) {
+  const Fq2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  TC_UNROLL for (int k = 0; k < 6; k++) {
+    const Fq v = c[k]->m.reduce_value();
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) rows[(k * FQ_LIMBS + i) * 64] = v.l[i];
+  }
+}
+__device__ __forceinline__ Fq12 fq12_load_rows(const int32_t* __restrict__ rows) {
+  Fq12 f;
+  Fq2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+  TC_UNROLL for (int k = 0; k < 6; k++) {
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) c[k]->m.l[i] = rows[(k * FQ_LIMBS + i) * 64];
+  }
+  return f;
+}
+#else
+__device__ __forceinline__ void fq12_store_rows(int32_t*, const Fq12&) {}
+__device__ __forceinline__ Fq12 fq12_load_rows(const int32_t*) { return Fq12::one(); }
+#endif
+
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_miller_loop(const uint8_t* __restrict__ a, size_t sa,
+                                                        const uint8_t* __restrict__ b, size_t sb,
+                                                        const uint8_t* __restrict__ c, size_t sc,
+                                                        const uint8_t* __restrict__ d, size_t sd, size_t B,
+                                                        int32_t* __restrict__ fbuf, uint8_t* __restrict__ ok) {
+  using IO1 = WaveRowIO<96, kG2Lanes>;
+  using IO2 = WaveRowIO<192, kG2Lanes>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[IO2::BYTES];
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const bool live = j < B;
+  const size_t jj = live ? j : 0;
+  IO1 ia{lds, live ? a + jj * sa : nullptr, 0, nullptr}, ic{lds, live ? c + jj * sc : nullptr, 0, nullptr};
+  IO2 ib{lds, live ? b + jj * sb : nullptr, 0, nullptr}, id{lds, live ? d + jj * sd : nullptr, 0, nullptr};
+  Fq12 f = Fq12::one();
+  const bool good = job_miller_io(live, ia, ib, ic, id, f);
+  fq12_store_rows(fbuf + (size_t)blockIdx.x * kFq12Words * 64 + threadIdx.x, f);
+  if (live && pair_leader()) ok[j] = good ? 1 : 0;  // 0: an operand did not decode; the second kernel keeps it
+}
+
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_final_exp(const int32_t* __restrict__ fbuf, size_t B, uint8_t* __restrict__ ok) {
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const Fq12 f = fq12_load_rows(fbuf + (size_t)blockIdx.x * kFq12Words * 64 + threadIdx.x);
+  const uint8_t r = job_final_exp_is_one(f);
+  if (j < B && pair_leader() && ok[j]) ok[j] = r;
+}
+
+size_t pairing_ws_words(size_t B) { return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64; }
+
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
-                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok) {
-  if (B) hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
+                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws) {
+  if (!B) return;
+  static const int mode = getenv("TC_PAIRING_FUSED") ? 1 : 0;  // experiments: the one-kernel form
+  if (mode || !ws) {
+    hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
+    return;
+  }
+  hipLaunchKernelGGL(k_miller_loop, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
+  hipLaunchKernelGGL(k_final_exp, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, (const int32_t*)ws, B, ok);
 }
 
 }  // namespace tc

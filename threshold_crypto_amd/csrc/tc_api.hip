@@ -137,6 +137,8 @@ struct Call {
     if (d && zero && n) check(hipMemsetAsync(d, 0, n, c->stream), "memset");
     return d;
   }
+  // the Miller values between the two kernels of a pairing check (k_pairing.hip)
+  int32_t* pairing_ws(size_t B) { return temp<int32_t>(tc::pairing_ws_words(B)); }
   // Checked-input mode (tc_ctx_set_input_checks): validate the first `take` points of `records` records of
   // n_per_job points each (stride 0 = ONE point shared by every job); job j owns record j / group.
   void check_points(bool g2, const uint8_t* d_pts, size_t stride, size_t n_per_job, size_t take, size_t records, size_t group) {
@@ -644,7 +646,7 @@ int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8
   k.check_points(true, db, sb, 1, 1, B, 1);
   k.check_points(false, dc, sc, 1, 1, B, 1);
   k.check_points(true, dd, sd, 1, 1, B, 1);
-  if (!k.failed) tc::launch_pairing_check(ctx->stream, da, sa, db, sb, dc, sc, dd, sd, B, d_ok);
+  if (!k.failed) tc::launch_pairing_check(ctx->stream, da, sa, db, sb, dc, sc, dd, sd, B, d_ok, k.pairing_ws(B));
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
@@ -666,7 +668,7 @@ int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const u
   k.check_points(true, d_sig, 192, 1, 1, B, 1);
   k.check_points(true, d_hash, 192, 1, 1, B, 1);
   // e(pk, hash) == e(g1, sig)                                           (src/lib.rs:109)
-  if (!k.failed) tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen, 0, d_sig, 192, B, d_ok);
+  if (!k.failed) tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen, 0, d_sig, 192, B, d_ok, k.pairing_ws(B));
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
@@ -695,7 +697,7 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
     // e(pk, [c] Q') == e(g1, sig)  <=>  e(pk, Q') == e([1/c] g1, sig): the hash skips its last constant
     // multiplication and the generator side uses the context's pre-scaled generator
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
-    tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen_unfix, 0, d_sig, 192, B, d_ok);
+    tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen_unfix, 0, d_sig, 192, B, d_ok, k.pairing_ws(B));
   }
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
@@ -748,7 +750,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
     tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     // e(P, [c] Q') == e(g1, S)  <=>  e(P, Q') == e([1/c] g1, S)   (the folded hash constant of tc_verify_sig_batch)
-    tc::launch_pairing_check(ctx->stream, d_P, 96, d_hash, 192, ctx->g1_gen_unfix, 0, d_S, 192, B, d_okmsg);
+    tc::launch_pairing_check(ctx->stream, d_P, 96, d_hash, 192, ctx->g1_gen_unfix, 0, d_S, 192, B, d_okmsg, k.pairing_ws(B));
     // a share that does not decode (status below) or, in checked-input mode, is no group member sends its
     // message to the per-share fallback
     k.apply_checks(B, nullptr, nullptr, 0, d_okmsg);
@@ -783,7 +785,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
         tc::launch_gather_rows(ctx->stream, d_sig, 192, d_maps, R, c_sig);
         tc::launch_gather_rows(ctx->stream, d_hash, 192, d_maps + R, R, c_hash);
         tc::launch_gather_rows(ctx->stream, d_pk, 96, d_maps + 2 * R, R, c_pk);
-        tc::launch_pairing_check(ctx->stream, c_pk, 96, c_hash, 192, ctx->g1_gen_unfix, 0, c_sig, 192, R, c_ok);
+        tc::launch_pairing_check(ctx->stream, c_pk, 96, c_hash, 192, ctx->g1_gen_unfix, 0, c_sig, 192, R, c_ok, k.pairing_ws(R));
         if (ctx->input_checks) {  // members only, as the per-share path would require
           uint8_t* v = k.temp<uint8_t>(R);
           tc::launch_subgroup_check_g2(ctx->stream, c_sig, 192, 1, 1, R, v);
@@ -823,7 +825,7 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
     // an undecodable u leaves an infinity hash; the pairing kernel then rejects u itself
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
     // e(g1, w) == e(u, [c] Q')  <=>  e([1/c] g1, w) == e(u, Q')         (src/lib.rs:511)
-    tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok);
+    tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok, k.pairing_ws(B));
   }
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
@@ -860,7 +862,7 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st, /*fix=*/false);
     tc::launch_g1_scale_cofactor_fix(ctx->stream, d_share, 96, B, d_sharec);
     // e(share, hash) = e([c] share, Q') == e(pk_share, w)               (src/lib.rs:185)
-    tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok);
+    tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok, k.pairing_ws(B));
   }
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();

@@ -388,6 +388,32 @@ TC_HD uint8_t job_pairing_check_io(bool live, IOA& a, IOB& b, IOC& c, IOD& d) {
   return pairing_check(pa, qb, pc, qd) ? 1 : 0;
 }
 
+// The check in two halves (k_pairing.hip runs them as two kernels): the product Miller loop of the two pairs ...
+template <class IOA, class IOB, class IOC, class IOD>
+TC_HD bool job_miller_io(bool live, IOA& a, IOB& b, IOC& c, IOD& d, Fq12& f) {
+  G1Affine pa = G1Affine::infinity(), pc = G1Affine::infinity();
+  G2Affine qb = G2Affine::infinity(), qd = G2Affine::infinity();
+  bool ok = live;
+  const uint8_t* e = a.operand(0);
+  if (live) ok &= g1_decode_uncompressed(e, pa);
+  e = b.operand(0);
+  if (live) ok &= g2_decode_uncompressed(e, qb);
+  e = c.operand(0);
+  if (live) ok &= g1_decode_uncompressed(e, pc);
+  e = d.operand(0);
+  if (live) ok &= g2_decode_uncompressed(e, qd);
+  if (!ok) {  // the value of an empty product; the caller reports the job as failed
+    pa = pc = G1Affine::infinity();
+    qb = qd = G2Affine::infinity();
+  }
+  G1Affine ps[2] = {pa, G1Affine{pc.x, (-pc.y), pc.inf}};
+  G2Affine qs[2] = {qb, qd};
+  f = miller_loop<2>(ps, qs);
+  return ok;
+}
+// ... and the final exponentiation with the comparison
+TC_HD uint8_t job_final_exp_is_one(const Fq12& f) { return final_exponentiation(f) == Fq12::one() ? 1 : 0; }
+
 // hash_g2(msg)      (src/lib.rs:691-694)
 // fix = false: the point Q' with hash_g2(msg) = [FR_COFACTOR_FIX] Q' (tc_gls.h g2_clear_cofactor), for the
 // composed entry points that fold the constant into a scalar or into the G1 operand of a pairing.

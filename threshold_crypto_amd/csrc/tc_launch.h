@@ -99,8 +99,10 @@ void launch_subgroup_check_g2(hipStream_t st, const uint8_t* pts, size_t stride,
 void launch_invalidate_jobs(hipStream_t st, const uint8_t* valid, size_t per_job, size_t group, size_t B, uint8_t* status,
                             uint8_t* out, size_t out_bytes, uint8_t* ok);
 
+// ws: pairing_ws_words(B) words -- the Miller values between the two kernels of a check (k_pairing.hip)
+size_t pairing_ws_words(size_t B);
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
-                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok);
+                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws);
 
 // fix = false: the hash point WITHOUT its last constant multiplication (tc_gls.h g2_clear_cofactor); the
 // caller folds the constant into a scalar (launch_fr_scale_cofactor_fix) or a G1 operand

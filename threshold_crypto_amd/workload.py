@@ -58,16 +58,19 @@ class ThresholdSigWorkload:
     caller).  `prehashed=True` replaces hash_g2(m_j) by h_j * G2 with h_j = j+1 scrambled, which
     decouples the determined arithmetic from the H-spec (SURVEY.md 8c "Decoupling")."""
 
-    def __init__(self, engine, t, N, B, seed=SEED, start=0, chunk=8192):
+    def __init__(self, engine, t, N, B, seed=SEED, start=0, chunk=8192, index_offset=0, hashes=None):
+        """index_offset: the N signers are the nodes index_offset .. index_offset + N - 1 (share indices of 65 535 and
+        above leave the combiner's small-index fast path: bench.py's general-path leg); hashes: the hash points of
+        the same messages when the caller already has them."""
         self.t, self.N, self.B = t, N, B
         self.sks = key_set(t, seed)
-        self.shares_sk = [self.sks.secret_key_share(i) for i in range(N)]
+        self.shares_sk = [self.sks.secret_key_share(index_offset + i) for i in range(N)]
         fr = np.stack([np.frombuffer(s._bytes(), dtype=np.uint8) for s in self.shares_sk])
         self.msgs = messages(B, start)
         flat, off = pack_messages(self.msgs)
         self.msg_flat, self.msg_off = flat, off
-        self.hashes = engine.hash_g2(flat, off)                      # (B, 192)
-        self.idx = signer_subsets(B, N, t, seed, start)              # (B, t+1)
+        self.hashes = engine.hash_g2(flat, off) if hashes is None else hashes   # (B, 192)
+        self.idx = signer_subsets(B, N, t, seed, start)              # (B, t+1): positions in the signer table
         # only the t+1 selected shares of each job are needed by combine; sign all N per message in
         # chunks (S x B lanes) and gather the selected ones
         sel = np.empty((B, t + 1, 192), dtype=np.uint8)
@@ -78,6 +81,7 @@ class ThresholdSigWorkload:
             rows = np.arange(hi - lo)[:, None]
             sel[lo:hi] = allsh[rows, self.idx[lo:hi].astype(np.int64)]
         self.shares = sel
+        self.idx = self.idx + np.uint64(index_offset)                # the share indices the combiner sees
         pk, st = engine.g1_mul(np.frombuffer(self.sks.poly[0].to_bytes(32, "little"), dtype=np.uint8)[None].copy(),
                                np.frombuffer(_g1_gen(), dtype=np.uint8)[None].copy())
         self.master_pk = np.ascontiguousarray(pk[0, 0])
