@@ -13,17 +13,17 @@
  *   compressed: 48 B / 96 B = PublicKey::to_bytes / Signature::to_bytes (src/lib.rs:149-153,255-259)
  *   Fr scalar : 32 B little-endian canonical (4 x u64 LE limbs)  (src/serde_impl.rs:296)
  *   share idx : u64, the `T: IntoFr` index of combine_signatures/decrypt (src/into_fr.rs:16-26)
- * Decoding an uncompressed point checks range, flags and the curve equation.  By DEFAULT it does NOT
- * run the order-r subgroup check: uncompressed operands are the in-memory form of values the reference
- * already holds as G1/G2 (`into_affine().into_uncompressed()`), and those passed the checked decode of
- * from_bytes (src/lib.rs:140-146, 246-252) when they entered the process.  The scalar-multiplication and
- * pairing kernels RELY on membership (GLV/GLS ladders through phi = [-x^2] and psi = [x], the psi forms of
- * the share combiner's division, the folded cofactor constant): an on-curve point outside the subgroup
- * gives a result the reference's plain double-and-add would not.  Bytes from an untrusted source must
- * therefore enter through tc_g{1,2}_decompress_batch (the reference's own checked decode), or be tested
- * with tc_g{1,2}_subgroup_check_batch, or the context must run in checked-input mode
- * (tc_ctx_set_input_checks: every point operand of every entry is validated on the device first; a job
- * that owns an invalid point fails exactly like one with an undecodable encoding).
+ * Decoding an uncompressed point checks range, flags and the curve equation, and BY DEFAULT every point operand
+ * of every entry is also tested for order-r subgroup membership on the device before it is used (what the
+ * reference does once per value in from_bytes, src/lib.rs:140-146, 246-252): a job that owns an invalid point
+ * fails exactly like one with an undecodable encoding.  The scalar-multiplication and pairing kernels RELY on
+ * membership (GLV/GLS ladders through phi = [-x^2] and psi = [x], the psi forms of the share combiner's
+ * division, the folded cofactor constant, the 2^-63 bound of the random-linear-combination checks): an on-curve
+ * point outside the subgroup would give a result the reference's plain double-and-add does not.  A caller whose
+ * operands are KNOWN members -- outputs of this library's own entries, values that entered through
+ * tc_g{1,2}_decompress_batch (the reference's checked decode) or were tested with
+ * tc_g{1,2}_subgroup_check_batch; typically device-resident data -- opts out with
+ * tc_ctx_set_input_checks(ctx, 0) and saves one 64-bit ladder per G2 operand and two per G1 operand.
  *
  * Return value: 0 = TC_OK, < 0 = call-level failure (bad argument / HIP error / no device);
  * never aborts, never throws across the boundary.  Per-job results go to `status[]`
@@ -84,11 +84,13 @@ const char* tc_last_error(const tc_ctx* ctx);
  * the context's stream (0 if timing is disabled).  tc_ctx_set_timing(ctx, 1) enables it. */
 int tc_ctx_set_timing(tc_ctx* ctx, int enabled);
 double tc_last_kernel_ms(const tc_ctx* ctx);
-/* Checked-input mode (default off; see "Decoding" above): every uncompressed point operand of every
- * entry is tested for order-r subgroup membership on the device before it is used -- what the reference
- * does once per value in from_bytes (src/lib.rs:140-146, 246-252).  A job that owns an invalid point
- * reports TC_JOB_INVALID_ENCODING / ok = 0, as for an undecodable encoding.  Costs one 64-bit ladder
- * per G2 point (psi(P) = [x]P) and two per G1 point (phi(P) = [-x^2]P). */
+/* Checked-input mode (default ON; see "Decoding" above): every uncompressed point operand of every entry is
+ * tested for order-r subgroup membership on the device before it is used -- what the reference does once per
+ * value in from_bytes (src/lib.rs:140-146, 246-252).  A job that owns an invalid point reports
+ * TC_JOB_INVALID_ENCODING / ok = 0, as for an undecodable encoding.  Costs one 64-bit ladder per G2 point
+ * (psi(P) = [x]P) and two per G1 point (phi(P) = [-x^2]P).  enabled = 0 is the explicit opt-out for operands the
+ * caller knows to be members (this library's own outputs, checked decodes); results on non-members are then
+ * unspecified (never memory-unsafe). */
 int tc_ctx_set_input_checks(tc_ctx* ctx, int enabled);
 const char* tc_version(void);
 

@@ -121,3 +121,22 @@ def test_ref_distributed_key_generation(engine, rnd):
     assert BivarCommitment(faulty_num, pub_bi_commits[0].coeff).evaluate(3, 4) == o.g1_uncompressed(
         o.bivar_commitment_evaluate(faulty_num, o.bivar_commitment(bi_polys[0].coeff), 3, 4))
     assert Commitment(rows0[0].coeff).degree() == faulty_num
+
+
+def test_commitment_evaluate_any_into_fr_abscissa(engine, rnd):
+    """ADVICE r02: Commitment::evaluate takes any `T: IntoFr` (src/poly.rs:497-508, src/into_fr.rs): 0, the u64 range,
+    2^64 (the share index 2^64 - 1), negative i64 values (they wrap modulo r) and full-size field elements -- the
+    out-of-u64 ones run as a linear combination of powers instead of re-entering the u64 path."""
+    api.set_default_engine(engine)
+    poly = [rnd.randrange(o.R) for _ in range(4)]
+    commit = o.commitment(poly)
+    c = Commitment([o.g1_uncompressed(p) for p in commit])
+    xs = [0, 1, 5, 2 ** 64 - 1, 2 ** 64, -1, -7, o.R - 3, rnd.randrange(o.R)]
+    got = c.evaluate_batch(xs)
+    for x, g in zip(xs, got):
+        assert g == o.g1_uncompressed(o.commitment_evaluate(commit, x % o.R)), x
+    assert c.evaluate(2 ** 64) == o.g1_uncompressed(o.E1.mul(o.G1_GEN, o.poly_evaluate(poly, 2 ** 64)))
+    # BivarCommitment.evaluate reaches the same path through row(x).evaluate(y)
+    bp = BivarPoly(1, [rnd.randrange(o.R) for _ in range(3)])
+    bc = bp.commitment()
+    assert bc.evaluate(2, 2 ** 64) == o.g1_uncompressed(o.E1.mul(o.G1_GEN, bp.evaluate(2, 2 ** 64)))

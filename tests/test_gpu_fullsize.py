@@ -210,10 +210,11 @@ def test_out_of_subgroup_operands_default_mode_vs_checked_mode(engine):
     """The reference multiplies bit by bit (CurveAffine::mul, reached from src/lib.rs:372-374), which is
     correct on all of E'(Fq2); the kernels use psi = [x] and therefore REQUIRE order-r operands -- the
     reference guarantees that by construction (checked from_bytes, src/lib.rs:246-252).  This test pins the
-    contract: (1) in the default trusted-operand mode an on-curve point outside G2 is accepted (status OK)
-    and the result differs from plain double-and-add -- the documented divergence; (2) the membership entry
-    and checked-input mode reject it exactly like an undecodable encoding; (3) checked-input mode leaves
-    valid operands' results untouched."""
+    contract: (1) a context validates every point operand by DEFAULT: the membership entry and
+    every batch entry reject an on-curve point outside G2 exactly like an undecodable encoding, and leave valid
+    operands' results untouched; (2) after the explicit opt-out (tc_ctx_set_input_checks(ctx, 0): operands the caller
+    knows to be members) such a point is accepted (status OK) and the result differs from plain double-and-add --
+    the documented divergence."""
     rnd = random.Random(77)
     P0 = _point_outside_g2(rnd)
     good = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
@@ -221,7 +222,11 @@ def test_out_of_subgroup_operands_default_mode_vs_checked_mode(engine):
     assert engine.g2_subgroup_check(pts).tolist() == [0, 1, 1]
     k = rnd.randrange(1, o.R)
     fr = u8(o.fr_to_bytes(k))[None]
-    out, st = engine.g2_mul(fr, pts)
+    engine.set_input_checks(False)   # the explicit opt-out
+    try:
+        out, st = engine.g2_mul(fr, pts)
+    finally:
+        engine.set_input_checks(True)
     assert st[:, 0].tolist() == [0, 0, 0]
     assert bytes(out[1, 0]) == o.g2_uncompressed(o.E2.mul(good, k))
     assert bytes(out[0, 0]) != o.g2_uncompressed(o.E2.mul(P0, k)), "GLS on a non-member happened to agree: pick another point"
@@ -235,8 +240,7 @@ def test_out_of_subgroup_operands_default_mode_vs_checked_mode(engine):
             break
     g1pts = np.stack([u8(o.g1_uncompressed(Q1)), u8(o.g1_uncompressed(o.G1_GEN))])
     assert engine.g1_subgroup_check(g1pts).tolist() == [0, 1]
-    engine.set_input_checks(True)
-    try:
+    try:   # the context's default mode
         out2, st2 = engine.g2_mul(fr, pts)
         assert st2[:, 0].tolist() == [3, 0, 0]
         assert bytes(out2[0, 0]) == o.g2_uncompressed(None) and (out2[1:] == out[1:]).all()
@@ -259,7 +263,7 @@ def test_out_of_subgroup_operands_default_mode_vs_checked_mode(engine):
         okp = engine.pairing_check(g1pts, enc([h, h]), g1pts, enc([h, h]))
         assert okp.tolist() == [0, 1]
     finally:
-        engine.set_input_checks(False)
+        engine.set_input_checks(True)
     # the API mirror validates raw uncompressed bytes by default (threshold_crypto_amd/api.py)
     from threshold_crypto_amd import api
     api.set_default_engine(engine)

@@ -214,3 +214,26 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert out.returncode != 0 and not lines and "refusing" in out.stderr
     out, lines = _run_bench("--gpus", "2", "--backend", "gloo", timeout=60)          # gloo without the test engine: no CPU path
     assert out.returncode != 0 and not lines
+
+
+def test_commitment_evaluate_batch_never_re_enters_itself():
+    """abscissae outside [1, 2^64 - 1] used to recurse forever; they are routed by value (IntoFr: modulo r):
+    0 -> coefficient 0, 1 .. 2^64 - 1 -> the Horner kernel with idx = x - 1, everything else -> a linear combination."""
+    from threshold_crypto_amd import poly
+
+    class StubEngine:
+        def public_key_shares(self, c, idx):
+            self.idx = idx.tolist()
+            return np.full((len(idx), 96), 1, np.uint8), np.zeros(len(idx), np.uint8)
+
+        def lincomb_g1(self, sc, pts):
+            self.scalars = [[int.from_bytes(bytes(r), "little") for r in row] for row in sc]
+            return np.full((sc.shape[0], 96), 2, np.uint8), np.zeros(sc.shape[0], np.uint8)
+
+    e = StubEngine()
+    c = poly.Commitment([bytes([3]) * 96, bytes([4]) * 96, bytes([5]) * 96], _trusted=True)
+    r = c.evaluate_batch([0, 1, 2 ** 64, -1, 2 ** 64 - 1], e)
+    assert [x[0] for x in r] == [3, 1, 2, 2, 1]
+    assert e.idx == [0, 2 ** 64 - 2]
+    R = poly._R
+    assert e.scalars == [[1, 2 ** 64, 2 ** 128 % R], [1, R - 1, 1]]

