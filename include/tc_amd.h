@@ -92,6 +92,14 @@ double tc_last_kernel_ms(const tc_ctx* ctx);
  * caller knows to be members (this library's own outputs, checked decodes); results on non-members are then
  * unspecified (never memory-unsafe). */
 int tc_ctx_set_input_checks(tc_ctx* ctx, int enabled);
+int tc_ctx_get_input_checks(const tc_ctx* ctx);
+/* A context keeps its staging and table buffers between calls (grow-only; a t = 67 combination of 131 072 jobs holds
+ * ~18 GB of per-share tables, sized to a third of the HBM that was free at the call, at most 24 GiB).  tc_ctx_trim
+ * waits for the context's stream and gives them back; they are allocated again on demand. */
+int tc_ctx_trim(tc_ctx* ctx);
+/* Bytes this context's own staging copies have moved over PCIe since it was created (host-I/O mode: every operand up,
+ * every result down; device-I/O mode: the 8-byte read-back of off[B] per message-taking call and nothing else). */
+int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 const char* tc_version(void);
 
 /* ---- hashing onto G2 -------------------------------------------------------------------- */
@@ -243,6 +251,8 @@ tc_ctx* tc_group_ctx(tc_group* g, int rank);             /* the rank's context, 
 const char* tc_group_last_error(const tc_group* g);
 /* contiguous range [start, start + count) of a B-job batch that rank `rank` works on */
 int tc_group_shard(const tc_group* g, size_t B, int rank, size_t* start, size_t* count);
+/* bytes that crossed PCIe since the group was created: the group's own copies plus its contexts' staging copies */
+int tc_group_transfer_bytes(const tc_group* g, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 /* PublicKeySet { commit } src/lib.rs:539-543: (t+1) x 96 B from host memory to rank 0, then RCCL broadcast */
 int tc_group_set_keyset(tc_group* g, size_t t, const uint8_t* commit);
 int tc_group_get_keyset(tc_group* g, int rank, uint8_t* out_commit);
@@ -252,7 +262,10 @@ int tc_group_combine_signatures(tc_group* g, size_t n_per_job, const uint64_t* i
 /* PublicKeySet::public_key().verify_g2 src/lib.rs:565-567, 108-110 for B jobs; n_valid (optional): all-reduced count */
 int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, size_t B, uint8_t* ok, uint64_t* n_valid);
 /* BASELINE config 5 in one call: hash each message, sign the n shares of its signer subset ON the device from the
- * N x 32 B table of secret key shares, combine, verify under the master key.  idx: B x n ascending signer indices. */
+ * N x 32 B table of secret key shares, combine, verify under the master key.  idx: B x n ascending signer indices.
+ * Per rank only its slice of msgs / off / idx and the share table go up and its slice of sig / ok comes back; the hash
+ * points and the B x n x 192 B of share signatures are made and consumed in the rank's HBM (persistent per-rank device
+ * buffers, one persistent worker thread per GPU).  off must start at 0 and be non-decreasing (checked before sharding). */
 int tc_group_sign_combine_verify(tc_group* g, const uint8_t* sk_table, size_t N, const uint64_t* idx, size_t n, const uint8_t* msgs,
                                  const uint64_t* off, size_t B, uint8_t* sig, uint8_t* ok, uint64_t* n_valid);
 

@@ -535,12 +535,20 @@ class Group {
   std::vector<Signature> combine_signatures(std::size_t n, const std::vector<std::uint64_t>& idx, const std::vector<std::uint8_t>& shares,
                                             std::vector<std::uint8_t>& status) {
     const std::size_t B = n ? idx.size() / n : 0;
+    // the C ABI trusts its sizes: the vectors must hold exactly B x n indices and B x n x 192 share bytes
+    if (n == 0 || idx.size() != B * n || shares.size() != B * n * 192) throw GpuError("Group::combine_signatures: idx / shares sizes do not match n");
     std::vector<std::uint8_t> out(B * 192 + 1);
     status.assign(B, 0);
     if (B) check(tc_group_combine_signatures(g_, n, idx.data(), shares.data(), B, out.data(), status.data()));
     std::vector<Signature> res(B);
     for (std::size_t j = 0; j < B; j++) std::memcpy(res[j].g2.data(), &out[j * 192], 192);
     return res;
+  }
+  // (host-to-device, device-to-host) bytes the group and its contexts have moved over PCIe
+  std::pair<std::uint64_t, std::uint64_t> transfer_bytes() const {
+    std::uint64_t up = 0, down = 0;
+    check(tc_group_transfer_bytes(g_, &up, &down));
+    return {up, down};
   }
   tc_group* raw() const { return g_; }
 

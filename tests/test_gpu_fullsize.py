@@ -345,9 +345,9 @@ def test_rlc_share_validation_equals_per_share_path(engine):
 
 
 def test_large_threshold_g1_and_g2_combination_vs_oracle(engine):
-    """t = 9 and t = 21 through BOTH groups: G2 takes the two-stage kernels (k_lagrange_all + k_msm_*), G1 the
-    chunked Straus path fed by the same one-inversion Lagrange kernel; every job against Oracle B, including a job
-    with a repeated index (filtered by value, src/lib.rs:758) and one whose index list is not sorted."""
+    """t = 9 and t = 21 through BOTH groups: the two-stage kernels (k_lagrange_all + k_msm_* / k_msm_*_g1) -- at this batch
+    size the SPLIT stage L (2 and 4 lanes or lane pairs per job); every job against Oracle B, including a job with a
+    repeated index (filtered by value, src/lib.rs:758) and one whose index list is not sorted."""
     rnd = random.Random(4242)
     for t in (9, 21):
         N, B = 40, 70
@@ -374,6 +374,32 @@ def test_large_threshold_g1_and_g2_combination_vs_oracle(engine):
             rc, want = c.combine_g1(t, ids, [bytes(x) for x in sh1[j]])
             assert rc == 0 and bytes(out1[j]) == want, (t, j)
         assert bytes(out2[0]) == o.g2_uncompressed(o.E2.mul(h2, poly[0])) and bytes(out1[0]) == o.g1_uncompressed(o.E1.mul(h1, poly[0]))
+
+
+def test_large_threshold_g1_combination_full_batch(engine):
+    """PublicKeySet::decrypt's combination (src/lib.rs:618-626, 739-765) at the config-5 threshold in G1: t = 67, N = 200,
+    131 072 jobs -- the NON-split stage L of the G1 two-stage kernels (one lane per job, two waves per SIMD).  Every job
+    combines the decryption shares of its own 68-signer subset of ONE ciphertext, so every result must equal
+    [master key] u; the first jobs are also recomputed by Oracle B.  TC_TEST_G1_LARGE_JOBS shrinks it for local runs."""
+    import os
+    from threshold_crypto_amd.config5 import signer_subsets_np
+    from threshold_crypto_amd.workload import key_set
+    B = int(os.environ.get("TC_TEST_G1_LARGE_JOBS", "131072"))
+    t, N = 67, 200
+    sks = key_set(t)
+    fr = np.stack([u8(sks.secret_key_share(i)._bytes()) for i in range(N)])
+    u = o.E1.mul(o.G1_GEN, 0xC0FFEE)
+    allsh, st = engine.g1_mul(fr, u8(o.g1_uncompressed(u))[None])      # (1, N, 96): every node's decryption share
+    assert not st.any()
+    idx = signer_subsets_np(B, N, t)
+    shares = np.ascontiguousarray(allsh[0][idx.astype(np.int64)])      # (B, t+1, 96)
+    out, st = engine.combine_g1(t, idx, shares)
+    assert not st.any()
+    want = o.g1_uncompressed(o.E1.mul(u, sks.poly[0]))
+    assert (out == u8(want)[None]).all()
+    for j in range(2):
+        rc, w = c.combine_g1(t, [int(i) for i in idx[j]], [bytes(x) for x in shares[j]])
+        assert rc == 0 and w == bytes(out[j]) == want
 
 
 def test_config5_one_gpu_slice_properties(engine):

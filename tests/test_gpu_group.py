@@ -51,10 +51,26 @@ def test_group_config5_pipeline(engine):
     g = Group([0, 0])
     try:
         g.set_keyset(commit)
+        up0, down0 = g.transfer_bytes()
         sig, ok, nvalid = g.sign_combine_verify(sk_table, idx, flat, off)
+        up1, down1 = g.transfer_bytes()
+        # a second call reuses the persistent workers and the per-rank device buffers
+        sig2, ok2, nvalid2 = g.sign_combine_verify(sk_table, idx, flat, off)
+        with pytest.raises(ValueError):
+            bad_off = off.copy()
+            bad_off[3] = off[2] - 1
+            g.sign_combine_verify(sk_table, idx, flat, bad_off)
     finally:
         g.close()
-    assert ok.all() and nvalid == B
+    assert ok.all() and nvalid == B and (sig2 == sig).all() and ok2.all() and nvalid2 == B
+    # hash points and share signatures (B x n x 192 B = %d KB here) stay in the ranks' HBM: what crosses PCIe is
+    # the messages, offsets, signer indices and the secret share table going up, signatures + ok + status coming back
+    share_bytes = B * (t + 1) * 192
+    ranks = 2
+    up_budget = flat.nbytes + (B + ranks) * 8 + idx.nbytes + ranks * sk_table.nbytes + 64 * ranks
+    down_budget = B * (192 + 1 + 1) + 64 * ranks
+    assert up1 - up0 <= up_budget and down1 - down0 <= down_budget, (up1 - up0, down1 - down0)
+    assert (up1 - up0) + (down1 - down0) < share_bytes / 4 and (up1 - up0) + (down1 - down0) < (1 << 20)
     h = engine.hash_g2(flat, off)
     msig, st = engine.g2_mul(np.frombuffer(sks.poly[0].to_bytes(32, "little"), dtype=np.uint8)[None].copy(), h)
     assert (msig[:, 0] == sig).all()

@@ -681,6 +681,53 @@ def test_two_stage_msm_matches_oracle(L, rnd):
             assert L.hs_msm_g2_split(n, blob, words, out, parts) == 0 and out.raw == o.g2_uncompressed(want), (n, parts)
 
 
+def test_two_stage_msm_g1_matches_oracle(L, rnd):
+    """tc_msm.h in G1 (threshold decryption at large thresholds): the sign-aligned GLV form of every scalar taken two
+    columns at a time (base 4: an 8-entry table {P, P - f, P + 2f, P + f, 3P, 3P + f, 3P + 2f, 3P + 3f}, f = [x^2] P, per
+    share), tables + column codes + ONE ladder of 64 double-doubling steps == sum_i s_i P_i; whole jobs and jobs split over 2 .. 8 lanes; the identity, zero / one / even /
+    maximal scalars, equal and opposite points (special cases of the addition: the guarded second pass)."""
+    L.hs_msm_g1.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    # the recoding itself: sum over the columns of 4^c sigma (A + B x^2) == +-k (mod r), every index / sign as documented
+    X2 = o.BLS_X * o.BLS_X
+    AB = [(1, 0), (1, -1), (1, 2), (1, 1), (3, 0), (3, 1), (3, 2), (3, 3)]
+    for k in [1, 2, 3, o.R - 1, o.R - 2, X2, X2 + 1, (1 << 254) + 5] + [rnd.randrange(o.R) for _ in range(60)]:
+        kw = (ctypes.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        codes = buf(65)
+        flip = ctypes.c_int(0)
+        L.hs_msm_g1_recode(kw, codes, ctypes.byref(flip))
+        assert codes.raw[64] in (0, 3)
+        val = (AB[codes.raw[64]][0] + AB[codes.raw[64]][1] * X2) << 128
+        for c in range(64):
+            a, b2 = AB[codes.raw[c] & 7]
+            val += (-1 if codes.raw[c] & 8 else 1) * (a + b2 * X2) << (2 * c)
+        assert val % o.R == ((o.R - k) if flip.value else k) % o.R, hex(k)
+    for n in (8, 9, 13, 23):
+        pts = [o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)) for _ in range(n)]
+        pts[2] = None
+        pts[6] = o.E1.neg(pts[5])
+        sc = [rnd.randrange(o.R) for _ in range(n)]
+        sc[0], sc[1], sc[3], sc[4], sc[6] = 0, o.R - 1, 2, 1, sc[5]
+        want = None
+        for p, s in zip(pts, sc):
+            want = o.E1.add(want, o.E1.mul(p, s))
+        words = (ctypes.c_uint32 * (8 * n))(*[(s >> (32 * i)) & 0xffffffff for s in sc for i in range(8)])
+        blob = b"".join(o.g1_uncompressed(p) for p in pts)
+        for parts in (1, 2, 4, 8):
+            if parts * 4 > n and parts > 1:
+                continue
+            out = buf(96)
+            assert L.hs_msm_g1(n, blob, words, out, parts) == 0 and out.raw == o.g1_uncompressed(want), (n, parts)
+    bad = bytearray(blob)
+    bad[96 * 5 + 50] ^= 1
+    assert L.hs_msm_g1(n, bytes(bad), words, buf(96), 1) == 3
+    # all shares equal, all scalars equal (every addition of a column is a doubling in disguise)
+    p = o.E1.mul(o.G1_GEN, 7)
+    n = 8
+    words = (ctypes.c_uint32 * (8 * n))(*[(5 >> (32 * i)) & 0xffffffff for _ in range(n) for i in range(8)])
+    out = buf(96)
+    assert L.hs_msm_g1(n, o.g1_uncompressed(p) * n, words, out, 1) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(p, 40))
+
+
 def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
     """tc_threshold.h lagrange_all_at_zero == the reference's per-coefficient construction (src/lib.rs:739-763),
     including repeated indices (filtered by VALUE out of the denominator, :758) and u64 edge values."""

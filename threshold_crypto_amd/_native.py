@@ -58,7 +58,8 @@ PROTOTYPES = {
 }
 
 CONTEXT_SYMBOLS = ["tc_ctx_create", "tc_ctx_destroy", "tc_ctx_set_device_io", "tc_ctx_set_stream", "tc_sync",
-                   "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version", "tc_ctx_set_input_checks"]
+                   "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version", "tc_ctx_set_input_checks",
+                   "tc_ctx_get_input_checks", "tc_ctx_transfer_bytes", "tc_ctx_trim"]
 
 # the multi-GPU surface (tc_group_*): name -> (restype, argtypes); the group handle is an opaque pointer
 _grp = ctypes.c_void_p
@@ -72,6 +73,7 @@ GROUP_PROTOTYPES = {
     "tc_group_ctx": (ctypes.c_void_p, [_grp, ctypes.c_int]),
     "tc_group_last_error": (ctypes.c_char_p, [_grp]),
     "tc_group_shard": (ctypes.c_int, [_grp, _sz, ctypes.c_int, _szp, _szp]),
+    "tc_group_transfer_bytes": (ctypes.c_int, [_grp, _u64out, _u64out]),
     "tc_group_set_keyset": (ctypes.c_int, [_grp, _sz, _u8p]),
     "tc_group_get_keyset": (ctypes.c_int, [_grp, ctypes.c_int, _u8p]),
     "tc_group_combine_signatures": (ctypes.c_int, [_grp, _sz, _u64p, _u8p, _sz, _u8p, _u8p]),
@@ -117,6 +119,12 @@ def load():
     lib.tc_ctx_set_timing.restype = ctypes.c_int
     lib.tc_ctx_set_input_checks.argtypes = [_ctx, ctypes.c_int]
     lib.tc_ctx_set_input_checks.restype = ctypes.c_int
+    lib.tc_ctx_trim.argtypes = [_ctx]
+    lib.tc_ctx_trim.restype = ctypes.c_int
+    lib.tc_ctx_get_input_checks.argtypes = [_ctx]
+    lib.tc_ctx_get_input_checks.restype = ctypes.c_int
+    lib.tc_ctx_transfer_bytes.argtypes = [_ctx, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.tc_ctx_transfer_bytes.restype = ctypes.c_int
     lib.tc_last_kernel_ms.argtypes = [_ctx]
     lib.tc_last_kernel_ms.restype = ctypes.c_double
     lib.tc_sync.argtypes = [_ctx]

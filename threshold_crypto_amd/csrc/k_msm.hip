@@ -75,6 +75,65 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder_split(size_t
   if (g == 0) g2_encode_uncompressed(jac_to_affine(r), out + j * 192);
 }
 
+// ---- G1 (tc_msm.h): stage T one lane per (job, chunk of 4 shares), stage L one lane per job -- or per PART of a job
+// when the batch alone does not fill the GPU (a job's `parts` lanes are adjacent; their partial sums meet in
+// log2(parts) rounds of one __shfl_xor exchange + one addition).  Two waves per SIMD (256 registers).
+__global__ __launch_bounds__(kBlock, 2) void k_msm_tables_g1(size_t n, size_t pts_stride, const uint8_t* __restrict__ points,
+                                                           const uint32_t* __restrict__ scalars, size_t B, int32_t* __restrict__ tbl,
+                                                           uint8_t* __restrict__ codes, uint8_t* __restrict__ status) {
+  const size_t chunks = msm_chunks(n);
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= B * chunks) return;
+  const size_t j = tid / chunks, c = tid % chunks;
+  const size_t shares4 = chunks * kMsmChunk;
+  const bool ok = job_msm_tables_g1(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + j * shares4 * 8 * kMsmEntryWordsG1,
+                                    codes + j * kMsmColumns * shares4);
+  if (!ok && status[j] == TC_JOB_OK) status[j] = TC_JOB_INVALID_ENCODING;
+}
+__device__ __forceinline__ Fq msm_from_lane(const Fq& v, int lanes) {
+  Fq r = v;
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = __shfl_xor(v.l[i], lanes, 64);
+  return r;
+}
+template <bool SPLIT>
+__global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B, const int32_t* __restrict__ tbl, const uint8_t* __restrict__ codes,
+                                                           uint8_t* __restrict__ out, const uint8_t* __restrict__ status, size_t parts) {
+  const size_t lp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t j = lp / parts, g = lp % parts;
+  if (j >= B) return;  // (parts divides 64: a job's lanes leave together)
+  if (status[j] != TC_JOB_OK) {
+    if (g == 0) g1_encode_uncompressed(G1Affine::infinity(), out + j * 96);
+    return;
+  }
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  G1Jac r = job_msm_ladder_g1_part<SPLIT>(n, tbl + j * shares4 * 8 * kMsmEntryWordsG1, codes + j * kMsmColumns * shares4, msm_part(n, g, parts));
+  if (SPLIT) {
+    TC_NOUNROLL for (size_t d = 1; d < parts; d <<= 1) {
+      const G1Jac o{msm_from_lane(r.x, (int)d), msm_from_lane(r.y, (int)d), msm_from_lane(r.z, (int)d)};
+      r = jac_add(r, o);
+    }
+  }
+  if (g == 0) g1_encode_uncompressed(jac_to_affine(r), out + j * 96);
+}
+
+size_t msm_table_bytes_g1(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWordsG1 * sizeof(int32_t); }
+// status: B bytes, TC_JOB_OK for the jobs to run (others get the identity and keep their status)
+void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B, int32_t* tbl,
+                   uint8_t* codes, uint8_t* out, uint8_t* status) {
+  if (!B || !n) return;
+  hipLaunchKernelGGL(k_msm_tables_g1, dim3(grid_for(B * msm_chunks(n))), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status);
+  // lanes per job in stage L: 1 when the batch fills the 2048 wave slots by itself (131 072 lanes), else the power of two
+  // that does, with at least four shares per part
+  size_t parts = 1;
+  while (parts < 64 && B * parts * 2 <= 131072 && parts * 2 * 4 <= n) parts *= 2;
+  if (parts == 1)
+    hipLaunchKernelGGL(k_msm_ladder_g1<false>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
+                       (const uint8_t*)status, parts);
+  else
+    hipLaunchKernelGGL(k_msm_ladder_g1<true>, dim3(grid_for(B * parts)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
+                       (const uint8_t*)status, parts);
+}
+
 size_t msm_table_bytes(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWords * sizeof(int32_t); }
 size_t msm_code_bytes(size_t n, size_t B) { return B * kMsmColumns * msm_chunks(n) * kMsmChunk; }
 // status: B bytes, TC_JOB_OK for the jobs to run (others get the identity and keep their status)

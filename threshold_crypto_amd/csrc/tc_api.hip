@@ -44,6 +44,7 @@ struct tc_ctx {
   uint32_t* tbl_flags = nullptr;
   bool tbl_reset = false;  // a call failed: a kernel may have died holding slots, clear the flags before the next use
   int cus = 0;
+  uint64_t h2d_bytes = 0, d2h_bytes = 0;  // bytes this context's staging copies moved over PCIe (tc_ctx_transfer_bytes)
 };
 
 namespace {
@@ -116,6 +117,7 @@ struct Call {
     void* d = scratch(n);
     if (!d) return nullptr;
     if (n && !check(hipMemcpyAsync(d, p, n, hipMemcpyHostToDevice, c->stream), "H2D copy")) return nullptr;
+    c->h2d_bytes += n;
     if (secret) wipe.emplace_back(d, n);
     return (const T*)d;
   }
@@ -177,7 +179,10 @@ struct Call {
     for (auto& w : wipe) (void)hipMemsetAsync(w.first, 0, w.second, c->stream);  // zero secret scalars
     if (!failed)
       for (auto& o : outs)
-        if (o.n) check(hipMemcpyAsync(o.host, o.dev, o.n, hipMemcpyDeviceToHost, c->stream), "D2H copy");
+        if (o.n) {
+          check(hipMemcpyAsync(o.host, o.dev, o.n, hipMemcpyDeviceToHost, c->stream), "D2H copy");
+          c->d2h_bytes += o.n;
+        }
     if (!c->device_io || c->timing || failed) {
       hipError_t e = hipStreamSynchronize(c->stream);
       if (!failed) check(e, "stream sync");
@@ -207,6 +212,7 @@ bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
     return true;
   }
   if (!k.check(hipMemcpyAsync(total, off + B, 8, hipMemcpyDeviceToHost, k.c->stream), "offset readback")) return false;
+  k.c->d2h_bytes += 8;
   return k.check(hipStreamSynchronize(k.c->stream), "stream sync");
 }
 
@@ -215,10 +221,23 @@ bool total_bytes(Call& k, const uint64_t* off, size_t B, uint64_t* total) {
 // whose tables would exceed kMsmTableBudget run as consecutive tiles of jobs through ONE table buffer (the stream
 // orders a tile's ladder before the next tile's table stage).
 constexpr size_t kMsmTableBudget = (size_t)24 << 30;
+// What a call may spend on table buffers: a third of the HBM that is free right now (plus whatever the context's staging
+// slots already hold), at most 24 GiB, at least 1 GiB -- several contexts on one GPU, or a smaller card, tile their batches
+// finer instead of failing an allocation.  tc_ctx_trim() gives the slots back.
+size_t msm_table_budget(Call& k) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)1 << 30;
+  size_t held = 0;
+  for (auto& s : k.c->slots) held += s.cap;
+  size_t b = (free_b + held) / 3;
+  if (b > kMsmTableBudget) b = kMsmTableBudget;
+  if (b < ((size_t)1 << 30)) b = (size_t)1 << 30;
+  return b;
+}
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
             uint8_t* d_st, int nbits = 64, tc::MsmFilter filter = tc::MsmFilter()) {
   const size_t per_job = tc::msm_table_bytes(n, 1);
-  size_t tile = kMsmTableBudget / (per_job ? per_job : 1);
+  size_t tile = msm_table_budget(k) / (per_job ? per_job : 1);
   if (tile < 1) tile = 1;
   if (tile > B) tile = B;
   int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes(n, tile) / sizeof(int32_t));
@@ -229,6 +248,20 @@ void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const ui
     if (f.idx) f.idx += lo * f.n_per_job;
     tc::launch_msm_g2(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 192,
                       d_st + lo, nbits, f);
+  }
+}
+
+// the same in G1 (k_msm.hip launch_msm_g1)
+void msm_g1(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out, uint8_t* d_st) {
+  const size_t per_job = tc::msm_table_bytes_g1(n, 1);
+  size_t tile = msm_table_budget(k) / (per_job ? per_job : 1);
+  if (tile < 1) tile = 1;
+  if (tile > B) tile = B;
+  int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes_g1(n, tile) / sizeof(int32_t));
+  uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, tile));
+  for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
+    const size_t cnt = (B - lo < tile) ? B - lo : tile;
+    tc::launch_msm_g1(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 96, d_st + lo);
   }
 }
 
@@ -307,6 +340,27 @@ int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream) {
 int tc_ctx_set_input_checks(tc_ctx* ctx, int enabled) {
   if (!ctx) return TC_ERR_INVALID_ARG;
   ctx->input_checks = enabled != 0;
+  return TC_OK;
+}
+
+// gives the context's grow-only staging / table buffers back to the device (they are allocated again on demand)
+int tc_ctx_trim(tc_ctx* ctx) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return TC_ERR_HIP;
+  for (auto& s : ctx->slots) {
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr;
+    s.cap = 0;
+  }
+  return TC_OK;
+}
+
+int tc_ctx_get_input_checks(const tc_ctx* ctx) { return (ctx && ctx->input_checks) ? 1 : 0; }
+
+int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
+  if (!ctx) return TC_ERR_INVALID_ARG;
+  if (h2d_bytes) *h2d_bytes = ctx->h2d_bytes;
+  if (d2h_bytes) *d2h_bytes = ctx->d2h_bytes;
   return TC_OK;
 }
 
@@ -416,7 +470,7 @@ int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, cons
     // many signers per message: the doublings are done once per message, on a comb of its table (k_comb.hip); the combs
     // (133 KB per message) live in one HBM buffer, messages run through it in tiles
     const size_t per_msg = tc::comb_table_bytes(1);
-    size_t tile = kMsmTableBudget / per_msg;
+    size_t tile = msm_table_budget(k) / per_msg;
     if (tile < 1) tile = 1;
     if (tile > B) tile = B;
     int32_t* d_tbl = k.temp<int32_t>(tc::comb_table_bytes(tile) / sizeof(int32_t));
@@ -534,8 +588,8 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
         msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st, 64, f);
       }
     }
-    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st,
-                               t + 1 >= tc::kMsmMinPoints ? nullptr : d_need);  // (k_lagrange_all does not count: every job is general)
+    else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds in G1: the same two stages
+    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need);
     k.apply_checks(B, d_st, d_pt, PB, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
   }
@@ -589,6 +643,10 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
       uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
       if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
       msm_g2(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
+    } else if (n >= tc::kMsmMinPoints) {
+      uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
+      if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
+      msm_g1(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
     } else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
   }
   k.apply_checks(B, d_st, d_out, PB, nullptr);
@@ -731,6 +789,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
   uint8_t* d_seed = k.temp<uint8_t>(32);
   if (d_seed) {
     k.check(hipMemcpyAsync(d_seed, seed32, 32, hipMemcpyHostToDevice, ctx->stream), "seed copy");
+    ctx->h2d_bytes += 32;
     k.wipe.emplace_back(d_seed, 32);
   }
   uint8_t* d_r = k.temp<uint8_t>(B * N * 32);
@@ -761,6 +820,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
     k.check(hipMemcpyAsync(h_okmsg.data(), d_okmsg, B, hipMemcpyDeviceToHost, ctx->stream), "ok readback");
     std::vector<uint8_t> h_stS(B);
     k.check(hipMemcpyAsync(h_stS.data(), d_stS, B, hipMemcpyDeviceToHost, ctx->stream), "status readback");
+    ctx->d2h_bytes += 2 * B;
     k.check(hipStreamSynchronize(ctx->stream), "stream sync");
     std::vector<uint32_t> failed;
     if (!k.failed)
@@ -785,6 +845,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
         k.check(hipMemcpyAsync(d_maps, m_sig.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
         k.check(hipMemcpyAsync(d_maps + R, m_hash.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
         k.check(hipMemcpyAsync(d_maps + 2 * R, m_pk.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        ctx->h2d_bytes += 12 * R;
         tc::launch_gather_rows(ctx->stream, d_sig, 192, d_maps, R, c_sig);
         tc::launch_gather_rows(ctx->stream, d_hash, 192, d_maps + R, R, c_hash);
         tc::launch_gather_rows(ctx->stream, d_pk, 96, d_maps + 2 * R, R, c_pk);

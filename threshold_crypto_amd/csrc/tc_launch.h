@@ -89,6 +89,12 @@ size_t msm_code_bytes(size_t n, size_t B);
 void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B,
                    int32_t* tbl, uint8_t* codes, uint8_t* out, uint8_t* status, int nbits = 64, MsmFilter f = MsmFilter());
 
+// the same two stages in G1 (threshold decryption and G1 linear combinations from kMsmMinPoints points on): codes as for G2
+// (msm_code_bytes), tables of msm_table_bytes_g1
+size_t msm_table_bytes_g1(size_t n, size_t B);
+void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B, int32_t* tbl,
+                   uint8_t* codes, uint8_t* out, uint8_t* status);
+
 // opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
 // records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an
 // invalid point (status INVALID_ENCODING + identity output, or ok = 0); job j owns record j / group

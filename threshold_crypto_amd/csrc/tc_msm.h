@@ -166,4 +166,181 @@ TC_HD G2Jac job_msm_ladder(size_t n, const int32_t* tbl, const uint8_t* codes, i
   return job_msm_ladder_part<false>(n, tbl, codes, nbits, msm_part(n));
 }
 
+// ---- the same two stages in G1 (threshold decryption at large thresholds: PublicKeySet::decrypt, ---------------------
+// /root/reference/src/lib.rs:618-626, at t = 67; tc_g1_lincomb_batch from 8 points on) ---------------------------------
+// G1 has the 2-dimensional GLV decomposition k = k1 + k2 x^2 with 128-bit halves (tc_gls.h), sign-aligned over 129
+// columns:  k1 = sum_i s_i 2^i,  k2 = sum_i s_i u_i 2^i  (s_i = +-1, s_128 = +1, u_i in {0, 1}).  To run the SAME ladder as
+// G2 -- 64 steps, one table look-up and one mixed addition per share and step, an 8-entry table per share -- the columns
+// are taken two at a time (base 4): columns 2c and 2c+1 contribute
+//     4^c sigma (A P + B phi'),   phi' = -phi(P) = [x^2] P,  sigma = s_{2c+1},
+//     A = 2 + e in {1, 3},  B = e u_{2c} + 2 u_{2c+1},  e = s_{2c} s_{2c+1}
+// i.e. one of  { P, P - phi', P + 2 phi', P + phi',  3P, 3P + phi', 3P + 2 phi', 3P + 3 phi' }  (index u_{2c} + 2 u_{2c+1},
+// + 4 when e = +1), added or subtracted; the top column (i = 128) starts the accumulator with P or P + phi'.  A step of
+// the ladder is TWO doublings + the additions: per share 64 mixed additions + a table of six affine additions + 1/2
+// inversion, per job 128 doublings -- instead of 255 doublings + ~240 additions per chunk of four shares in the per-lane
+// Straus ladders (tc_threshold.h straus_chunk).  One lane per job (G1), tables of 128 B per entry in HBM.
+constexpr int kMsmEntryWordsG1 = 32;  // x: 14 limbs + 2 words (word 15: infinity flag), y: 14 limbs + 2 words
+
+TC_HD void msm_store_entry_g1(int32_t* e, const G1Affine& p) {
+  const Fq x = p.x.norm(), y = p.y.norm();
+#if defined(TC_BOUND_CHECK)
+  if (x.val() > 2.1f || y.val() > 2.1f) tc_bound_fail(x.val(), y.val());
+#endif
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    e[i] = x.l[i];
+    e[16 + i] = y.l[i];
+  }
+  e[14] = 0;
+  e[15] = p.inf ? 1 : 0;
+  e[30] = e[31] = 0;
+}
+TC_HD G1Affine msm_load_entry_g1(const int32_t* e) {
+  G1Affine p;
+  p.x = tbl_load_fq((const tbl_word*)e);
+  p.y = tbl_load_fq((const tbl_word*)e + 16);
+  p.inf = e[15] != 0;
+  return p;
+}
+// k (8 canonical words, < r) -> the 65 column codes of the base-4 sign-aligned form above, written `stride` bytes apart:
+// bits 0..2 table index, bit 3 = subtract (columns 0 .. 63); column 64: the index of the starting entry (0 or 3).
+// Returns true when r - k was recoded instead of k (k even; k1 = k mod x^2 must be odd): the caller negates the bases.
+TC_HD bool msm_g1_recode(const uint32_t* k, uint8_t* codes, size_t stride) {
+  const bool flip = (k[0] & 1u) == 0;
+  uint32_t kk[8];
+  uint32_t borrow = 0;
+  TC_UNROLL for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)FR_P[i] - k[i] - borrow;
+    borrow = (uint32_t)(t >> 63);
+    kk[i] = flip ? (uint32_t)t : k[i];
+  }
+  tc_u128 k1, k2;
+  glv_decompose(kk, &k1, &k2);
+  const tc_u128 neg = ~((k1 | 1) >> 1);  // bit i: s_i = -1 (i < 128)
+  tc_u128 u = 0;
+  TC_NOUNROLL for (int i = 0; i < 128; i++) {
+    const tc_u128 odd = k2 & 1;
+    u |= odd << i;
+    k2 = (k2 >> 1) + (odd & (neg >> i));
+  }
+  TC_NOUNROLL for (int c = 0; c < 64; c++) {
+    const uint32_t n0 = (uint32_t)(neg >> (2 * c)) & 1u, n1 = (uint32_t)(neg >> (2 * c + 1)) & 1u;
+    const uint32_t u0 = (uint32_t)(u >> (2 * c)) & 1u, u1 = (uint32_t)(u >> (2 * c + 1)) & 1u;
+    codes[(size_t)c * stride] = (uint8_t)(u0 | (u1 << 1) | ((n0 == n1 ? 1u : 0u) << 2) | (n1 << 3));
+  }
+  codes[(size_t)64 * stride] = (uint8_t)(k2 ? 3 : 0);  // u_128
+  return flip;
+}
+
+// Stage T in G1 for the chunk `c` of one job: tbl = (4 * chunks) shares x 8 entries x 32 words; codes: 65 columns x
+// (4 * chunks) shares, one byte each.
+TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes) {
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  G1Affine b0[kMsmChunk];
+  G1Jac mult[2 * kMsmChunk];  // 2P, 3P
+  bool ok = true;
+  TC_NOUNROLL for (int k = 0; k < kMsmChunk; k++) {
+    const size_t s = c * kMsmChunk + k;
+    G1Affine p = G1Affine::infinity();
+    uint32_t sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < n) {
+      ok &= g1_decode_uncompressed(points + s * 96, p);
+      for (int w = 0; w < 8; w++) sc[w] = scalars[s * 8 + w];
+      ok &= limbs_lt_p<FrParams>(sc);
+    }
+    if (!ok) p = G1Affine::infinity();
+    const bool flip = msm_g1_recode(sc, codes + s, shares4);
+    p.y = Fq::select(flip, -p.y, p.y).norm();
+    b0[k] = p;
+    mult[2 * k] = jac_dbl(G1Jac::from_affine(p));
+    mult[2 * k + 1] = jac_add_mixed(mult[2 * k], p);
+  }
+  // 2P and 3P of the four shares to affine with one inversion
+  G1Affine ma[2 * kMsmChunk];
+  jac_batch_to_affine<Fq, 2 * kMsmChunk>(mult, ma, 2 * kMsmChunk);
+  G1Jac sums[6 * kMsmChunk];
+  TC_NOUNROLL for (int k = 0; k < kMsmChunk; k++) {
+    const G1Affine p = b0[k], p2 = ma[2 * k], p3 = ma[2 * k + 1];
+    G1Affine f1 = g1_phi(p), f2 = g1_phi(p2), f3 = g1_phi(p3);  // phi' = -phi: negate y below
+    G1Affine m1 = f1;                                            // -phi' (P) = phi(P)
+    f1.y = (-f1.y).norm();
+    f2.y = (-f2.y).norm();
+    f3.y = (-f3.y).norm();
+    sums[6 * k + 0] = jac_add_affine(p, m1);   // index 1: P - phi'
+    sums[6 * k + 1] = jac_add_affine(p, f2);   // index 2: P + 2 phi'
+    sums[6 * k + 2] = jac_add_affine(p, f1);   // index 3: P + phi'
+    sums[6 * k + 3] = jac_add_affine(p3, f1);  // index 5: 3P + phi'
+    sums[6 * k + 4] = jac_add_affine(p3, f2);  // index 6: 3P + 2 phi'
+    sums[6 * k + 5] = jac_add_affine(p3, f3);  // index 7: 3P + 3 phi'
+  }
+  G1Affine aff[6 * kMsmChunk];
+  jac_batch_to_affine<Fq, 6 * kMsmChunk>(sums, aff, 6 * kMsmChunk);
+  TC_NOUNROLL for (int k = 0; k < kMsmChunk; k++) {
+    const size_t s = c * kMsmChunk + k;
+    int32_t* t = tbl + s * 8 * kMsmEntryWordsG1;
+    msm_store_entry_g1(t, b0[k]);
+    msm_store_entry_g1(t + 4 * kMsmEntryWordsG1, ma[2 * k + 1]);
+    TC_NOUNROLL for (int m = 0; m < 3; m++) {
+      msm_store_entry_g1(t + (1 + m) * kMsmEntryWordsG1, aff[6 * k + m]);
+      msm_store_entry_g1(t + (5 + m) * kMsmEntryWordsG1, aff[6 * k + 3 + m]);
+    }
+  }
+  return ok;
+}
+
+// Stage L in G1 (one lane per part of a job): every special case of the addition handled -- the slow path and the
+// g++ reference of the fast form below
+TC_HD_NOINLINE G1Jac job_msm_ladder_g1_safe(size_t n, const int32_t* tbl, const uint8_t* codes, MsmPart part) {
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  G1Jac acc = G1Jac::infinity();
+  TC_NOUNROLL for (int col = 64; col >= 0; col--) {
+    if (col != 64) acc = jac_dbl(jac_dbl(acc));
+    const uint8_t* cc = codes + (size_t)col * shares4;
+    TC_NOUNROLL for (size_t t = 0; t < part.trips; t++) {
+      const bool take = part.s0 + t < part.s1;
+      const size_t s = take ? part.s0 + t : part.s0;
+      const uint32_t code = cc[s];
+      G1Affine e = msm_load_entry_g1(tbl + (s * 8 + (code & 7)) * kMsmEntryWordsG1);
+      if (col != 64) e.y = Fq::select((code >> 3) & 1, -e.y, e.y);
+      acc = G1Jac::select(take, jac_add_mixed(acc, e), acc);
+    }
+  }
+  return acc;
+}
+template <bool SPLIT>
+TC_HD G1Jac job_msm_ladder_g1_part(size_t n, const int32_t* tbl, const uint8_t* codes, MsmPart part) {
+  const size_t shares4 = msm_chunks(n) * kMsmChunk;
+  bool exc = false;
+  G1Jac acc;
+  TC_NOUNROLL for (int col = 64; col >= 0; col--) {
+    tc_fair();
+    const uint8_t* cc = codes + (size_t)col * shares4;
+    size_t t = 0;
+    if (col != 64) {
+      acc = jac_dbl(jac_dbl(acc));
+    } else {
+      const G1Affine e0 = msm_load_entry_g1(tbl + (part.s0 * 8 + (size_t)(cc[part.s0] & 7)) * kMsmEntryWordsG1);
+      acc = G1Jac::from_affine(e0);
+      exc = e0.inf;
+      t = 1;
+    }
+    TC_NOUNROLL for (; t < part.trips; t++) {
+      const bool take = !SPLIT || part.s0 + t < part.s1;
+      const size_t s = take ? part.s0 + t : part.s0;
+      const uint32_t code = cc[s];
+      G1Affine e = msm_load_entry_g1(tbl + (s * 8 + (code & 7)) * kMsmEntryWordsG1);
+      if (col != 64) e.y = Fq::select((code >> 3) & 1, -e.y, e.y);
+      if (SPLIT) {
+        bool hit = false;
+        const G1Jac sum = jac_add_mixed_generic(acc, e, hit);
+        exc = exc || (take && hit);
+        acc = G1Jac::select(take, sum, acc);
+      } else {
+        acc = jac_add_mixed_generic(acc, e, exc);
+      }
+    }
+  }
+  if (wave_any(exc)) acc = G1Jac::select(exc, job_msm_ladder_g1_safe(n, tbl, codes, part), acc);
+  return acc;
+}
+
 }  // namespace tc

@@ -78,6 +78,19 @@ class Engine:
         device first.  False is the explicit opt-out for operands known to be members (this library's own outputs)."""
         self._lib.tc_ctx_set_input_checks(self._ctx, 1 if on else 0)
 
+    def input_checks(self):
+        return bool(self._lib.tc_ctx_get_input_checks(self._ctx))
+
+    def trim(self):
+        """give the context's staging / table buffers back to the device (tc_ctx_trim)"""
+        self._lib.tc_ctx_trim(self._ctx)
+
+    def transfer_bytes(self):
+        """(host-to-device, device-to-host) bytes this context's staging copies have moved over PCIe"""
+        up, down = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._lib.tc_ctx_transfer_bytes(self._ctx, ctypes.byref(up), ctypes.byref(down))
+        return int(up.value), int(down.value)
+
     def last_kernel_ms(self):
         return float(self._lib.tc_last_kernel_ms(self._ctx))
 
@@ -499,10 +512,21 @@ class Group:
         self._call("tc_group_verify_g2", _ptr(sig), _ptr(hashes), B, _ptr(ok), ctypes.byref(nv))
         return ok, int(nv.value)
 
+    def transfer_bytes(self):
+        """(host-to-device, device-to-host) bytes the group and its contexts have moved over PCIe"""
+        up, down = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._call("tc_group_transfer_bytes", ctypes.byref(up), ctypes.byref(down))
+        return int(up.value), int(down.value)
+
     def sign_combine_verify(self, sk_table, idx, msgs, off):
         Engine._arg(sk_table, (None, FR_BYTES), "u8", "sk_table")
         Engine._arg(idx, (None, None), "u64", "idx")
         B, n = idx.shape
+        # the same operand validation as the single-GPU Engine: dtype, contiguity, B + 1 offsets (ADVICE r02)
+        Engine._arg(off, (B + 1,), "u64", "off")
+        Engine._arg(msgs, (None,), "u8", "msgs")
+        if int(off[0]) != 0 or (np.diff(off.astype(np.int64)) < 0).any() or int(off[-1]) > msgs.shape[0]:
+            raise ValueError("off must start at 0, be non-decreasing and end inside msgs")
         sig = np.empty((B, G2_BYTES), dtype=np.uint8)
         ok = np.empty(B, dtype=np.uint8)
         nv = ctypes.c_uint64(0)
