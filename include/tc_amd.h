@@ -175,6 +175,18 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk_g1, size_t pk_stride, con
  * number of messages that needed the per-share pass. */
 int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* sig_shares, const uint8_t* msgs,
                                const uint64_t* off, size_t B, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback);
+/* Signature batches under ONE public key by random linear combination (opt-in; BASELINE config 3's shape).  The batch
+ * is cut into groups of `group` jobs (0 = 64; at most 1024); a group passes with ONE check
+ *     e(pk, sum_j r_j H_j) == e(g1, sum_j r_j sig_j)        instead of `group` checks of src/lib.rs:108-110,
+ * r_j = 2^63 secret values from ChaCha20(seed32, j); groups that fail -- or hold an undecodable or non-member operand -- are
+ * re-checked job by job, so ok[] equals tc_verify_g2_batch's (pk_stride 0) up to the 2^-63 of a wrongly passing group.
+ * *n_fallback (optional) = jobs that went through the per-job checks.  seed32: 32 secret random bytes in HOST memory,
+ * drawn after the signatures were received.  tc_verify_sig_rlc_batch hashes the messages on the device first
+ * (PublicKey::verify, src/lib.rs:114-117). */
+int tc_verify_g2_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* hash, size_t B, size_t group,
+                           const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback);
+int tc_verify_sig_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* off, size_t B,
+                            size_t group, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback);
 /* ok[j] = Ciphertext(u[j], v[j], w[j]).verify() = e(g1, w) == e(u, hash_g1_g2(u, v))   src/lib.rs:508-512 */
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
                                const uint8_t* w_g2, size_t B, uint8_t* ok);

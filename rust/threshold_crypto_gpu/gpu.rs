@@ -1,0 +1,538 @@
+//! `src/gpu.rs` of threshold_crypto 0.4.0 behind the optional feature "mi355x": batch forms of the crate's hot-path
+//! methods on an AMD MI355X through libtc_amd.so (crate `tc_amd_sys`, generated from include/tc_amd.h).
+//!
+//! Drop-in: the single-item methods of the crate stay as they are (the `pairing` crate on the CPU); every method here is
+//! the same computation for B independent jobs and returns exactly what B calls of the single-item method return -- the
+//! library's results are bit-identical encodings of the same group elements.  The module lives INSIDE the crate because
+//! the tuple fields of `PublicKey(G1)`, `Signature(G2)`, `SecretKey(Box<Fr>)`, ... are private (src/lib.rs:80,194,296).
+//!
+//! SOURCE ONLY: the build image of the MI355X engine has no Rust toolchain, so this file has not been compiled there;
+//! `tests/test_abi.py::test_rust_bindings_match_header` keeps the FFI declarations it relies on in step with the header,
+//! and `test_rust_shim_calls_existing_entry_points_with_matching_arity` checks every call below against them.
+//!
+//! Rows of SURVEY.md section 8(a) and where they are:
+//!   A2  hash_g2                         hash_g2_batch
+//!   A4  SecretKey(Share)::sign / sign_g2  SecretKey::sign_batch, sign_g2_batch, SecretKeySet::sign_shares_batch
+//!   A5  SecretKeyShare::decrypt_share   SecretKeyShare::decrypt_share_no_verify_batch, decrypt_share_batch
+//!   A6/A7 PublicKeySet::combine_signatures  PublicKeySet::combine_signatures_batch
+//!   A8  PublicKeySet::decrypt           PublicKeySet::decrypt_batch
+//!   A9  PublicKey::verify / verify_g2   PublicKey::verify_batch, verify_g2_batch, verify_rlc_batch (opt-in)
+//!   A10 Ciphertext::verify              Ciphertext::verify_batch
+//!   A11 PublicKeyShare::verify_decryption_share  PublicKeyShare::verify_decryption_share_batch
+//!   A12 PublicKeySet::public_key_share  PublicKeySet::public_key_shares
+//!   A13 to_bytes / from_bytes           g1_to_bytes_batch, g2_to_bytes_batch, g1_from_bytes_batch, g2_from_bytes_batch
+//!   f2  share validation                PublicKeySet::verify_signature_shares_rlc (opt-in)
+//!   f3  PublicKey::encrypt              PublicKey::encrypt_batch
+//!   f4  Poly::commitment, BivarCommitment::row, Poly::interpolate   commitment_batch, bivar_commitment_rows, interpolate_batch
+//!   (e) several GPUs of one node        GpuGroup
+use crate::error::{Error, FromBytesError, Result};
+use crate::poly::{BivarCommitment, Commitment, Poly};
+use crate::{
+    Ciphertext, DecryptionShare, Fr, G1Affine, G2Affine, PublicKey, PublicKeySet, PublicKeyShare, SecretKey, SecretKeySet, SecretKeyShare,
+    Signature, SignatureShare, G1, G2,
+};
+use ff::{PrimeField, PrimeFieldRepr};
+use group::{CurveAffine, CurveProjective, EncodedPoint};
+use pairing::bls12_381::{FrRepr, G1Uncompressed, G2Uncompressed};
+use std::os::raw::c_int;
+use tc_amd_sys::*;
+
+pub const G1_BYTES: usize = 96;
+pub const G2_BYTES: usize = 192;
+pub const FR_BYTES: usize = 32;
+
+/// One context of libtc_amd.so bound to one MI355X.  There is no CPU fallback: `new` fails without a gfx950 device.
+pub struct Gpu(*mut TcCtx);
+unsafe impl Send for Gpu {}
+
+#[derive(Debug)]
+pub struct GpuError(pub c_int, pub String);
+
+impl Gpu {
+    pub fn new(device: i32) -> std::result::Result<Self, GpuError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { tc_ctx_create(&mut p, device as c_int) };
+        if rc == TC_OK {
+            Ok(Gpu(p))
+        } else {
+            Err(GpuError(rc, "tc_ctx_create failed (no gfx950 HIP device?)".into()))
+        }
+    }
+    /// Operands that are typed values of this crate are group members by construction (`from_bytes` checked them), so the
+    /// per-operand membership tests a context runs by default can be switched off for them.
+    pub fn trusted_operands(&self, trusted: bool) {
+        unsafe { tc_ctx_set_input_checks(self.0, if trusted { 0 } else { 1 }) };
+    }
+    fn check(&self, rc: c_int) {
+        if rc != TC_OK {
+            let msg = unsafe { std::ffi::CStr::from_ptr(tc_last_error(self.0)) }.to_string_lossy().into_owned();
+            panic!("libtc_amd call failed ({}): {}", rc, msg);
+        }
+    }
+}
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        unsafe { tc_ctx_destroy(self.0) }
+    }
+}
+
+// ---- encodings (the reference's own canonical forms) ------------------------------------------------------
+fn g1_bytes(p: &G1) -> [u8; G1_BYTES] {
+    let mut b = [0u8; G1_BYTES];
+    b.copy_from_slice(p.into_affine().into_uncompressed().as_ref());
+    b
+}
+fn g2_bytes(p: &G2) -> [u8; G2_BYTES] {
+    let mut b = [0u8; G2_BYTES];
+    b.copy_from_slice(p.into_affine().into_uncompressed().as_ref());
+    b
+}
+fn g1_from(b: &[u8]) -> G1 {
+    let mut u = G1Uncompressed::empty();
+    u.as_mut().copy_from_slice(b);
+    u.into_affine_unchecked().expect("libtc_amd returns canonical encodings").into_projective()
+}
+fn g2_from(b: &[u8]) -> G2 {
+    let mut u = G2Uncompressed::empty();
+    u.as_mut().copy_from_slice(b);
+    u.into_affine_unchecked().expect("libtc_amd returns canonical encodings").into_projective()
+}
+/// Fr as 4 little-endian u64 limbs of `into_repr()` (src/serde_impl.rs:296)
+fn fr_bytes(f: &Fr) -> [u8; FR_BYTES] {
+    let mut b = [0u8; FR_BYTES];
+    for (i, limb) in f.into_repr().as_ref().iter().enumerate() {
+        b[8 * i..8 * i + 8].copy_from_slice(&limb.to_le_bytes());
+    }
+    b
+}
+fn fr_from(b: &[u8]) -> Fr {
+    let mut r = FrRepr::default();
+    for (i, limb) in r.as_mut().iter_mut().enumerate() {
+        let mut w = [0u8; 8];
+        w.copy_from_slice(&b[8 * i..8 * i + 8]);
+        *limb = u64::from_le_bytes(w);
+    }
+    Fr::from_repr(r).expect("libtc_amd returns canonical scalars")
+}
+fn pack_messages<M: AsRef<[u8]>>(msgs: &[M]) -> (Vec<u8>, Vec<u64>) {
+    let mut flat = Vec::new();
+    let mut off = Vec::with_capacity(msgs.len() + 1);
+    off.push(0u64);
+    for m in msgs {
+        flat.extend_from_slice(m.as_ref());
+        off.push(flat.len() as u64);
+    }
+    if flat.is_empty() {
+        flat.push(0);
+    }
+    (flat, off)
+}
+fn status_to_result<T>(st: u8, v: T) -> Result<T> {
+    match st {
+        TC_JOB_OK => Ok(v),
+        TC_JOB_NOT_ENOUGH_SHARES => Err(Error::NotEnoughShares),
+        _ => Err(Error::DuplicateEntry),
+    }
+}
+
+// ---- A2: hash_g2 (src/lib.rs:691-694) ---------------------------------------------------------------------------------
+pub fn hash_g2_batch<M: AsRef<[u8]>>(gpu: &Gpu, msgs: &[M]) -> Vec<G2> {
+    let (flat, off) = pack_messages(msgs);
+    let mut out = vec![0u8; msgs.len() * G2_BYTES];
+    gpu.check(unsafe { tc_hash_g2_batch(gpu.0, flat.as_ptr(), off.as_ptr(), msgs.len(), out.as_mut_ptr()) });
+    out.chunks(G2_BYTES).map(g2_from).collect()
+}
+
+// ---- A4: signing (src/lib.rs:372-381, 442-449) -----------------------------------------------------------------------
+impl SecretKey {
+    /// `sign` for B messages: hash_g2 and the multiplication both on the device (tc_sign_batch, S = 1).
+    pub fn sign_batch<M: AsRef<[u8]>>(&self, gpu: &Gpu, msgs: &[M]) -> Vec<Signature> {
+        let (flat, off) = pack_messages(msgs);
+        let mut fr = fr_bytes(&self.0);
+        let (mut out, mut st) = (vec![0u8; msgs.len() * G2_BYTES], vec![0u8; msgs.len()]);
+        let rc = unsafe { tc_sign_batch(gpu.0, fr.as_ptr(), flat.as_ptr(), off.as_ptr(), 1, msgs.len(), out.as_mut_ptr(), st.as_mut_ptr()) };
+        fr.iter_mut().for_each(|b| *b = 0); // the reference zeroizes secrets (src/lib.rs:304-314)
+        gpu.check(rc);
+        assert!(st.iter().all(|&s| s == TC_JOB_OK));
+        out.chunks(G2_BYTES).map(|c| Signature(g2_from(c))).collect()
+    }
+    /// `sign_g2` for B pre-hashed messages (tc_g2_mul_batch, S = 1).
+    pub fn sign_g2_batch(&self, gpu: &Gpu, hashes: &[G2Affine]) -> Vec<Signature> {
+        let mut fr = fr_bytes(&self.0);
+        let mut pts = Vec::with_capacity(hashes.len() * G2_BYTES);
+        for h in hashes {
+            pts.extend_from_slice(h.into_uncompressed().as_ref());
+        }
+        let (mut out, mut st) = (vec![0u8; hashes.len() * G2_BYTES], vec![0u8; hashes.len()]);
+        let rc = unsafe { tc_g2_mul_batch(gpu.0, fr.as_ptr(), pts.as_ptr(), 1, hashes.len(), out.as_mut_ptr(), st.as_mut_ptr()) };
+        fr.iter_mut().for_each(|b| *b = 0);
+        gpu.check(rc);
+        assert!(st.iter().all(|&s| s == TC_JOB_OK));
+        out.chunks(G2_BYTES).map(|c| Signature(g2_from(c))).collect()
+    }
+}
+impl SecretKeyShare {
+    pub fn sign_batch<M: AsRef<[u8]>>(&self, gpu: &Gpu, msgs: &[M]) -> Vec<SignatureShare> {
+        self.0.sign_batch(gpu, msgs).into_iter().map(SignatureShare).collect()
+    }
+    pub fn sign_g2_batch(&self, gpu: &Gpu, hashes: &[G2Affine]) -> Vec<SignatureShare> {
+        self.0.sign_g2_batch(gpu, hashes).into_iter().map(SignatureShare).collect()
+    }
+}
+impl SecretKeySet {
+    /// The shares of B messages by per-message signer subsets, generated on the device from the key set
+    /// (tc_sign_shares_g2_batch): `signers[j]` lists the n share indices of message j; out[j][k] = share(signers[j][k]).sign_g2(hashes[j]).
+    pub fn sign_shares_batch(&self, gpu: &Gpu, n_nodes: usize, signers: &[Vec<u64>], hashes: &[G2Affine]) -> Vec<Vec<SignatureShare>> {
+        let b = hashes.len();
+        let n = signers.first().map(|s| s.len()).unwrap_or(0);
+        assert!(signers.len() == b && signers.iter().all(|s| s.len() == n));
+        let mut table = Vec::with_capacity(n_nodes * FR_BYTES);
+        for i in 0..n_nodes {
+            table.extend_from_slice(&fr_bytes(&(self.secret_key_share(i).0).0));
+        }
+        let idx: Vec<u64> = signers.iter().flatten().cloned().collect();
+        let mut pts = Vec::with_capacity(b * G2_BYTES);
+        for h in hashes {
+            pts.extend_from_slice(h.into_uncompressed().as_ref());
+        }
+        let (mut out, mut st) = (vec![0u8; b * n * G2_BYTES], vec![0u8; b * n]);
+        let rc = unsafe { tc_sign_shares_g2_batch(gpu.0, table.as_ptr(), n_nodes, idx.as_ptr(), pts.as_ptr(), n, b, out.as_mut_ptr(), st.as_mut_ptr()) };
+        table.iter_mut().for_each(|x| *x = 0);
+        gpu.check(rc);
+        assert!(st.iter().all(|&s| s == TC_JOB_OK));
+        out.chunks(n * G2_BYTES).map(|job| job.chunks(G2_BYTES).map(|c| SignatureShare(Signature(g2_from(c)))).collect()).collect()
+    }
+}
+
+// ---- A5: decryption shares (src/lib.rs:452-462) -----------------------------------------------------------------------
+impl SecretKeyShare {
+    /// `decrypt_share_no_verify` for B ciphertexts (tc_g1_mul_batch, S = 1).
+    pub fn decrypt_share_no_verify_batch(&self, gpu: &Gpu, cts: &[Ciphertext]) -> Vec<DecryptionShare> {
+        let mut fr = fr_bytes(&(self.0).0);
+        let mut pts = Vec::with_capacity(cts.len() * G1_BYTES);
+        for ct in cts {
+            pts.extend_from_slice(&g1_bytes(&ct.0));
+        }
+        let (mut out, mut st) = (vec![0u8; cts.len() * G1_BYTES], vec![0u8; cts.len()]);
+        let rc = unsafe { tc_g1_mul_batch(gpu.0, fr.as_ptr(), pts.as_ptr(), 1, cts.len(), out.as_mut_ptr(), st.as_mut_ptr()) };
+        fr.iter_mut().for_each(|b| *b = 0);
+        gpu.check(rc);
+        out.chunks(G1_BYTES).map(|c| DecryptionShare(g1_from(c))).collect()
+    }
+    /// `decrypt_share`: `None` where the ciphertext does not verify (src/lib.rs:452-457).
+    pub fn decrypt_share_batch(&self, gpu: &Gpu, cts: &[Ciphertext]) -> Vec<Option<DecryptionShare>> {
+        let ok = Ciphertext::verify_batch(gpu, cts);
+        let shares = self.decrypt_share_no_verify_batch(gpu, cts);
+        shares.into_iter().zip(ok).map(|(s, good)| if good { Some(s) } else { None }).collect()
+    }
+}
+
+// ---- A6 / A7 / A8 / A12: the key set (src/lib.rs:565-626, 719-773) -----------------------------------------------------
+impl PublicKeySet {
+    fn commit_bytes(&self) -> Vec<u8> {
+        self.commit.coeff.iter().flat_map(|c| g1_bytes(c).to_vec()).collect()
+    }
+    /// Batch form of `combine_signatures` (src/lib.rs:608-615).  `jobs[j]` iterates `(index, share)` in the order the
+    /// single-item method would see it (BTreeMap order); every job holds the same number of shares.
+    pub fn combine_signatures_batch<'a, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<Result<Signature>>
+    where
+        I: Clone + IntoIterator<Item = (u64, &'a SignatureShare)>,
+    {
+        let t = self.threshold();
+        let n = jobs.first().map(|j| j.clone().into_iter().count()).unwrap_or(0);
+        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * G2_BYTES));
+        for job in jobs {
+            for (i, s) in job.clone() {
+                idx.push(i);
+                shares.extend_from_slice(&g2_bytes(&(s.0).0));
+            }
+        }
+        assert_eq!(idx.len(), jobs.len() * n, "every job must hold the same number of shares");
+        let (mut out, mut st) = (vec![0u8; jobs.len() * G2_BYTES], vec![0u8; jobs.len()]);
+        gpu.check(unsafe { tc_combine_g2_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        st.iter().enumerate().map(|(j, &s)| status_to_result(s, Signature(g2_from(&out[j * G2_BYTES..(j + 1) * G2_BYTES])))).collect()
+    }
+    /// Batch form of `decrypt` (src/lib.rs:618-626): per job the shares of one ciphertext; returns the plaintexts.
+    pub fn decrypt_batch<'a, I>(&self, gpu: &Gpu, jobs: &[I], cts: &[Ciphertext]) -> Vec<Result<Vec<u8>>>
+    where
+        I: Clone + IntoIterator<Item = (u64, &'a DecryptionShare)>,
+    {
+        let t = self.threshold();
+        let n = jobs.first().map(|j| j.clone().into_iter().count()).unwrap_or(0);
+        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * G1_BYTES));
+        for job in jobs {
+            for (i, s) in job.clone() {
+                idx.push(i);
+                shares.extend_from_slice(&g1_bytes(&s.0));
+            }
+        }
+        let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
+        let (flat, off) = pack_messages(&vs);
+        let (mut out, mut st) = (vec![0u8; flat.len()], vec![0u8; jobs.len()]);
+        gpu.check(unsafe {
+            tc_decrypt_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
+        });
+        st.iter().enumerate().map(|(j, &s)| status_to_result(s, out[off[j] as usize..off[j + 1] as usize].to_vec())).collect()
+    }
+    /// `public_key_share(i)` for many indices (src/lib.rs:570-573 -> Commitment::evaluate, src/poly.rs:497-508).
+    pub fn public_key_shares(&self, gpu: &Gpu, indices: &[u64]) -> Vec<PublicKeyShare> {
+        let commit = self.commit_bytes();
+        let (mut out, mut st) = (vec![0u8; indices.len() * G1_BYTES], vec![0u8; indices.len()]);
+        gpu.check(unsafe { tc_public_key_share_batch(gpu.0, commit.as_ptr(), self.threshold(), indices.as_ptr(), indices.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        assert!(st.iter().all(|&s| s == TC_JOB_OK));
+        out.chunks(G1_BYTES).map(|c| PublicKeyShare(PublicKey(g1_from(c)))).collect()
+    }
+    /// The share-validation loop of examples/threshold_sig.rs:115-131 for B messages x N nodes by ONE random linear
+    /// combination per message (opt-in): ok[j][i] = pk_share(i).verify(&shares[j][i], msgs[j]).
+    pub fn verify_signature_shares_rlc<M: AsRef<[u8]>>(&self, gpu: &Gpu, n_nodes: usize, shares: &[Vec<SignatureShare>], msgs: &[M], seed: &[u8; 32]) -> Vec<Vec<bool>> {
+        let pks: Vec<u8> = self.public_key_shares(gpu, &(0..n_nodes as u64).collect::<Vec<_>>()).iter().flat_map(|p| g1_bytes(&(p.0).0).to_vec()).collect();
+        let mut sig = Vec::with_capacity(msgs.len() * n_nodes * G2_BYTES);
+        for job in shares {
+            assert_eq!(job.len(), n_nodes);
+            for s in job {
+                sig.extend_from_slice(&g2_bytes(&(s.0).0));
+            }
+        }
+        let (flat, off) = pack_messages(msgs);
+        let mut ok = vec![0u8; msgs.len() * n_nodes];
+        let mut fallback = 0u64;
+        gpu.check(unsafe {
+            tc_verify_shares_rlc_batch(gpu.0, pks.as_ptr(), n_nodes, sig.as_ptr(), flat.as_ptr(), off.as_ptr(), msgs.len(), seed.as_ptr(), ok.as_mut_ptr(), &mut fallback)
+        });
+        ok.chunks(n_nodes).map(|r| r.iter().map(|&b| b == 1).collect()).collect()
+    }
+}
+
+// ---- A9: verification (src/lib.rs:108-117) ----------------------------------------------------------------------------
+impl PublicKey {
+    /// Batch form of `verify`: one key, B (signature, message) pairs; hashing on the device.
+    pub fn verify_batch<M: AsRef<[u8]>>(&self, gpu: &Gpu, sigs: &[Signature], msgs: &[M]) -> Vec<bool> {
+        let pk = g1_bytes(&self.0);
+        let (flat, off) = pack_messages(msgs);
+        let mut s = Vec::with_capacity(sigs.len() * G2_BYTES);
+        for sig in sigs {
+            s.extend_from_slice(&g2_bytes(&sig.0));
+        }
+        let mut ok = vec![0u8; sigs.len()];
+        gpu.check(unsafe { tc_verify_sig_batch(gpu.0, pk.as_ptr(), 0 /* broadcast the key */, s.as_ptr(), flat.as_ptr(), off.as_ptr(), sigs.len(), ok.as_mut_ptr()) });
+        ok.into_iter().map(|b| b == 1).collect()
+    }
+    /// Batch form of `verify_g2` (src/lib.rs:108-110): pre-hashed messages.
+    pub fn verify_g2_batch(&self, gpu: &Gpu, sigs: &[Signature], hashes: &[G2Affine]) -> Vec<bool> {
+        let pk = g1_bytes(&self.0);
+        let (mut s, mut h) = (Vec::with_capacity(sigs.len() * G2_BYTES), Vec::with_capacity(sigs.len() * G2_BYTES));
+        for (sig, hash) in sigs.iter().zip(hashes) {
+            s.extend_from_slice(&g2_bytes(&sig.0));
+            h.extend_from_slice(hash.into_uncompressed().as_ref());
+        }
+        let mut ok = vec![0u8; sigs.len()];
+        gpu.check(unsafe { tc_verify_g2_batch(gpu.0, pk.as_ptr(), 0, s.as_ptr(), h.as_ptr(), sigs.len(), ok.as_mut_ptr()) });
+        ok.into_iter().map(|b| b == 1).collect()
+    }
+    /// The same booleans as `verify_batch` through one random linear combination per group of 64 jobs (opt-in;
+    /// groups that fail are re-checked job by job).  `seed`: 32 secret random bytes drawn after the signatures arrived.
+    pub fn verify_rlc_batch<M: AsRef<[u8]>>(&self, gpu: &Gpu, sigs: &[Signature], msgs: &[M], seed: &[u8; 32]) -> Vec<bool> {
+        let pk = g1_bytes(&self.0);
+        let (flat, off) = pack_messages(msgs);
+        let mut s = Vec::with_capacity(sigs.len() * G2_BYTES);
+        for sig in sigs {
+            s.extend_from_slice(&g2_bytes(&sig.0));
+        }
+        let mut ok = vec![0u8; sigs.len()];
+        let mut fallback = 0u64;
+        gpu.check(unsafe { tc_verify_sig_rlc_batch(gpu.0, pk.as_ptr(), s.as_ptr(), flat.as_ptr(), off.as_ptr(), sigs.len(), 0, seed.as_ptr(), ok.as_mut_ptr(), &mut fallback) });
+        ok.into_iter().map(|b| b == 1).collect()
+    }
+    /// `encrypt_with_rng` for B messages (src/lib.rs:128-137); the Fr draws come from the caller's RNG, in order.
+    pub fn encrypt_batch<R: rand::Rng, M: AsRef<[u8]>>(&self, gpu: &Gpu, rng: &mut R, msgs: &[M]) -> Vec<Ciphertext> {
+        let pk = g1_bytes(&self.0);
+        let mut r = Vec::with_capacity(msgs.len() * FR_BYTES);
+        for _ in msgs {
+            let f: Fr = rng.gen04();
+            r.extend_from_slice(&fr_bytes(&f));
+        }
+        let (flat, off) = pack_messages(msgs);
+        let (mut u, mut v, mut w, mut st) = (vec![0u8; msgs.len() * G1_BYTES], vec![0u8; flat.len()], vec![0u8; msgs.len() * G2_BYTES], vec![0u8; msgs.len()]);
+        let rc = unsafe {
+            tc_encrypt_batch(gpu.0, pk.as_ptr(), 0, r.as_ptr(), flat.as_ptr(), off.as_ptr(), msgs.len(), u.as_mut_ptr(), v.as_mut_ptr(), w.as_mut_ptr(), st.as_mut_ptr())
+        };
+        r.iter_mut().for_each(|b| *b = 0);
+        gpu.check(rc);
+        (0..msgs.len()).map(|j| Ciphertext(g1_from(&u[j * G1_BYTES..(j + 1) * G1_BYTES]), v[off[j] as usize..off[j + 1] as usize].to_vec(), g2_from(&w[j * G2_BYTES..(j + 1) * G2_BYTES]))).collect()
+    }
+}
+
+// ---- A10 / A11: ciphertexts (src/lib.rs:182-186, 508-512) -------------------------------------------------------------
+impl Ciphertext {
+    /// Batch form of `verify` (src/lib.rs:508-512).
+    pub fn verify_batch(gpu: &Gpu, cts: &[Ciphertext]) -> Vec<bool> {
+        let (mut u, mut w) = (Vec::with_capacity(cts.len() * G1_BYTES), Vec::with_capacity(cts.len() * G2_BYTES));
+        for ct in cts {
+            u.extend_from_slice(&g1_bytes(&ct.0));
+            w.extend_from_slice(&g2_bytes(&ct.2));
+        }
+        let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
+        let (flat, off) = pack_messages(&vs);
+        let mut ok = vec![0u8; cts.len()];
+        gpu.check(unsafe { tc_ciphertext_verify_batch(gpu.0, u.as_ptr(), flat.as_ptr(), off.as_ptr(), w.as_ptr(), cts.len(), ok.as_mut_ptr()) });
+        ok.into_iter().map(|b| b == 1).collect()
+    }
+}
+impl PublicKeyShare {
+    /// Batch form of `verify_decryption_share` (src/lib.rs:182-186): one key share, B (share, ciphertext) pairs.
+    pub fn verify_decryption_share_batch(&self, gpu: &Gpu, shares: &[DecryptionShare], cts: &[Ciphertext]) -> Vec<bool> {
+        let pk = g1_bytes(&(self.0).0);
+        let (mut s, mut u, mut w) = (Vec::new(), Vec::new(), Vec::new());
+        for (sh, ct) in shares.iter().zip(cts) {
+            s.extend_from_slice(&g1_bytes(&sh.0));
+            u.extend_from_slice(&g1_bytes(&ct.0));
+            w.extend_from_slice(&g2_bytes(&ct.2));
+        }
+        let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
+        let (flat, off) = pack_messages(&vs);
+        let mut ok = vec![0u8; shares.len()];
+        gpu.check(unsafe {
+            tc_verify_decryption_share_batch(gpu.0, pk.as_ptr(), 0, s.as_ptr(), u.as_ptr(), flat.as_ptr(), off.as_ptr(), w.as_ptr(), shares.len(), ok.as_mut_ptr())
+        });
+        ok.into_iter().map(|b| b == 1).collect()
+    }
+}
+
+// ---- A13: wire formats (src/lib.rs:140-153, 246-259) ------------------------------------------------------------------
+pub fn g1_to_bytes_batch(gpu: &Gpu, pts: &[G1]) -> Vec<[u8; 48]> {
+    let inp: Vec<u8> = pts.iter().flat_map(|p| g1_bytes(p).to_vec()).collect();
+    let (mut out, mut st) = (vec![0u8; pts.len() * 48], vec![0u8; pts.len()]);
+    gpu.check(unsafe { tc_g1_compress_batch(gpu.0, inp.as_ptr(), pts.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+    out.chunks(48).map(|c| { let mut a = [0u8; 48]; a.copy_from_slice(c); a }).collect()
+}
+pub fn g2_to_bytes_batch(gpu: &Gpu, pts: &[G2]) -> Vec<[u8; 96]> {
+    let inp: Vec<u8> = pts.iter().flat_map(|p| g2_bytes(p).to_vec()).collect();
+    let (mut out, mut st) = (vec![0u8; pts.len() * 96], vec![0u8; pts.len()]);
+    gpu.check(unsafe { tc_g2_compress_batch(gpu.0, inp.as_ptr(), pts.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+    out.chunks(96).map(|c| { let mut a = [0u8; 96]; a.copy_from_slice(c); a }).collect()
+}
+/// `PublicKey::from_bytes` for B encodings: the CHECKED decode (on the curve and in the order-r subgroup).
+pub fn g1_from_bytes_batch(gpu: &Gpu, enc: &[[u8; 48]]) -> Vec<std::result::Result<G1, FromBytesError>> {
+    let inp: Vec<u8> = enc.iter().flat_map(|e| e.to_vec()).collect();
+    let (mut out, mut st) = (vec![0u8; enc.len() * G1_BYTES], vec![0u8; enc.len()]);
+    gpu.check(unsafe { tc_g1_decompress_batch(gpu.0, inp.as_ptr(), enc.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+    st.iter().enumerate().map(|(j, &s)| if s == TC_JOB_OK { Ok(g1_from(&out[j * G1_BYTES..(j + 1) * G1_BYTES])) } else { Err(FromBytesError::Invalid) }).collect()
+}
+pub fn g2_from_bytes_batch(gpu: &Gpu, enc: &[[u8; 96]]) -> Vec<std::result::Result<G2, FromBytesError>> {
+    let inp: Vec<u8> = enc.iter().flat_map(|e| e.to_vec()).collect();
+    let (mut out, mut st) = (vec![0u8; enc.len() * G2_BYTES], vec![0u8; enc.len()]);
+    gpu.check(unsafe { tc_g2_decompress_batch(gpu.0, inp.as_ptr(), enc.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+    st.iter().enumerate().map(|(j, &s)| if s == TC_JOB_OK { Ok(g2_from(&out[j * G2_BYTES..(j + 1) * G2_BYTES])) } else { Err(FromBytesError::Invalid) }).collect()
+}
+
+// ---- f4: DKG algebra (src/poly.rs:372-377, 388-417, 694-727) ------------------------------------------------------------
+/// `Poly::commitment` for several polynomials at once: one fixed-base multiplication per coefficient.
+pub fn commitment_batch(gpu: &Gpu, polys: &[&Poly]) -> Vec<Commitment> {
+    let mut fr = Vec::new();
+    for p in polys {
+        for c in &p.coeff {
+            fr.extend_from_slice(&fr_bytes(c));
+        }
+    }
+    let m = fr.len() / FR_BYTES;
+    let (mut out, mut st) = (vec![0u8; m * G1_BYTES], vec![0u8; m]);
+    let rc = unsafe { tc_g1_commitment_batch(gpu.0, fr.as_ptr(), m, out.as_mut_ptr(), st.as_mut_ptr()) };
+    fr.iter_mut().for_each(|b| *b = 0);
+    gpu.check(rc);
+    let mut pts = out.chunks(G1_BYTES).map(g1_from);
+    polys.iter().map(|p| Commitment { coeff: (0..p.coeff.len()).map(|_| pts.next().unwrap()).collect() }).collect()
+}
+/// `BivarCommitment::row(x)` for several x.
+pub fn bivar_commitment_rows(gpu: &Gpu, c: &BivarCommitment, xs: &[u64]) -> Vec<Commitment> {
+    let inp: Vec<u8> = c.coeff.iter().flat_map(|p| g1_bytes(p).to_vec()).collect();
+    let d = c.degree();
+    let (mut out, mut st) = (vec![0u8; xs.len() * (d + 1) * G1_BYTES], vec![0u8; xs.len() * (d + 1)]);
+    gpu.check(unsafe { tc_bivar_commitment_row_batch(gpu.0, inp.as_ptr(), d, xs.as_ptr(), xs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+    out.chunks((d + 1) * G1_BYTES).map(|row| Commitment { coeff: row.chunks(G1_BYTES).map(g1_from).collect() }).collect()
+}
+/// `Poly::interpolate` for B sample sets of n points each.
+pub fn interpolate_batch(gpu: &Gpu, samples: &[Vec<(Fr, Fr)>]) -> Vec<Result<Poly>> {
+    let n = samples.first().map(|s| s.len()).unwrap_or(0);
+    let (mut xs, mut ys) = (Vec::new(), Vec::new());
+    for job in samples {
+        assert_eq!(job.len(), n);
+        for (x, y) in job {
+            xs.extend_from_slice(&fr_bytes(x));
+            ys.extend_from_slice(&fr_bytes(y));
+        }
+    }
+    let (mut out, mut st) = (vec![0u8; samples.len() * n * FR_BYTES], vec![0u8; samples.len()]);
+    let rc = unsafe { tc_fr_interpolate_batch(gpu.0, n, xs.as_ptr(), ys.as_ptr(), samples.len(), out.as_mut_ptr(), st.as_mut_ptr()) };
+    ys.iter_mut().for_each(|b| *b = 0);
+    gpu.check(rc);
+    st.iter().enumerate().map(|(j, &s)| status_to_result(s, Poly::from(out[j * n * FR_BYTES..(j + 1) * n * FR_BYTES].chunks(FR_BYTES).map(fr_from).collect::<Vec<_>>()))).collect()
+}
+
+// ---- (e): several GPUs of one node from one process ---------------------------------------------------------------------
+/// One worker thread + one context per GPU inside the library; batches are sharded contiguously, the key set travels
+/// by ONE RCCL broadcast over xGMI, valid counts by one all-reduce.
+pub struct GpuGroup(*mut TcGroup);
+unsafe impl Send for GpuGroup {}
+impl GpuGroup {
+    pub fn new(devices: &[i32]) -> std::result::Result<Self, GpuError> {
+        let devs: Vec<c_int> = devices.iter().map(|&d| d as c_int).collect();
+        let mut g = std::ptr::null_mut();
+        let rc = unsafe { tc_group_create(&mut g, devs.as_ptr(), devs.len() as c_int) };
+        if rc == TC_OK {
+            Ok(GpuGroup(g))
+        } else {
+            Err(GpuError(rc, "tc_group_create failed".into()))
+        }
+    }
+    fn check(&self, rc: c_int) {
+        if rc != TC_OK {
+            let msg = unsafe { std::ffi::CStr::from_ptr(tc_group_last_error(self.0)) }.to_string_lossy().into_owned();
+            panic!("libtc_amd group call failed ({}): {}", rc, msg);
+        }
+    }
+    pub fn size(&self) -> usize {
+        unsafe { tc_group_size(self.0) as usize }
+    }
+    pub fn set_key_set(&self, pks: &PublicKeySet) {
+        let commit = pks.commit_bytes();
+        self.check(unsafe { tc_group_set_keyset(self.0, pks.threshold(), commit.as_ptr()) });
+    }
+    /// `combine_signatures` (src/lib.rs:608-615) for B jobs of n shares, sharded over the GPUs of the group.
+    pub fn combine_signatures(&self, n: usize, idx: &[u64], shares: &[u8]) -> Vec<Result<Signature>> {
+        let b = idx.len() / n;
+        assert!(idx.len() == b * n && shares.len() == b * n * G2_BYTES);
+        let (mut out, mut st) = (vec![0u8; b * G2_BYTES], vec![0u8; b]);
+        self.check(unsafe { tc_group_combine_signatures(self.0, n, idx.as_ptr(), shares.as_ptr(), b, out.as_mut_ptr(), st.as_mut_ptr()) });
+        st.iter().enumerate().map(|(j, &s)| status_to_result(s, Signature(g2_from(&out[j * G2_BYTES..(j + 1) * G2_BYTES])))).collect()
+    }
+    /// `public_key().verify_g2` for B jobs; returns the booleans and the all-reduced number of valid signatures.
+    pub fn verify_g2(&self, sigs: &[u8], hashes: &[u8]) -> (Vec<bool>, u64) {
+        let b = sigs.len() / G2_BYTES;
+        let mut ok = vec![0u8; b];
+        let mut n_valid = 0u64;
+        self.check(unsafe { tc_group_verify_g2(self.0, sigs.as_ptr(), hashes.as_ptr(), b, ok.as_mut_ptr(), &mut n_valid) });
+        (ok.into_iter().map(|x| x == 1).collect(), n_valid)
+    }
+    /// BASELINE config 5 in one call: hash, sign the selected shares on the device, combine, verify.
+    pub fn sign_combine_verify<M: AsRef<[u8]>>(&self, sk_table: &[u8], n_nodes: usize, idx: &[u64], n: usize, msgs: &[M]) -> (Vec<Signature>, Vec<bool>, u64) {
+        let (flat, off) = pack_messages(msgs);
+        let b = msgs.len();
+        let (mut sig, mut ok) = (vec![0u8; b * G2_BYTES], vec![0u8; b]);
+        let mut n_valid = 0u64;
+        self.check(unsafe {
+            tc_group_sign_combine_verify(self.0, sk_table.as_ptr(), n_nodes, idx.as_ptr(), n, flat.as_ptr(), off.as_ptr(), b, sig.as_mut_ptr(), ok.as_mut_ptr(), &mut n_valid)
+        });
+        (sig.chunks(G2_BYTES).map(|c| Signature(g2_from(c))).collect(), ok.into_iter().map(|x| x == 1).collect(), n_valid)
+    }
+    /// bytes that crossed PCIe since the group was created: (host-to-device, device-to-host)
+    pub fn transfer_bytes(&self) -> (u64, u64) {
+        let (mut up, mut down) = (0u64, 0u64);
+        self.check(unsafe { tc_group_transfer_bytes(self.0, &mut up, &mut down) });
+        (up, down)
+    }
+}
+impl Drop for GpuGroup {
+    fn drop(&mut self) {
+        unsafe { tc_group_destroy(self.0) }
+    }
+}

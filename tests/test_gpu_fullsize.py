@@ -344,6 +344,37 @@ def test_rlc_share_validation_equals_per_share_path(engine):
     assert c.verify(bytes(pks[3]), bytes(bad[5, 3]), msgs[5]) == 0 and c.verify(bytes(pks[4]), bytes(bad[5, 3]), msgs[5]) == 1
 
 
+def test_rlc_same_key_verification_equals_per_job_path(engine, sig_workload, combined):
+    """tc_verify_g2_rlc_batch / tc_verify_sig_rlc_batch (opt-in) on BASELINE config 3's shape -- 65 536
+    signatures under ONE key: ok[] must equal tc_verify_g2_batch's with planted bad signatures (swapped neighbours, an
+    undecodable one, a non-member), only the groups that hold them fall back to per-job checks, and an all-valid batch
+    needs no fallback at all; group sizes that do and do not divide the batch."""
+    wl, sig = sig_workload, combined
+    B = wl.B
+    rnd = random.Random(31)
+    bad = sig.copy()
+    planted = sorted(rnd.sample(range(B), 9))
+    for j in planted[:7]:
+        bad[j] = sig[(j + 1) % B]
+    bad[planted[7], 5] ^= 0x40                                            # undecodable
+    bad[planted[8]] = u8(o.g2_uncompressed(_point_outside_g2(rnd)))       # on the twist, outside G2
+    want = engine.verify_g2(wl.master_pk, bad, wl.hashes)
+    assert want.sum() == B - 9 and not want[planted].any()
+    for group in (64, 100):
+        ok, nfb = engine.verify_g2_rlc(wl.master_pk, bad, wl.hashes, group=group, seed=bytes(range(32)))
+        assert (ok == want).all(), group
+        groups_hit = {j // group for j in planted}
+        assert nfb == sum(min(group, B - g * group) for g in groups_hit), (group, nfb)
+    ok, nfb = engine.verify_g2_rlc(wl.master_pk, sig, wl.hashes, seed=bytes(range(32)))
+    assert ok.all() and nfb == 0
+    ok, nfb = engine.verify_sig_rlc(wl.master_pk, bad, wl.msg_flat, wl.msg_off, group=64)
+    assert (ok == want).all() and nfb == 64 * len({j // 64 for j in planted})
+    # a wrong key fails every group: everything falls back and every job is (correctly) rejected
+    other = engine.g1_mul(u8(o.fr_to_bytes(12345))[None], u8(o.g1_uncompressed(o.G1_GEN))[None])[0][0, 0]
+    ok, nfb = engine.verify_g2_rlc(np.ascontiguousarray(other), sig[:300], wl.hashes[:300], group=64)
+    assert not ok.any() and nfb == 300
+
+
 def test_large_threshold_g1_and_g2_combination_vs_oracle(engine):
     """t = 9 and t = 21 through BOTH groups: the two-stage kernels (k_lagrange_all + k_msm_* / k_msm_*_g1) -- at this batch
     size the SPLIT stage L (2 and 4 lanes or lane pairs per job); every job against Oracle B, including a job with a

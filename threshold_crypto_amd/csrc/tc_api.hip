@@ -867,6 +867,152 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
   return k.finish();
 }
 
+// Signature batches under ONE key (BASELINE config 3's shape: 65 536 verifies under the master key) by random linear
+// combination, opt-in: the batch is cut into groups of `group` jobs, and a group passes with ONE check
+//     e(pk, sum_j r_j H_j) == e(g1, sum_j r_j sig_j)          (bilinearity; r_j secret, 2^63 values each)
+// instead of `group` checks of src/lib.rs:109; a group that fails (or holds an undecodable / non-member operand) is
+// re-checked job by job, so ok[] equals tc_verify_g2_batch's up to the 2^-63 of a wrongly passing group.  The two sums
+// are 16-column ladders over the psi-images (the two-stage kernels' short-scalar mode).  hash == nullptr: the hash points
+// are made on the device from msgs / off first (tc_verify_sig_batch's composition, hash constant folded into g1).
+static int verify_rlc(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* hash, const uint8_t* msgs, const uint64_t* off,
+                      size_t B, size_t group, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+  TC_REQUIRE(ctx);
+  if (n_fallback) *n_fallback = 0;
+  if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && pk && sig && (hash || off) && seed32 && ok);
+  TC_REQUIRE(B < (1ull << 32));
+  if (group == 0) group = 64;
+  if (group > 1024) group = 1024;
+  if (group > B) group = B;
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!hash) {
+    if (!total_bytes(k, off, B, &total)) return k.finish();
+    TC_REQUIRE(total == 0 || msgs);
+  }
+  const uint8_t* d_pk = k.in(pk, 96);
+  const uint8_t* d_sig = k.in(sig, B * 192);
+  const uint8_t* d_hash_in = hash ? k.in(hash, B * 192) : nullptr;
+  const uint8_t* d_msgs = hash ? nullptr : k.in(msgs, (size_t)total);
+  const uint64_t* d_off = hash ? nullptr : k.in(off, B + 1);
+  uint8_t* d_hash_own = hash ? nullptr : k.temp<uint8_t>(B * 192);
+  const uint8_t* d_hash = hash ? d_hash_in : d_hash_own;
+  const uint8_t* d_g1 = hash ? ctx->g1_gen : ctx->g1_gen_unfix;
+  uint8_t* d_seed = k.temp<uint8_t>(32);
+  if (d_seed) {
+    k.check(hipMemcpyAsync(d_seed, seed32, 32, hipMemcpyHostToDevice, ctx->stream), "seed copy");
+    ctx->h2d_bytes += 32;
+    k.wipe.emplace_back(d_seed, 32);
+  }
+  uint8_t* d_r = k.temp<uint8_t>(B * 32);
+  if (d_r) k.wipe.emplace_back(d_r, B * 32);
+  const size_t G = B / group, tail = B % group, NG = G + (tail ? 1 : 0);
+  uint8_t* d_S = k.temp<uint8_t>(NG * 192);
+  uint8_t* d_H = k.temp<uint8_t>(NG * 192);
+  uint8_t* d_st = k.temp<uint8_t>(2 * NG);
+  uint8_t* d_okg = k.temp<uint8_t>(NG);
+  uint8_t* d_ok = k.out(ok, B);
+  k.begin_timing();
+  k.check_points(false, d_pk, 0, 1, 1, B, 1);
+  k.check_points(true, d_sig, 192, 1, 1, B, 1);
+  if (hash) k.check_points(true, d_hash, 192, 1, 1, B, 1);
+  std::vector<uint8_t> h_okg(NG), h_st(2 * NG), h_valid;
+  if (!k.failed) {
+    if (!hash) tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash_own, /*fix=*/false);
+    tc::launch_rlc_scalars(ctx->stream, d_seed, B, d_r);
+    k.check(hipMemsetAsync(d_st, 0, 2 * NG, ctx->stream), "memset");
+    const uint32_t* rr = reinterpret_cast<const uint32_t*>(d_r);
+    if (G) {
+      msm_g2(k, group, group * 192, d_sig, rr, G, d_S, d_st, /*nbits=*/16);
+      msm_g2(k, group, group * 192, d_hash, rr, G, d_H, d_st + NG, 16);
+    }
+    if (tail) {
+      msm_g2(k, tail, tail * 192, d_sig + G * group * 192, rr + G * group * 8, 1, d_S + G * 192, d_st + G, 16);
+      msm_g2(k, tail, tail * 192, d_hash + G * group * 192, rr + G * group * 8, 1, d_H + G * 192, d_st + NG + G, 16);
+    }
+    tc::launch_pairing_check(ctx->stream, d_pk, 0, d_H, 192, d_g1, 0, d_S, 192, NG, d_okg, k.pairing_ws(NG));
+    k.check(hipMemsetAsync(d_ok, 1, B, ctx->stream), "memset");
+    k.check(hipMemcpyAsync(h_okg.data(), d_okg, NG, hipMemcpyDeviceToHost, ctx->stream), "ok readback");
+    k.check(hipMemcpyAsync(h_st.data(), d_st, 2 * NG, hipMemcpyDeviceToHost, ctx->stream), "status readback");
+    ctx->d2h_bytes += 3 * NG;
+    // checked-input mode: a group that owns a non-member operand goes to the per-job path as well
+    std::vector<const uint8_t*> valid_ptrs;
+    for (auto& p : k.checks) valid_ptrs.push_back(p.valid);
+    const size_t n_checks = k.checks.size();
+    k.checks.clear();
+    if (n_checks) {
+      h_valid.resize(n_checks * B);
+      for (size_t q = 0; q < n_checks; q++) {
+        const bool shared = (q == 0);  // the first pending check is the key's (one byte for the whole batch)
+        k.check(hipMemcpyAsync(h_valid.data() + q * B, valid_ptrs[q], shared ? 1 : B, hipMemcpyDeviceToHost, ctx->stream), "valid readback");
+        ctx->d2h_bytes += shared ? 1 : B;
+      }
+    }
+    k.check(hipStreamSynchronize(ctx->stream), "stream sync");
+    std::vector<uint32_t> failed;
+    if (!k.failed) {
+      const bool key_bad = n_checks && h_valid[0] == 0;
+      for (size_t g = 0; g < NG; g++) {
+        bool bad = key_bad || !h_okg[g] || h_st[g] != TC_JOB_OK || h_st[NG + g] != TC_JOB_OK;
+        const size_t lo = g * group, hi = (lo + group < B) ? lo + group : B;
+        for (size_t q = 1; q < n_checks && !bad; q++)
+          for (size_t j = lo; j < hi && !bad; j++) bad = h_valid[q * B + j] == 0;
+        if (bad)
+          for (size_t j = lo; j < hi; j++) failed.push_back((uint32_t)j);
+      }
+    }
+    if (!k.failed && !failed.empty()) {
+      // per-job pairing checks for every job of the failed groups, on compacted operands
+      const size_t R = failed.size();
+      uint32_t* d_map = k.temp<uint32_t>(R);
+      uint8_t* c_sig = k.temp<uint8_t>(R * 192);
+      uint8_t* c_hash = k.temp<uint8_t>(R * 192);
+      uint8_t* c_ok = k.temp<uint8_t>(R);
+      if (!k.failed) {
+        k.check(hipMemcpyAsync(d_map, failed.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        ctx->h2d_bytes += 4 * R;
+        tc::launch_gather_rows(ctx->stream, d_sig, 192, d_map, R, c_sig);
+        tc::launch_gather_rows(ctx->stream, d_hash, 192, d_map, R, c_hash);
+        tc::launch_pairing_check(ctx->stream, d_pk, 0, c_hash, 192, d_g1, 0, c_sig, 192, R, c_ok, k.pairing_ws(R));
+        if (ctx->input_checks) {  // members only, as the per-job path would require
+          uint8_t* v = k.temp<uint8_t>(R);
+          tc::launch_subgroup_check_g2(ctx->stream, c_sig, 192, 1, 1, R, v);
+          tc::launch_invalidate_jobs(ctx->stream, v, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          if (hash) {
+            tc::launch_subgroup_check_g2(ctx->stream, c_hash, 192, 1, 1, R, v);
+            tc::launch_invalidate_jobs(ctx->stream, v, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          }
+          tc::launch_subgroup_check_g1(ctx->stream, d_pk, 0, 1, 1, 1, v);
+          tc::launch_invalidate_jobs(ctx->stream, v, 1, (size_t)-1, R, nullptr, nullptr, 0, c_ok);
+        }
+        tc::launch_scatter_bytes(ctx->stream, c_ok, d_map, R, d_ok);
+        k.check(hipStreamSynchronize(ctx->stream), "stream sync");  // the host map goes out of scope
+      }
+      if (n_fallback) *n_fallback = R;
+    }
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_verify_g2_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* hash, size_t B, size_t group,
+                           const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+  if (ctx && !hash) {
+    ctx->err = "invalid argument: hash";
+    return TC_ERR_INVALID_ARG;
+  }
+  return verify_rlc(ctx, pk, sig, hash, nullptr, nullptr, B, group, seed32, ok, n_fallback);
+}
+
+int tc_verify_sig_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* off, size_t B,
+                            size_t group, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+  if (ctx && !off) {
+    ctx->err = "invalid argument: off";
+    return TC_ERR_INVALID_ARG;
+  }
+  return verify_rlc(ctx, pk, sig, nullptr, msgs, off, B, group, seed32, ok, n_fallback);
+}
+
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, const uint64_t* off,
                                const uint8_t* w, size_t B, uint8_t* ok) {
   TC_REQUIRE(ctx);

@@ -322,6 +322,38 @@ class Engine:
                    ctypes.byref(nfb))
         return ok, int(nfb.value)
 
+    def verify_g2_rlc(self, pk, sig, hash_, group=0, seed=None):
+        """Same-key signature batch by random linear combination (opt-in; see tc_amd.h): returns (ok (B,), number of jobs
+        that fell back to per-job checks).  `seed`: 32 secret random bytes (os.urandom when omitted)."""
+        import os
+        dev = self._mode(pk, sig, hash_)
+        self._arg(pk, (G1_BYTES,), "u8", "pk")
+        self._arg(sig, (None, G2_BYTES), "u8", "sig")
+        B = sig.shape[0]
+        self._arg(hash_, (B, G2_BYTES), "u8", "hash")
+        seed = bytes(seed) if seed is not None else os.urandom(32)
+        if len(seed) != 32:
+            raise ValueError("seed: 32 bytes")
+        ok = self._empty(dev, (B,), ref=sig)
+        nfb = ctypes.c_uint64(0)
+        self._call("tc_verify_g2_rlc_batch", _ptr(pk), _ptr(sig), _ptr(hash_), B, int(group), seed, _ptr(ok), ctypes.byref(nfb))
+        return ok, int(nfb.value)
+
+    def verify_sig_rlc(self, pk, sig, msgs, off, group=0, seed=None):
+        import os
+        dev = self._mode(pk, sig, msgs, off)
+        self._arg(pk, (G1_BYTES,), "u8", "pk")
+        self._arg(sig, (None, G2_BYTES), "u8", "sig")
+        B = sig.shape[0]
+        self._msgs(msgs, off, B)
+        seed = bytes(seed) if seed is not None else os.urandom(32)
+        if len(seed) != 32:
+            raise ValueError("seed: 32 bytes")
+        ok = self._empty(dev, (B,), ref=sig)
+        nfb = ctypes.c_uint64(0)
+        self._call("tc_verify_sig_rlc_batch", _ptr(pk), _ptr(sig), _ptr(msgs), _ptr(off), B, int(group), seed, _ptr(ok), ctypes.byref(nfb))
+        return ok, int(nfb.value)
+
     def ciphertext_verify(self, u, v, off, w):
         dev = self._mode(u, v, off, w)
         self._arg(u, (None, G1_BYTES), "u8", "u")
