@@ -1125,18 +1125,37 @@ static uint32_t chacha_u32(chacha_rng *g) {
   if (g->idx >= 16) chacha_block(g);
   return g->buf[g->idx++];
 }
+/* H-spec alternatives (the implementation-defined sampling order behind hash_g2 / xor_with_hash that no
+ * vector of the real crate pins yet).  0 = the recalled behaviour of rand_chacha 0.2 / ff_derive 0.6 / pairing 0.16; each
+ * bit switches ONE item to its documented alternative, the same bits as TC_HSPEC in threshold_crypto_amd/csrc/tc_hash.h and
+ * HSPEC in oracle/tc_oracle.py.  tests/ref_fixtures.py diagnose() names the setting that reproduces reference vectors. */
+#define HSPEC_U64_HI_FIRST 1      /* next_u64 = high word then low word */
+#define HSPEC_COMPARE_THEN_MASK 2 /* Fq::random accepts iff the UNMASKED draw is below q */
+#define HSPEC_GREATEST_MSB 4      /* greatest = top bit of next_u32 (rand's bool sampling) instead of next_u32 % 2 */
+#define HSPEC_KEYSTREAM_BYTES 8   /* xor_with_hash uses consecutive keystream bytes (fill_bytes), not one word per byte */
+#define HSPEC_CANONICAL_DRAW 16   /* the accepted pattern is the canonical value, not the Montgomery representation */
+static int g_hspec = 0;
+__attribute__((visibility("default"))) void or_set_hspec(int v) { g_hspec = v; }
+__attribute__((visibility("default"))) int or_get_hspec(void) { return g_hspec; }
+
 static u64 chacha_u64(chacha_rng *g) {
-  u64 lo = chacha_u32(g);
-  u64 hi = chacha_u32(g);
-  return lo | (hi << 32);
+  u64 a = chacha_u32(g);
+  u64 b = chacha_u32(g);
+  return (g_hspec & HSPEC_U64_HI_FIRST) ? (b | (a << 32)) : (a | (b << 32));
 }
 
 /* ff_derive random(): raw limbs ARE the Montgomery representation */
 static void fq_random(fq *out, chacha_rng *g) {
   for (;;) {
     for (int i = 0; i < 6; i++) out->l[i] = chacha_u64(g);
-    out->l[5] &= 0xffffffffffffffffull >> 3;
-    if (!big_geq(out->l, FQ_MOD, 6)) return;
+    if (!(g_hspec & HSPEC_COMPARE_THEN_MASK)) out->l[5] &= 0xffffffffffffffffull >> 3;
+    if (big_geq(out->l, FQ_MOD, 6)) continue;
+    if (g_hspec & HSPEC_CANONICAL_DRAW) {  /* value = the pattern itself: Montgomery form = pattern * R */
+      fq r2;
+      memcpy(r2.l, FQ_R2, sizeof r2.l);
+      fq_mul(out, &r2);
+    }
+    return;
   }
 }
 static const u64 G2_COFACTOR[8] = {0xcf1c38e31c7238e5ull, 0x1616ec6e786f0c70ull, 0x21537e293a6691aeull,
@@ -1148,7 +1167,8 @@ static void g2_random(g2_jac *out, chacha_rng *g) {
     fq2 x;
     fq_random(&x.c0, g);
     fq_random(&x.c1, g);
-    int greatest = (chacha_u32(g) % 2) != 0;
+    const uint32_t gw = chacha_u32(g);
+    int greatest = (g_hspec & HSPEC_GREATEST_MSB) ? (int)(gw >> 31) : (gw % 2) != 0;
     fq2 x3b = x, b, y;
     fq2_sqr(&x3b); fq2_mul(&x3b, &x); fq2_b_g2(&b); fq2_add(&x3b, &b);
     if (!fq2_sqrt(&y, &x3b)) continue;
@@ -1213,6 +1233,14 @@ static void xor_with_hash(const g1_aff *g, const uint8_t *data, size_t len, uint
   sha3_256(comp, 48, digest);
   chacha_rng rng;
   chacha_seed(&rng, digest);
+  if (g_hspec & HSPEC_KEYSTREAM_BYTES) {
+    uint32_t w = 0;
+    for (size_t i = 0; i < len; i++) {
+      if ((i & 3) == 0) w = chacha_u32(&rng);
+      out[i] = data[i] ^ (uint8_t)(w >> (8 * (i & 3)));
+    }
+    return;
+  }
   for (size_t i = 0; i < len; i++) out[i] = data[i] ^ (uint8_t)chacha_u32(&rng);
 }
 EXPORT int or_xor_with_hash(const uint8_t *g1, const uint8_t *data, size_t len, uint8_t *out) {

@@ -28,6 +28,8 @@ def load():
         sz = ctypes.c_size_t
         cp = ctypes.c_char_p
         vp = ctypes.c_void_p
+        _lib.or_set_hspec.argtypes = [ctypes.c_int]
+        _lib.or_set_hspec.restype = None
         _lib.or_hash_g2.argtypes = [cp, sz, cp]
         _lib.or_hash_g1_g2.argtypes = [cp, cp, sz, cp]
         _lib.or_xor_with_hash.argtypes = [cp, cp, sz, cp]
@@ -58,6 +60,11 @@ def load():
         _lib.or_threshold_decrypt_batch.argtypes = [sz, sz, vp, vp, vp, sz, sz, vp, vp, ctypes.c_int]
         _lib.or_threshold_decrypt_batch.restype = None
     return _lib
+
+
+def set_hspec(v):
+    """H-spec alternative bits (oracle/c/tc_oracle.c g_hspec; the same bits as tc_oracle.HSPEC); 0 = the recalled behaviour"""
+    load().or_set_hspec(int(v))
 
 
 def _buf(n):

@@ -788,6 +788,31 @@ def chacha20_block(key_words, counter, stream=0):
     return [(w[i] + s[i]) & 0xffffffff for i in range(16)]
 
 
+# H-spec alternatives (the implementation-defined sampling order behind hash_g2 / xor_with_hash / key draws that
+# no vector of the real crate pins yet).  HSPEC = 0 is the recalled behaviour of rand_chacha 0.2 / ff_derive 0.6 /
+# pairing 0.16; each bit switches ONE item to its documented alternative -- the same bits as g_hspec in oracle/c/tc_oracle.c
+# (or_set_hspec) and TC_HSPEC in threshold_crypto_amd/csrc/tc_hash.h.  tests/ref_fixtures.py diagnose() names the setting
+# that reproduces a set of reference vectors.
+HSPEC_U64_HI_FIRST = 1        # next_u64 = high word then low word
+HSPEC_COMPARE_THEN_MASK = 2   # Fq/Fr::random accept iff the UNMASKED draw is below the modulus
+HSPEC_GREATEST_MSB = 4        # greatest = top bit of next_u32 (rand's bool sampling) instead of next_u32 % 2
+HSPEC_KEYSTREAM_BYTES = 8     # xor_with_hash uses consecutive keystream bytes (fill_bytes), not one word per byte
+HSPEC_CANONICAL_DRAW = 16     # the accepted pattern is the canonical value, not the Montgomery representation
+HSPEC_NAMES = {1: "next_u64 takes the HIGH word first", 2: "Fq::random compares BEFORE masking the top limb",
+               4: "G2::random takes `greatest` from the TOP bit of next_u32", 8: "xor_with_hash uses consecutive keystream BYTES",
+               16: "Fq::random's accepted pattern is the CANONICAL value (not Montgomery)"}
+HSPEC = 0
+
+
+def set_hspec(v):
+    global HSPEC
+    HSPEC = int(v)
+
+
+def describe_hspec(v):
+    return "the recalled H-spec (0)" if not v else "; ".join(n for b, n in HSPEC_NAMES.items() if v & b) + " (HSPEC = %d)" % v
+
+
 class ChaChaRng:
     """rand_chacha 0.2.2 ChaChaRng::from_seed(seed): ChaCha20, key = seed, 64-bit block
     counter 0, 64-bit stream 0; output = keystream as sequential LE u32 words
@@ -808,9 +833,9 @@ class ChaChaRng:
         return self.buf.pop(0)
 
     def next_u64(self):
-        lo = self.next_u32()
-        hi = self.next_u32()
-        return lo | (hi << 32)
+        a = self.next_u32()
+        b = self.next_u32()
+        return (b | (a << 32)) if HSPEC & HSPEC_U64_HI_FIRST else (a | (b << 32))
 
 
 FQ_R = (1 << 384) % Q
@@ -824,20 +849,22 @@ def fq_random(rng):
     61 bits, accept if < q; the accepted pattern IS the Montgomery representation.  H-spec item 4."""
     while True:
         limbs = [rng.next_u64() for _ in range(6)]
-        limbs[5] &= 0xffffffffffffffff >> 3
+        if not HSPEC & HSPEC_COMPARE_THEN_MASK:
+            limbs[5] &= 0xffffffffffffffff >> 3
         v = sum(l << (64 * i) for i, l in enumerate(limbs))
         if v < Q:
-            return v * FQ_RINV % Q
+            return v if HSPEC & HSPEC_CANONICAL_DRAW else v * FQ_RINV % Q
 
 
 def fr_random(rng):
     """ff_derive 0.6 random for Fr: 4 x next_u64, top limb masked to 63 bits.  H-spec item 5."""
     while True:
         limbs = [rng.next_u64() for _ in range(4)]
-        limbs[3] &= 0xffffffffffffffff >> 1
+        if not HSPEC & HSPEC_COMPARE_THEN_MASK:
+            limbs[3] &= 0xffffffffffffffff >> 1
         v = sum(l << (64 * i) for i, l in enumerate(limbs))
         if v < R:
-            return v * FR_RINV % R
+            return v if HSPEC & HSPEC_CANONICAL_DRAW else v * FR_RINV % R
 
 
 def g2_get_point_from_x(x, greatest):
@@ -857,7 +884,8 @@ def g2_random(rng, stats=None):
         attempts += 1
         c0 = fq_random(rng)
         c1 = fq_random(rng)
-        greatest = (rng.next_u32() % 2) != 0
+        gw = rng.next_u32()
+        greatest = bool(gw >> 31) if HSPEC & HSPEC_GREATEST_MSB else (gw % 2) != 0
         P = g2_get_point_from_x((c0, c1), greatest)
         if P is not None:
             P = E2.mul(P, H2)
@@ -882,6 +910,13 @@ def hash_g1_g2(g1, msg):
 def xor_with_hash(g1, data):
     """src/lib.rs:710-715: byte i ^= (u8) of the i-th next_u32()."""
     rng = ChaChaRng(sha3_256(g1_compressed(g1)))
+    if HSPEC & HSPEC_KEYSTREAM_BYTES:
+        out, w = bytearray(), 0
+        for i, b in enumerate(data):
+            if i % 4 == 0:
+                w = rng.next_u32()
+            out.append(((w >> (8 * (i % 4))) & 0xff) ^ b)
+        return bytes(out)
     return bytes((rng.next_u32() & 0xff) ^ b for b in data)
 
 

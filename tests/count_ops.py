@@ -158,6 +158,18 @@ _out = buf(192)
 assert L.hs_combine_g2(67, (ctypes.c_uint64 * 68)(*ids67), b"".join(_sh), _out) == 0
 res["combine_g2_t67_msm"] = (cnt(), 2)
 assert _out.raw == o.g2_uncompressed(o.E2.mul(P2, poly67[0]))
+# the same shape in G1 (threshold decryption at t = 67): tc_msm.h job_msm_tables_g1 + job_msm_ladder_g1, one lane per job
+L.hs_msm_g1.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+_lam = o.lagrange_coeffs(67, [o.into_fr_plus_1(i) for i in ids67])
+_sh1 = b"".join(o.g1_uncompressed(o.E1.mul(P1, o.secret_key_share(poly67, i))) for i in ids67)
+_words = (ctypes.c_uint32 * (8 * 68))(*[(k >> (32 * i)) & 0xffffffff for k in _lam for i in range(8)])
+cnt()
+_out1 = buf(96)
+assert L.hs_msm_g1(68, _sh1, _words, _out1, 1) == 0 and _out1.raw == o.g1_uncompressed(o.E1.mul(P1, poly67[0]))
+res["combine_g1_t67_msm"] = (cnt(), 1)
+_m = b"tc/enc-payload-0123456789abcdef0123456789abcdef"[:32]
+assert L.hs_hash_g1_g2(o.g1_uncompressed(P1), _m, ctypes.c_size_t(len(_m)), buf(192)) == 0
+res["hash_g1_g2"] = (cnt(), 2)
 a = rnd.randrange(o.R)
 L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
                    o.g2_uncompressed(o.E2.mul(P2, a))); res["verify_g2"] = (cnt(), 2)

@@ -4,6 +4,8 @@
 #include "tc_jobs.h"
 #include "tc_dkg.h"
 #include "tc_msm.h"
+#include "tc_quad.h"
+#include <thread>
 #include "tc_comb.h"
 #include <vector>
 #include <string.h>
@@ -153,6 +155,21 @@ int hs_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_t* c, const
   return job_pairing_check(a, b, c, d);
 }
 // GT value of FE(ML(a,b)) : 12 x 48 B big-endian in tower order c0.c0.c0, c0.c0.c1, c0.c1.c0 ...
+// the four-lanes-per-check form (tc_quad.h): the two pairs of the quad as two host threads
+int hs_pairing_check_quad(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
+  QuadSim sim;
+  int res[2] = {-1, -1};
+  auto run = [&](int hi) {
+    tl_quad_sim = &sim;
+    tl_quad_hi = hi;
+    DirectIO g1{hi ? c : a, 0, nullptr}, g2{hi ? d : b, 0, nullptr};
+    res[hi] = job_pairing_check_quad_io(true, g1, g2);
+  };
+  std::thread tb(run, 1);
+  run(0);
+  tb.join();
+  return res[0] == res[1] ? res[0] : -1;
+}
 int hs_pairing_gt(const uint8_t* a, const uint8_t* b, uint8_t* out576) {
   G1Affine p;
   G2Affine q;

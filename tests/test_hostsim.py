@@ -768,3 +768,35 @@ def test_two_stage_msm_short_scalar_mode(L, rnd):
     assert L.hs_msm_g2_nbits(n, enc, words(sc), out64, 64) == 0 and out64.raw == out.raw
     assert L.hs_msm_g2_nbits(n, enc, words([sc[0] + 1] + sc[1:]), buf(192), 16) == 3          # even
     assert L.hs_msm_g2_nbits(n, enc, words([sc[0] + (1 << 16)] + sc[1:]), buf(192), 16) == 3  # a 17-bit digit
+
+
+@pytest.mark.parametrize("setting", [1 | 4 | 8 | 16, 2])
+def test_hspec_switch_of_the_device_source(setting, rnd):
+    """every documented H-spec alternative is ONE constant in the device source too
+    (csrc/tc_hash.h TC_HSPEC, the same bits as tc_oracle.HSPEC): the headers compiled with -DTC_HSPEC=<n> reproduce
+    Oracle A switched to <n> for hash_g2, hash_g1_g2 and xor_with_hash."""
+    lib = LIB.replace(".so", "_hspec%d.so" % setting)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DTC_TEST_HOOKS", "-DTC_HSPEC=%d" % setting, "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", lib],
+                   check=True, stderr=subprocess.DEVNULL)
+    H = ctypes.CDLL(lib)
+    H.hs_hash_g2.restype = None
+    o.set_hspec(setting)
+    try:
+        for m in (b"", b"Test message", bytes(range(200))):
+            out = buf(192)
+            H.hs_hash_g2(m, ctypes.c_size_t(len(m)), out)
+            assert out.raw == o.g2_uncompressed(o.hash_g2(m)), (setting, m)
+        g = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        data = bytes(rnd.randrange(256) for _ in range(77))
+        out = buf(77)
+        assert H.hs_xor_with_hash(o.g1_uncompressed(g), data, ctypes.c_size_t(77), out) == 0 and out.raw == o.xor_with_hash(g, data)
+        out = buf(192)
+        assert H.hs_hash_g1_g2(o.g1_uncompressed(g), data, ctypes.c_size_t(77), out) == 0 and out.raw == o.g2_uncompressed(o.hash_g1_g2(g, data))
+        # ... and differ from the default build's (the switch does something)
+        o.set_hspec(0)
+        out = buf(192)
+        H.hs_hash_g2(b"Test message", ctypes.c_size_t(12), out)
+        assert out.raw != o.g2_uncompressed(o.hash_g2(b"Test message"))
+    finally:
+        o.set_hspec(0)
+        os.remove(lib)

@@ -208,6 +208,8 @@ def test_reference_fixtures_if_present():
     if not rf.present():
         pytest.skip("no reference fixtures (tests/golden/ref_v0.4.0/vectors.hex): parity against the Rust crate unpinned")
     v = rf.load()
+    hits, verdict = rf.diagnose(v)
+    assert hits and hits[0] == 0, verdict      # a mismatch names the H-spec alternative that DOES reproduce the vectors
     for h in v.get("hash_g2", []):
         want = h["out"]
         assert c.g2_compress(c.hash_g2(h["msg"])) == (0, want)
@@ -224,3 +226,53 @@ def test_reference_fixtures_if_present():
         sk = int.from_bytes(e["sk_be"], "big")
         ct = (o.g1_from_compressed(u), vv, o.g2_from_compressed(w))
         assert o.ciphertext_verify(ct) and o.decrypt(sk, ct) == e["msg"]
+
+
+def _fabricated_vectors(setting, tmp_path):
+    """the records tools/ref_fixtures prints, made by Oracle A under one H-spec alternative (what a reference run would look
+    like if THAT were the crate's behaviour)"""
+    import ref_fixtures as rf
+    o.set_hspec(setting)
+    try:
+        lines = []
+        for m in (b"", b"a", b"Test message", b"tc/msg" + (0).to_bytes(8, "little")):
+            lines.append("hash_g2 msg=%s out=%s" % (m.hex(), o.g2_compressed(o.hash_g2(m)).hex()))
+        seed = bytes((31 + i) & 0xff for i in range(32))
+        rng = o.ChaChaRng(seed)
+        sk = o.fr_random(rng)
+        pk = o.public_key(sk)
+        lines.append("key seed=%s sk_be=%s pk=%s" % (seed.hex(), sk.to_bytes(32, "big").hex(), o.g1_compressed(pk).hex()))
+        msg = b"Muffins in the canteen today! Don't tell Bob."
+        u, v, w = o.encrypt_with_r(pk, o.fr_random(rng), msg)
+        blob = o.g1_compressed(u) + len(v).to_bytes(8, "little") + v + o.g2_compressed(w)
+        lines.append("encrypt seed=%s sk_be=%s msg=%s ciphertext_bincode=%s" % (seed.hex(), sk.to_bytes(32, "big").hex(), msg.hex(), blob.hex()))
+    finally:
+        o.set_hspec(0)
+    path = tmp_path / "vectors.hex"
+    path.write_text("\n".join(lines) + "\n")
+    return str(path)
+
+
+@pytest.mark.parametrize("setting", [0, 1, 4, 8, 16, 2 | 16])
+def test_hspec_mismatch_is_diagnosed(setting, tmp_path, monkeypatch):
+    """the day tests/golden/ref_v0.4.0/vectors.hex arrives and a hash_g2 / xor_with_hash vector
+    disagrees, the failure must NAME the documented alternative that reproduces it (word order of next_u64, compare vs
+    mask order in Fq::random, the source of `greatest`, the keystream's byte source, Montgomery vs canonical draw) -- each a
+    one-constant switch in both oracles and in csrc/tc_hash.h.  A vectors.hex fabricated by Oracle A under one
+    alternative is diagnosed as exactly that alternative, and Oracle B switched the same way reproduces it too."""
+    import ref_fixtures as rf
+    monkeypatch.setattr(rf, "PATH", _fabricated_vectors(setting, tmp_path))
+    assert rf.present()
+    hits, verdict = rf.diagnose()
+    assert hits and hits[0] == setting, (setting, hits, verdict)
+    if setting:
+        assert "TC_HSPEC=%d" % setting in verdict and 0 not in hits
+    else:
+        assert "parity pinned" in verdict
+    v = rf.load()
+    c.set_hspec(setting)
+    try:
+        for h in v["hash_g2"]:
+            assert c.g2_compress(c.hash_g2(h["msg"])) == (0, h["out"])
+    finally:
+        c.set_hspec(0)

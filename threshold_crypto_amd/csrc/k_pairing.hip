@@ -2,6 +2,7 @@
 #include "tc_jobs.h"
 #include "tc_launch.h"
 #include "tc_stage.h"
+#include "tc_quad.h"
 
 #include <stdlib.h>
 
@@ -81,11 +82,37 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_final_exp(const int32_t
   if (j < B && pair_leader() && ok[j]) ok[j] = r;
 }
 
+// ---- four lanes per check (tc_quad.h) -----------------------------------------------------------------------------------
+// Pair A of a quad stages and decodes (a, b), pair B (c, d): two passes through the LDS row buffer with a PAIR as the
+// staging unit (32 rows per wave), each pair parses one G1 and one G2 record.
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_quad(const uint8_t* __restrict__ a, size_t sa,
+                                                         const uint8_t* __restrict__ b, size_t sb,
+                                                         const uint8_t* __restrict__ c, size_t sc,
+                                                         const uint8_t* __restrict__ d, size_t sd, size_t B,
+                                                         uint8_t* __restrict__ ok) {
+  using IO1 = WaveRowIO<96, kG2Lanes>;
+  using IO2 = WaveRowIO<192, kG2Lanes>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[IO2::BYTES];
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kQuadLanes;
+  const bool live = j < B;
+  const size_t jj = live ? j : 0;
+  const bool hi = quad_hi();
+  IO1 i1{lds, live ? (hi ? c + jj * sc : a + jj * sa) : nullptr, 0, nullptr};
+  IO2 i2{lds, live ? (hi ? d + jj * sd : b + jj * sb) : nullptr, 0, nullptr};
+  const uint8_t r = job_pairing_check_quad_io(live, i1, i2);
+  if (live && (threadIdx.x & (kQuadLanes - 1)) == 0) ok[j] = r;
+}
+
 size_t pairing_ws_words(size_t B) { return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64; }
 
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws) {
   if (!B) return;
+  static const int quad = getenv("TC_PAIRING_QUAD") ? 1 : 0;   // experiments: four lanes per check
+  if (quad) {
+    hipLaunchKernelGGL(k_pairing_quad, dim3(grid_for(B * kQuadLanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
+    return;
+  }
   static const int mode = getenv("TC_PAIRING_FUSED") ? 1 : 0;  // experiments: the one-kernel form
   if (mode || !ws) {
     hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);

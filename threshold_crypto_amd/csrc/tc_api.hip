@@ -60,6 +60,7 @@ struct Call {
   };
   std::vector<CopyBack> outs;
   std::vector<std::pair<void*, size_t>> wipe;
+  std::vector<std::pair<void*, size_t>> wipe_after_copy;  // secret RESULTS staged for the host: zeroed after the D2H copy
   struct Pending {
     const uint8_t* valid;
     size_t per_job, group;
@@ -183,6 +184,7 @@ struct Call {
           check(hipMemcpyAsync(o.host, o.dev, o.n, hipMemcpyDeviceToHost, c->stream), "D2H copy");
           c->d2h_bytes += o.n;
         }
+    for (auto& w : wipe_after_copy) (void)hipMemsetAsync(w.first, 0, w.second, c->stream);  // stream-ordered after the copies
     if (!c->device_io || c->timing || failed) {
       hipError_t e = hipStreamSynchronize(c->stream);
       if (!failed) check(e, "stream sync");
@@ -1127,6 +1129,9 @@ int tc_fr_interpolate_batch(tc_ctx* ctx, size_t n, const uint8_t* xs, const uint
   const uint8_t* d_x = k.in(xs, B * n * 32);
   const uint8_t* d_y = k.in(ys, B * n * 32, /*secret=*/true);
   uint8_t* d_out = k.out(out_coeff, B * n * 32);
+  // host-I/O mode: the interpolated (secret) coefficients pass through a staging slot that outlives the call: wiped after
+  // the copy back, like every other secret operand
+  if (d_out && !ctx->device_io) k.wipe_after_copy.emplace_back(d_out, B * n * 32);
   uint32_t* d_ws = k.temp<uint32_t>(B * 2 * (n + 1) * 8);
   if (d_ws) k.wipe.emplace_back(d_ws, B * 2 * (n + 1) * 8 * sizeof(uint32_t));
   uint8_t* d_st = k.out(status, B);

@@ -384,6 +384,17 @@ struct Fq {
     return r;
   }
 
+  // select on a predicate that is LANE IDENTITY, not data (which pair of a quad this is: tc_quad.h): the same instruction,
+  // but the interval bookkeeping of the bound-check build follows the operand this lane really takes
+  TC_HD static Fq select_lane(bool c, const Fq& a, const Fq& b) {
+    Fq r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    const Fq& pick = c ? a : b;
+    r.set_range(pick.lo(), pick.hi());
+    r.set_val(pick.val());
+    return r;
+  }
+
   // Zero test in two steps.  value = k p with |k| <= 300 (the value bound every operand
   // obeys) forces the low 26 bits of the value -- l[0] & mask, whatever the lazy upper limbs
   // hold -- to be k p mod 2^26, i.e. (l[0] * p^-1) mod 2^26 must land within 300 of zero.

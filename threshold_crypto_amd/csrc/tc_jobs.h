@@ -471,10 +471,11 @@ TC_HD uint8_t job_xor_with_hash(const uint8_t* g1, const uint8_t* data, size_t l
   sha3_256_words(comp, 48, seed);
   ChaChaRng rng;
   rng.init(seed);
+  KeystreamBytes ks;
   size_t i = 0;
   TC_NOUNROLL while (wave_any(i < len)) {
     if (i < len) {
-      out[i] = data[i] ^ (uint8_t)rng.next_u32();
+      out[i] = data[i] ^ ks.next(rng);
       i++;
     }
   }

@@ -73,6 +73,7 @@ struct Fq2 {
     return Fq2{Fq::select(odd(), -r, r)};
   }
   TC_HD static Fq2 select(bool c, const Fq2& a, const Fq2& b) { return Fq2{Fq::select(c, a.m, b.m)}; }
+  TC_HD static Fq2 select_lane(bool c, const Fq2& a, const Fq2& b) { return Fq2{Fq::select_lane(c, a.m, b.m)}; }
 };
 #else
 struct Fq2 {
@@ -128,6 +129,9 @@ struct Fq2 {
   }
   TC_HD static Fq2 select(bool c, const Fq2& a, const Fq2& b) {
     return Fq2{Fq::select(c, a.c0, b.c0), Fq::select(c, a.c1, b.c1)};
+  }
+  TC_HD static Fq2 select_lane(bool c, const Fq2& a, const Fq2& b) {
+    return Fq2{Fq::select_lane(c, a.c0, b.c0), Fq::select_lane(c, a.c1, b.c1)};
   }
 };
 #endif

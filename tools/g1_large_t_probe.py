@@ -16,6 +16,9 @@ allsh, st = e.g1_mul(fr, np.ascontiguousarray(u[:, 0]))          # (1, N, 96): e
 idx = signer_subsets_np(B, N, t)
 shares = np.ascontiguousarray(allsh[0][idx.astype(np.int64)])    # (B, t+1, 96)
 res = {"t": t, "N": N, "B": B}
+for rep in range(2):   # a context's default: every share tested for group membership first (two 64-bit ladders per G1 point)
+    out, st = e.combine_g1(t, idx, shares); res["combine_g1_with_input_checks_ms"] = round(e.last_kernel_ms(), 2)
+e.set_input_checks(False)   # the shares are outputs of tc_g1_mul_batch: known members
 for rep in range(2):
     out, st = e.combine_g1(t, idx, shares); res["combine_g1_ms"] = round(e.last_kernel_ms(), 2)
 assert not st.any() and (out == out[0]).all()

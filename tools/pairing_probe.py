@@ -17,4 +17,4 @@ for rep in range(reps):
     ok = e.verify_g2(wl.master_pk, bad, wl.hashes); ts.append(round(e.last_kernel_ms(), 3))
 assert (ok == want).all()
 print(json.dumps({"lib": os.path.basename(os.environ.get("TC_AMD_LIB", "default")), "fused": bool(os.environ.get("TC_PAIRING_FUSED")),
-                  "w1": bool(os.environ.get("TC_MILLER_W1")), "B": B, "verify_ms": ts}), flush=True)
+                  "w1": bool(os.environ.get("TC_MILLER_W1")), "quad": bool(os.environ.get("TC_PAIRING_QUAD")), "B": B, "verify_ms": ts}), flush=True)
