@@ -144,6 +144,9 @@ def parse_args(argv=None):
                     help="contexts (one HIP stream each) of the `streaming` leg of config 2; 1 = skip that leg")
     ap.add_argument("--sustain-seconds", type=float, default=1.2, help="length of the `sustained` leg of config 2 (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (general path, configs 3 and 4, PCIe-inclusive rate)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3 captures (tools/capture_r03.sh): skip the legs that launch the headline kernels on OTHER work "
+                         "(general-path and checked-input combines), so that a kernel's per-launch averages describe one kind of launch")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks, only with --test-engine")
     ap.add_argument("--test-engine", default=None, choices=[None, "hostsim"],
                     help="TEST HARNESS: tests/hostsim (g++ build of the device source) instead of the GPU; needs --backend gloo")
@@ -444,6 +447,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         # ---- the same batch through the GENERAL path: share indices the small-index fast path does not take ---------
         # (signers OFFSET + i: abscissae above 65 535; Lagrange coefficients from k_lagrange, two-stage combination)
         OFFSET = 1 << 20
+    if not args.no_extras and not harness and not args.profile_run:
         wg = ThresholdSigWorkload(eng, t, N, B, start=start, index_offset=OFFSET, hashes=wl.hashes)
         g_idx = torch.from_numpy(wg.idx.view(np.int64)).to(dev)
         g_shares = torch.from_numpy(wg.shares).to(dev)
@@ -461,6 +465,7 @@ def run_config2(args, eng, dev, rank, world, peak):
                    "roofline": roofline("k_lagrange + k_msm_tables + k_msm_ladder", "combine_g2_t3_general", "combine_g2_t3", "combine_g2", t, B,
                                         general_kernel_ms, peak) if t == 3 else None}
         del wg, g_idx, g_shares, gsig
+    if not args.no_extras and not harness:
         # ---- verify incl. hashing on the device, hash_g2 alone --------------------------------------------
         d_msgs = torch.from_numpy(wl.msg_flat).to(dev)
         d_off = torch.from_numpy(wl.msg_off.view(np.int64)).to(dev)
@@ -513,6 +518,7 @@ def run_config2(args, eng, dev, rank, world, peak):
                    "roofline": roofline("k_hash_g1_g2 + k_miller_loop + k_final_exp + k_combine_fast<Fq> + k_xor_with_hash", None, None,
                                         "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
                                         executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"])}
+    if not args.no_extras and not harness and not args.profile_run:
         # ---- the headline step with the context's default membership tests on every share -------------------------
         eng.set_input_checks(True)
         csig, cst = eng.combine_g2(t, d_idx, d_shares)
@@ -523,6 +529,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         extras["combine_with_input_checks_per_s"] = round(B * world / (time.perf_counter() - c0), 1)
         eng.set_input_checks(False)
         assert bool((csig == sig).all().item()) and int(cst.to(torch.int32).sum().item()) == 0
+    if not args.no_extras and not harness and not args.profile_run:
         # ---- the same combine with HOST buffers at the C ABI (pageable numpy memory): PCIe-inclusive ---------
         eng.combine_g2(t, wl.idx, wl.shares)
         best = 1e9

@@ -187,6 +187,16 @@ int tc_verify_g2_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, c
                            const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback);
 int tc_verify_sig_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* off, size_t B,
                             size_t group, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback);
+/* Decryption-share validation by one random linear combination per ciphertext (opt-in): the loop of
+ * examples/threshold_enc.rs over PublicKeyShare::verify_decryption_share (src/lib.rs:182-186) for B ciphertexts x N nodes.
+ * pk_shares: N x 96 B (public_key_share(i), the same for every ciphertext); shares: B x N x 96 B; u / v / off / w: the
+ * ciphertexts.  ok[j * N + i] = pk_share(i).verify_decryption_share(&shares[j][i], &ct[j]) -- one combined check
+ *     e(sum_i r_i share_i, hash_g1_g2(u, v)) == e(sum_i r_i pk_i, w)
+ * per ciphertext (r_i: 2^63 secret values from ChaCha20(seed32, .)), share-by-share checks for the ciphertexts whose
+ * combined check fails; *n_fallback (optional) = how many did.  seed32: 32 secret random bytes in HOST memory. */
+int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* shares, const uint8_t* u,
+                                          const uint8_t* v, const uint64_t* off, const uint8_t* w, size_t B, const uint8_t* seed32,
+                                          uint8_t* ok, uint64_t* n_fallback);
 /* ok[j] = Ciphertext(u[j], v[j], w[j]).verify() = e(g1, w) == e(u, hash_g1_g2(u, v))   src/lib.rs:508-512 */
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
                                const uint8_t* w_g2, size_t B, uint8_t* ok);

@@ -351,22 +351,27 @@ int hs_msm_g2_split(size_t n, const uint8_t* points, const uint32_t* scalars, ui
 
 // the same two stages in G1 (tc_msm.h job_msm_tables_g1 / job_msm_ladder_g1_part); parts > 1: the split form with the
 // butterfly of additions the lanes of a job run
+int hs_msm_g1_nbits(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out96, size_t parts, int nbits);
 int hs_msm_g1(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out96, size_t parts) {
+  return hs_msm_g1_nbits(n, points, scalars, out96, parts, 128);
+}
+int hs_msm_g1_nbits(size_t n, const uint8_t* points, const uint32_t* scalars, uint8_t* out96, size_t parts, int nbits) {
   const size_t chunks = msm_chunks(n), shares4 = chunks * kMsmChunk;
+  const int top = nbits / 2;
   std::vector<int32_t> tbl(shares4 * 8 * kMsmEntryWordsG1);
   std::vector<uint8_t> codes(kMsmColumns * shares4);
   bool ok = true;
-  for (size_t c = 0; c < chunks; c++) ok &= job_msm_tables_g1(n, c, points, scalars, tbl.data(), codes.data());
+  for (size_t c = 0; c < chunks; c++) ok &= job_msm_tables_g1(n, c, points, scalars, tbl.data(), codes.data(), nbits);
   if (!ok) {
     g1_encode_uncompressed(G1Affine::infinity(), out96);
     return TC_JOB_INVALID_ENCODING;
   }
   if (parts <= 1) {
-    g1_encode_uncompressed(jac_to_affine(job_msm_ladder_g1_part<false>(n, tbl.data(), codes.data(), msm_part(n))), out96);
+    g1_encode_uncompressed(jac_to_affine(job_msm_ladder_g1_part<false>(n, tbl.data(), codes.data(), msm_part(n), top)), out96);
     return TC_JOB_OK;
   }
   std::vector<G1Jac> r(parts);
-  for (size_t g = 0; g < parts; g++) r[g] = job_msm_ladder_g1_part<true>(n, tbl.data(), codes.data(), msm_part(n, g, parts));
+  for (size_t g = 0; g < parts; g++) r[g] = job_msm_ladder_g1_part<true>(n, tbl.data(), codes.data(), msm_part(n, g, parts), top);
   for (size_t d = 1; d < parts; d <<= 1) {
     std::vector<G1Jac> nx(parts);
     for (size_t g = 0; g < parts; g++) nx[g] = jac_add(r[g], r[g ^ d]);

@@ -375,6 +375,46 @@ def test_rlc_same_key_verification_equals_per_job_path(engine, sig_workload, com
     assert not ok.any() and nfb == 300
 
 
+def test_rlc_decryption_share_validation_equals_per_share_path(engine):
+    """tc_verify_decryption_shares_rlc_batch (opt-in): B ciphertexts x N nodes' decryption shares; ok[]
+    must equal PublicKeyShare::verify_decryption_share (src/lib.rs:182-186) share by share -- with swapped shares, an
+    undecodable share, a share outside G1 and a ciphertext whose w was replaced -- and only the ciphertexts that hold a bad
+    operand fall back to per-share checks."""
+    from threshold_crypto_amd.workload import ThresholdEncWorkload
+    t, N, B = 3, 10, 1500
+    we = ThresholdEncWorkload(engine, t, N, B)
+    fr = np.stack([u8(we.sks.secret_key_share(i)._bytes()) for i in range(N)])
+    shares, st = engine.g1_mul(fr, we.u)                                   # (B, N, 96): every node's share of every ciphertext
+    assert not st.any()
+    commit = np.stack([u8(c_) for c_ in we.sks.public_keys(engine).commit])
+    pks, st = engine.public_key_shares(commit, np.arange(N, dtype=np.uint64))
+    assert not st.any()
+    rnd = random.Random(8)
+    bad, w = shares.copy(), we.w.copy()
+    bad[5, 2], bad[5, 3] = shares[5, 3], shares[5, 2]                      # two nodes' shares swapped
+    bad[40, 0, 7] ^= 0x55                                                  # undecodable (or off the curve)
+    while True:                                                            # a point of E(Fq) outside G1
+        x = rnd.randrange(o.Q)
+        y = pow((x * x * x + 4) % o.Q, (o.Q + 1) // 4, o.Q)
+        if y * y % o.Q == (x * x * x + 4) % o.Q and o.E1.mul((x, y), o.R) is not None:
+            break
+    bad[77, 9] = u8(o.g1_uncompressed((x, y)))
+    w[300] = we.w[301]                                                     # a ciphertext with somebody else's w
+    v32 = we.v.reshape(B, 32)
+    flat = lambda a: np.ascontiguousarray(a.reshape(-1, a.shape[-1]))
+    want = engine.verify_decryption_share(np.ascontiguousarray(np.tile(pks, (B, 1))), flat(bad), np.ascontiguousarray(np.repeat(we.u, N, axis=0)),
+                                          np.ascontiguousarray(np.repeat(v32, N, axis=0).reshape(-1)), np.arange(B * N + 1, dtype=np.uint64) * 32,
+                                          np.ascontiguousarray(np.repeat(w, N, axis=0))).reshape(B, N)
+    expect = np.ones((B, N), np.uint8)
+    expect[5, 2] = expect[5, 3] = expect[40, 0] = expect[77, 9] = 0
+    expect[300] = 0
+    assert (want == expect).all()
+    ok, nfb = engine.verify_decryption_shares_rlc(pks, bad, we.u, we.v, we.off, w, seed=bytes(range(32)))
+    assert (ok == want).all() and nfb == 4
+    ok, nfb = engine.verify_decryption_shares_rlc(pks, shares, we.u, we.v, we.off, we.w)
+    assert ok.all() and nfb == 0
+
+
 def test_large_threshold_g1_and_g2_combination_vs_oracle(engine):
     """t = 9 and t = 21 through BOTH groups: the two-stage kernels (k_lagrange_all + k_msm_* / k_msm_*_g1) -- at this batch
     size the SPLIT stage L (2 and 4 lanes or lane pairs per job); every job against Oracle B, including a job with a

@@ -162,6 +162,45 @@ def test_committed_bench_lines_are_self_consistent():
         summary = open(os.path.join(root, "profiles", tag + "_rocprofv3_summary.csv")).read()
         for k in ("k_combine_fast<tc::Fq2>", "k_pairing_check", "k_hash_g2", "k_g2_mul_shared", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
             assert k in summary, (tag, k)
+    # round 3: the headline is K steps on ONE stream (per-launch event times measured inside the timed region), the two-contexts
+    # figure is the `streaming` object; a mechanical reader's check kernel_ms <= ms_per_step holds; every leg of configs 2-4
+    # carries its own roofline
+    d = json.loads([l for l in open(os.path.join(root, "profiles", "r03_b_bench.txt")) if l.startswith("{")][-1])
+    B = d["config"]["batch_per_gpu"]
+    assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 == d["ranks"]["world_size"] and d["vs_baseline"] is None
+    assert d["config"]["overlapped"] is False and d["config"]["steps_in_flight"] == 1
+    assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+    assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert d["streaming"]["overlapped"] is True and d["streaming"]["value"] > d["value"]
+    assert d["sustained"]["seconds"] >= 1.0 and abs(d["sustained"]["value"] - d["value"]) / d["value"] < 0.05
+    legs = [d["roofline"], d["general_path"]["roofline"], d["config3"]["roofline"], d["config4"]["roofline"]] + list(d["secondary_rooflines"].values())
+    for r in legs:
+        assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+        want = r["executed_macs_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12
+        assert abs(r["achieved"] - want) / want < 2e-3 and r["hbm_frac"] < 0.01
+    assert d["roofline"]["executed_macs_per_unit"] == macs["combine_g2_t3_fast"]
+    assert d["general_path"]["roofline"]["executed_macs_per_unit"] == macs["combine_g2_t3_general"]
+    assert d["config3"]["roofline"]["executed_macs_per_unit"] == macs["verify_g2"] and d["config3"]["kernel_ms"] == d["config3"]["roofline"]["kernel_ms"]
+    assert d["config4"]["roofline"]["executed_macs_per_unit"] == macs["verify_g2"] + macs["hash_g1_g2"] + macs["combine_g1_t3_fast"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["value"] / d["cpu_baseline"]["value"] > 100
+    prof = json.load(open(os.path.join(root, "profiles", "profile_constants.json")))
+    assert prof["combine_g2_t3"]["source"] == "profiles/r03_b_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
+    # (the line embeds the constants of the capture BEFORE it -- the capture that goes with it produces the next ones)
+    assert d["roofline"]["traffic"] > 50 * d["roofline"]["algorithmic_bytes_per_launch"] and "profiles/" in d["roofline"]["traffic_is"]
+    summary = open(os.path.join(root, "profiles", "r03_b_rocprofv3_summary.csv")).read()
+    for k in ("k_combine_fast<tc::Fq2>", "k_miller_loop", "k_final_exp", "k_hash_g2", "k_hash_g1_g2", "k_g2_mul_shared", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+        assert k in summary, k
+    # frac reproducible from the profile within 5 %: executed multiply-adds / the profile's average duration
+    avg = {}
+    for line in summary.splitlines():
+        f = line.split(",")
+        if len(f) >= 12 and f[0].replace("void ", "") in ("tc::k_combine_fast<tc::Fq2>", "tc::k_miller_loop", "tc::k_final_exp") and f[0] not in avg:
+            avg[f[0].replace("void ", "")] = float(f[3])
+    pair_ms = avg["tc::k_miller_loop"] + avg["tc::k_final_exp"]
+    assert abs(pair_ms - d["config3"]["kernel_ms"]) / pair_ms < 0.05
+    assert abs(avg["tc::k_combine_fast<tc::Fq2>"] - d["roofline"]["kernel_ms"]) / d["roofline"]["kernel_ms"] < 0.08   # (+ the small grouping kernels)
+    c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r03_config5_1gpu_bench.txt")) if l.startswith("{")][-1])
+    assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True and c5["ranks"]["world_size"] == 1
     c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r02_config5_1gpu_bench.txt")) if l.startswith("{")][-1])
     assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True
     assert abs(c5["value"] - c5["config"]["batch_per_gpu"] / (c5["ms_per_step"] * 1e-3)) / c5["value"] < 2e-3

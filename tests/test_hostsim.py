@@ -728,6 +728,34 @@ def test_two_stage_msm_g1_matches_oracle(L, rnd):
     assert L.hs_msm_g1(n, o.g1_uncompressed(p) * n, words, out, 1) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(p, 40))
 
 
+def test_two_stage_msm_g1_short_scalar_mode(L, rnd):
+    """the random-linear-combination scalars of the decryption-share validation (k_check.hip k_rlc_scalars_g1): a + b x^2
+    with a odd, a, b < 2^32 -- 16 double-doubling steps instead of 64; anything else fails the job."""
+    L.hs_msm_g1_nbits.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    X2 = o.BLS_X * o.BLS_X
+    words = lambda sc: (ctypes.c_uint32 * (8 * len(sc)))(*[(s >> (32 * i)) & 0xffffffff for s in sc for i in range(8)])
+    for n in (3, 10, 13):
+        pts = [o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)) for _ in range(n)]
+        if n > 3:
+            pts[2] = None
+        sc = [(rnd.getrandbits(32) | 1) + rnd.getrandbits(32) * X2 for _ in range(n)]
+        sc[0] = 1
+        sc[1] = (2 ** 32 - 1) + (2 ** 32 - 1) * X2
+        want = None
+        for p, k in zip(pts, sc):
+            want = o.E1.add(want, o.E1.mul(p, k))
+        enc = b"".join(o.g1_uncompressed(p) for p in pts)
+        for parts in (1, 2):
+            if parts > 1 and parts * 4 > n:
+                continue
+            out = buf(96)
+            assert L.hs_msm_g1_nbits(n, enc, words(sc), out, parts, 32) == 0 and out.raw == o.g1_uncompressed(want), (n, parts)
+        out128 = buf(96)
+        assert L.hs_msm_g1_nbits(n, enc, words(sc), out128, 1, 128) == 0 and out128.raw == o.g1_uncompressed(want)
+    assert L.hs_msm_g1_nbits(n, enc, words([sc[0] + 1] + sc[1:]), buf(96), 1, 32) == 3            # even
+    assert L.hs_msm_g1_nbits(n, enc, words([sc[0] + (1 << 32)] + sc[1:]), buf(96), 1, 32) == 3    # a 33-bit half
+
+
 def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
     """tc_threshold.h lagrange_all_at_zero == the reference's per-coefficient construction (src/lib.rs:739-763),
     including repeated indices (filtered by VALUE out of the denominator, :758) and u64 edge values."""
@@ -800,3 +828,27 @@ def test_hspec_switch_of_the_device_source(setting, rnd):
     finally:
         o.set_hspec(0)
         os.remove(lib)
+
+
+def test_quad_pairing_check_matches_oracle(L, rnd):
+    """tc_quad.h: the pairing check on four lanes per job -- the two pairings of the product on the two lane pairs, Fq12
+    values distributed (c0 on pair A, c1 on pair B), the compressed chains of the final exponentiation split
+    (z2, z3 | z4, z5).  The host build runs the two pairs as two threads that meet at every exchange; true and false
+    checks, operands at infinity on either side (the skipped-pair convention of pairing 0.16), undecodable operands, and
+    agreement with the lane-pair form on every case."""
+    g1, g2 = o.g1_uncompressed, o.g2_uncompressed
+    cases = []
+    for _ in range(4):
+        a, b = rnd.randrange(1, o.R), rnd.randrange(1, o.R)
+        P, Q = o.E1.mul(o.G1_GEN, a), o.E2.mul(o.G2_GEN, b)
+        cases.append(((g1(P), g2(Q), g1(o.G1_GEN), g2(o.E2.mul(o.G2_GEN, a * b % o.R))), 1))
+        cases.append(((g1(P), g2(Q), g1(o.G1_GEN), g2(o.E2.mul(o.G2_GEN, (a * b + 1) % o.R))), 0))
+        cases.append(((g1(o.G1_GEN), g2(o.E2.mul(Q, a)), g1(P), g2(Q)), 1))          # the roles of the pairs swapped
+    inf1, inf2 = g1(None), g2(None)
+    cases += [((inf1, g2(Q), inf1, g2(Q)), 1), ((g1(P), inf2, inf1, g2(Q)), 1), ((g1(P), g2(Q), inf1, g2(Q)), 0),
+              ((inf1, inf2, g1(P), g2(Q)), 0), ((inf1, inf2, inf1, inf2), 1)]
+    bad = bytearray(g1(P))
+    bad[50] ^= 1
+    cases += [((bytes(bad), g2(Q), g1(P), g2(Q)), 0), ((g1(P), g2(Q), g1(P), b"\xff" * 192), 0)]
+    for ops, want in cases:
+        assert L.hs_pairing_check_quad(*ops) == want == L.hs_pairing_check(*ops)

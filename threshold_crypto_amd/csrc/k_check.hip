@@ -74,6 +74,32 @@ __global__ void k_rlc_scalars(const uint8_t* __restrict__ seed32, size_t n, uint
   for (int w = 0; w < 4; w++)
     for (int b = 0; b < 8; b++) out_fr[i * 32 + 8 * w + b] = (uint8_t)(acc[w] >> (8 * b));
 }
+// the same for values of G1, whose endomorphism is phi = [-x^2]: r[i] = a + b x^2 with a (odd) and b from two 32-bit draws
+// of ChaCha20(key = seed, block counter = i) -- 2^63 equally likely scalars, pairwise distinct mod r (a + b x^2 < r), and
+// a 16-step ladder in the base-4 sign-aligned form of tc_msm.h (short-scalar mode, nbits = 32).
+__global__ void k_rlc_scalars_g1(const uint8_t* __restrict__ seed32, size_t n, uint8_t* __restrict__ out_fr) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t key[8];
+  for (int w = 0; w < 8; w++)
+    key[w] = (uint32_t)seed32[4 * w] | ((uint32_t)seed32[4 * w + 1] << 8) | ((uint32_t)seed32[4 * w + 2] << 16) | ((uint32_t)seed32[4 * w + 3] << 24);
+  ChaChaRng rng;
+  rng.init(key);
+  rng.counter = i;
+  const uint64_t a = (uint64_t)(rng.next_u32() | 1u), b = (uint64_t)rng.next_u32();
+  // a + b x^2, x^2 = |x|^2 (128 bits): three words
+  const unsigned __int128 x2 = (unsigned __int128)BLS_X_ABS * BLS_X_ABS;
+  const uint64_t x2lo = (uint64_t)x2, x2hi = (uint64_t)(x2 >> 64);
+  uint64_t acc[4];
+  unsigned __int128 c = (unsigned __int128)x2lo * b + a;
+  acc[0] = (uint64_t)c;
+  c = (c >> 64) + (unsigned __int128)x2hi * b;
+  acc[1] = (uint64_t)c;
+  acc[2] = (uint64_t)(c >> 64);
+  acc[3] = 0;
+  for (int w = 0; w < 4; w++)
+    for (int bb = 0; bb < 8; bb++) out_fr[i * 32 + 8 * w + bb] = (uint8_t)(acc[w] >> (8 * bb));
+}
 __global__ void k_gather_rows(const uint8_t* __restrict__ src, size_t row_words, const uint32_t* __restrict__ map, size_t rows,
                               uint8_t* __restrict__ dst) {
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;  // one 8-byte word per lane: coalesced within a row
@@ -87,6 +113,9 @@ __global__ void k_scatter_bytes(const uint8_t* __restrict__ src, const uint32_t*
 }
 void launch_rlc_scalars(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr) {
   if (n) hipLaunchKernelGGL(k_rlc_scalars, dim3(grid_for(n)), dim3(kBlock), 0, st, seed32, n, out_fr);
+}
+void launch_rlc_scalars_g1(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr) {
+  if (n) hipLaunchKernelGGL(k_rlc_scalars_g1, dim3(grid_for(n)), dim3(kBlock), 0, st, seed32, n, out_fr);
 }
 void launch_gather_rows(hipStream_t st, const uint8_t* src, size_t row_bytes, const uint32_t* map, size_t rows, uint8_t* dst) {
   const size_t words = rows * (row_bytes / 8);

@@ -80,14 +80,14 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder_split(size_t
 // log2(parts) rounds of one __shfl_xor exchange + one addition).  Two waves per SIMD (256 registers).
 __global__ __launch_bounds__(kBlock, 2) void k_msm_tables_g1(size_t n, size_t pts_stride, const uint8_t* __restrict__ points,
                                                            const uint32_t* __restrict__ scalars, size_t B, int32_t* __restrict__ tbl,
-                                                           uint8_t* __restrict__ codes, uint8_t* __restrict__ status) {
+                                                           uint8_t* __restrict__ codes, uint8_t* __restrict__ status, int nbits) {
   const size_t chunks = msm_chunks(n);
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (tid >= B * chunks) return;
   const size_t j = tid / chunks, c = tid % chunks;
   const size_t shares4 = chunks * kMsmChunk;
   const bool ok = job_msm_tables_g1(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + j * shares4 * 8 * kMsmEntryWordsG1,
-                                    codes + j * kMsmColumns * shares4);
+                                    codes + j * kMsmColumns * shares4, nbits);
   if (!ok && status[j] == TC_JOB_OK) status[j] = TC_JOB_INVALID_ENCODING;
 }
 __device__ __forceinline__ Fq msm_from_lane(const Fq& v, int lanes) {
@@ -97,7 +97,7 @@ __device__ __forceinline__ Fq msm_from_lane(const Fq& v, int lanes) {
 }
 template <bool SPLIT>
 __global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B, const int32_t* __restrict__ tbl, const uint8_t* __restrict__ codes,
-                                                           uint8_t* __restrict__ out, const uint8_t* __restrict__ status, size_t parts) {
+                                                           uint8_t* __restrict__ out, const uint8_t* __restrict__ status, size_t parts, int top) {
   const size_t lp = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t j = lp / parts, g = lp % parts;
   if (j >= B) return;  // (parts divides 64: a job's lanes leave together)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B,
     return;
   }
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
-  G1Jac r = job_msm_ladder_g1_part<SPLIT>(n, tbl + j * shares4 * 8 * kMsmEntryWordsG1, codes + j * kMsmColumns * shares4, msm_part(n, g, parts));
+  G1Jac r = job_msm_ladder_g1_part<SPLIT>(n, tbl + j * shares4 * 8 * kMsmEntryWordsG1, codes + j * kMsmColumns * shares4, msm_part(n, g, parts), top);
   if (SPLIT) {
     TC_NOUNROLL for (size_t d = 1; d < parts; d <<= 1) {
       const G1Jac o{msm_from_lane(r.x, (int)d), msm_from_lane(r.y, (int)d), msm_from_lane(r.z, (int)d)};
@@ -118,20 +118,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B,
 
 size_t msm_table_bytes_g1(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWordsG1 * sizeof(int32_t); }
 // status: B bytes, TC_JOB_OK for the jobs to run (others get the identity and keep their status)
+// nbits = 128: any scalars below r.  nbits < 128 (even): odd scalars k1 + k2 x^2 with k1, k2 < 2^nbits (a job with another
+// scalar fails): nbits doublings instead of 128.
 void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B, int32_t* tbl,
-                   uint8_t* codes, uint8_t* out, uint8_t* status) {
+                   uint8_t* codes, uint8_t* out, uint8_t* status, int nbits) {
   if (!B || !n) return;
-  hipLaunchKernelGGL(k_msm_tables_g1, dim3(grid_for(B * msm_chunks(n))), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status);
+  const int top = nbits / 2;
+  hipLaunchKernelGGL(k_msm_tables_g1, dim3(grid_for(B * msm_chunks(n))), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status, nbits);
   // lanes per job in stage L: 1 when the batch fills the 2048 wave slots by itself (131 072 lanes), else the power of two
   // that does, with at least four shares per part
   size_t parts = 1;
   while (parts < 64 && B * parts * 2 <= 131072 && parts * 2 * 4 <= n) parts *= 2;
   if (parts == 1)
     hipLaunchKernelGGL(k_msm_ladder_g1<false>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                       (const uint8_t*)status, parts);
+                       (const uint8_t*)status, parts, top);
   else
     hipLaunchKernelGGL(k_msm_ladder_g1<true>, dim3(grid_for(B * parts)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                       (const uint8_t*)status, parts);
+                       (const uint8_t*)status, parts, top);
 }
 
 size_t msm_table_bytes(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWords * sizeof(int32_t); }

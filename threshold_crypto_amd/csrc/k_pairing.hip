@@ -55,8 +55,7 @@ __device__ __forceinline__ void fq12_store_rows(int32_t*, const Fq12&) {}
 __device__ __forceinline__ Fq12 fq12_load_rows(const int32_t*) { return Fq12::one(); }
 #endif
 
-template <int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_miller_loop(const uint8_t* __restrict__ a, size_t sa,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_miller_loop(const uint8_t* __restrict__ a, size_t sa,
                                                         const uint8_t* __restrict__ b, size_t sb,
                                                         const uint8_t* __restrict__ c, size_t sc,
                                                         const uint8_t* __restrict__ d, size_t sd, size_t B,
@@ -105,22 +104,27 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_quad(const uint
 
 size_t pairing_ws_words(size_t B) { return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64; }
 
+// Which form runs (measured on MI355X, profiles/r03_pairing_forms.txt): four lanes per check up to kQuadMaxBatch checks
+// -- the batch alone cannot give every SIMD two waves of the lane-pair kernels, and a check finishes in about 0.6 of the
+// time (6.9 instead of 10.9 ms at 4 096 checks, 8.5 instead of 11.4 ms at 16 384); two lanes per check above it, where the
+// quad form's exchanges and duplicated linear work cost more than its lower register pressure gains (27.0 against 22.4 ms
+// at 65 536).  TC_PAIRING_FORM = quad | pair | fused overrides the choice for experiments.
+constexpr size_t kQuadMaxBatch = 16384;
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws) {
   if (!B) return;
-  static const int quad = getenv("TC_PAIRING_QUAD") ? 1 : 0;   // experiments: four lanes per check
+  static const char* form = getenv("TC_PAIRING_FORM");
+  const bool fused = form && form[0] == 'f';
+  const bool quad = form ? form[0] == 'q' : B <= kQuadMaxBatch;
   if (quad) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(grid_for(B * kQuadLanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
   }
-  static const int mode = getenv("TC_PAIRING_FUSED") ? 1 : 0;  // experiments: the one-kernel form
-  if (mode || !ws) {
+  if (fused || !ws) {
     hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
   }
-  static const int w1 = getenv("TC_MILLER_W1") ? 1 : 0;  // experiments: one wave per SIMD, 512 registers (no spills)
-  if (w1) hipLaunchKernelGGL(k_miller_loop<1>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
-  else hipLaunchKernelGGL(k_miller_loop<TC_WAVES_G2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
+  hipLaunchKernelGGL(k_miller_loop, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
   hipLaunchKernelGGL(k_final_exp, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, (const int32_t*)ws, B, ok);
 }
 

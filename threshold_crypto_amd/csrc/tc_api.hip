@@ -254,7 +254,8 @@ void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const ui
 }
 
 // the same in G1 (k_msm.hip launch_msm_g1)
-void msm_g1(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out, uint8_t* d_st) {
+void msm_g1(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out, uint8_t* d_st,
+            int nbits = 128) {
   const size_t per_job = tc::msm_table_bytes_g1(n, 1);
   size_t tile = msm_table_budget(k) / (per_job ? per_job : 1);
   if (tile < 1) tile = 1;
@@ -263,7 +264,8 @@ void msm_g1(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const ui
   uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, tile));
   for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
     const size_t cnt = (B - lo < tile) ? B - lo : tile;
-    tc::launch_msm_g1(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 96, d_st + lo);
+    tc::launch_msm_g1(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 96, d_st + lo,
+                      nbits);
   }
 }
 
@@ -1077,6 +1079,118 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
     tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok, k.pairing_ws(B));
   }
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
+  k.end_timing();
+  return k.finish();
+}
+
+// Decryption-share validation by ONE random linear combination per ciphertext (opt-in fast path of the loop of
+// examples/threshold_enc.rs over PublicKeyShare::verify_decryption_share, src/lib.rs:182-186): instead of N checks
+// e(share_i, H) == e(pk_i, w) per ciphertext (H = hash_g1_g2(u, v)) the device checks
+//     e(sum_i r_i share_i, H) == e(sum_i r_i pk_i, w)
+// with secret r_i = a_i + b_i x^2 (2^63 values; a 16-step ladder through phi); ciphertexts whose combined check fails are
+// re-checked share by share, so ok[] equals the per-share path's up to 2^-63.
+int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* shares, const uint8_t* u,
+                                          const uint8_t* v, const uint64_t* off, const uint8_t* w, size_t B, const uint8_t* seed32,
+                                          uint8_t* ok, uint64_t* n_fallback) {
+  TC_REQUIRE(ctx);
+  if (n_fallback) *n_fallback = 0;
+  if (B == 0 || N == 0) return TC_OK;
+  TC_REQUIRE(ctx && pk_shares && shares && u && off && w && seed32 && ok);
+  TC_REQUIRE(B * N < (1ull << 32));
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || v);
+  const uint8_t* d_pk = k.in(pk_shares, N * 96);
+  const uint8_t* d_sh = k.in(shares, B * N * 96);
+  const uint8_t* d_u = k.in(u, B * 96);
+  const uint8_t* d_v = k.in(v, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  const uint8_t* d_w = k.in(w, B * 192);
+  uint8_t* d_seed = k.temp<uint8_t>(32);
+  if (d_seed) {
+    k.check(hipMemcpyAsync(d_seed, seed32, 32, hipMemcpyHostToDevice, ctx->stream), "seed copy");
+    ctx->h2d_bytes += 32;
+    k.wipe.emplace_back(d_seed, 32);
+  }
+  uint8_t* d_r = k.temp<uint8_t>(B * N * 32);
+  if (d_r) k.wipe.emplace_back(d_r, B * N * 32);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_D = k.temp<uint8_t>(B * 96);
+  uint8_t* d_Dc = k.temp<uint8_t>(B * 96);
+  uint8_t* d_P = k.temp<uint8_t>(B * 96);
+  uint8_t* d_st = k.temp<uint8_t>(3 * B);
+  uint8_t* d_okct = k.temp<uint8_t>(B);
+  uint8_t* d_ok = k.out(ok, B * N);
+  k.begin_timing();
+  k.check_points(false, d_pk, 96, N, N, 1, (size_t)-1);
+  k.check_points(false, d_sh, 96, N, N, B, 1);
+  k.check_points(false, d_u, 96, 1, 1, B, 1);
+  k.check_points(true, d_w, 192, 1, 1, B, 1);
+  std::vector<uint8_t> h_okct(B), h_st(3 * B);
+  if (!k.failed) {
+    tc::launch_rlc_scalars_g1(ctx->stream, d_seed, B * N, d_r);
+    k.check(hipMemsetAsync(d_st, 0, 3 * B, ctx->stream), "memset");
+    const uint32_t* rr = reinterpret_cast<const uint32_t*>(d_r);
+    msm_g1(k, N, N * 96, d_sh, rr, B, d_D, d_st, /*nbits=*/32);
+    msm_g1(k, N, 0, d_pk, rr, B, d_P, d_st + B, 32);
+    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st + 2 * B, /*fix=*/false);
+    tc::launch_g1_scale_cofactor_fix(ctx->stream, d_D, 96, B, d_Dc);
+    // e(D, [c] Q') = e([c] D, Q') == e(P, w)      (the folded hash constant of tc_verify_decryption_share_batch)
+    tc::launch_pairing_check(ctx->stream, d_Dc, 96, d_hash, 192, d_P, 96, d_w, 192, B, d_okct, k.pairing_ws(B));
+    k.apply_checks(B, nullptr, nullptr, 0, d_okct);  // checked-input mode: a ciphertext owning a non-member operand falls back
+    k.check(hipMemsetAsync(d_ok, 1, B * N, ctx->stream), "memset");
+    k.check(hipMemcpyAsync(h_okct.data(), d_okct, B, hipMemcpyDeviceToHost, ctx->stream), "ok readback");
+    k.check(hipMemcpyAsync(h_st.data(), d_st, 3 * B, hipMemcpyDeviceToHost, ctx->stream), "status readback");
+    ctx->d2h_bytes += 4 * B;
+    k.check(hipStreamSynchronize(ctx->stream), "stream sync");
+    std::vector<uint32_t> failed;
+    if (!k.failed)
+      for (size_t j = 0; j < B; j++)
+        if (!h_okct[j] || h_st[j] != TC_JOB_OK || h_st[B + j] != TC_JOB_OK || h_st[2 * B + j] != TC_JOB_OK) failed.push_back((uint32_t)j);
+    if (!k.failed && !failed.empty()) {
+      // per-share pairing checks for every share of the failed ciphertexts, on compacted operands
+      const size_t F = failed.size(), R = F * N;
+      std::vector<uint32_t> m_sh(R), m_ct(R), m_pk(R);
+      for (size_t f = 0; f < F; f++)
+        for (size_t i = 0; i < N; i++) {
+          m_sh[f * N + i] = (uint32_t)(failed[f] * N + i);
+          m_ct[f * N + i] = failed[f];
+          m_pk[f * N + i] = (uint32_t)i;
+        }
+      uint32_t* d_maps = k.temp<uint32_t>(3 * R);
+      uint8_t* c_sh = k.temp<uint8_t>(R * 96);
+      uint8_t* c_shc = k.temp<uint8_t>(R * 96);
+      uint8_t* c_hash = k.temp<uint8_t>(R * 192);
+      uint8_t* c_w = k.temp<uint8_t>(R * 192);
+      uint8_t* c_pk = k.temp<uint8_t>(R * 96);
+      uint8_t* c_ok = k.temp<uint8_t>(R);
+      if (!k.failed) {
+        k.check(hipMemcpyAsync(d_maps, m_sh.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        k.check(hipMemcpyAsync(d_maps + R, m_ct.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        k.check(hipMemcpyAsync(d_maps + 2 * R, m_pk.data(), R * 4, hipMemcpyHostToDevice, ctx->stream), "map copy");
+        ctx->h2d_bytes += 12 * R;
+        tc::launch_gather_rows(ctx->stream, d_sh, 96, d_maps, R, c_sh);
+        tc::launch_gather_rows(ctx->stream, d_hash, 192, d_maps + R, R, c_hash);
+        tc::launch_gather_rows(ctx->stream, d_w, 192, d_maps + R, R, c_w);
+        tc::launch_gather_rows(ctx->stream, d_pk, 96, d_maps + 2 * R, R, c_pk);
+        tc::launch_g1_scale_cofactor_fix(ctx->stream, c_sh, 96, R, c_shc);
+        tc::launch_pairing_check(ctx->stream, c_shc, 96, c_hash, 192, c_pk, 96, c_w, 192, R, c_ok, k.pairing_ws(R));
+        if (ctx->input_checks) {  // members only, as the per-share path would require
+          uint8_t* vv = k.temp<uint8_t>(R);
+          tc::launch_subgroup_check_g1(ctx->stream, c_sh, 96, 1, 1, R, vv);
+          tc::launch_invalidate_jobs(ctx->stream, vv, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          tc::launch_subgroup_check_g1(ctx->stream, c_pk, 96, 1, 1, R, vv);
+          tc::launch_invalidate_jobs(ctx->stream, vv, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          tc::launch_subgroup_check_g2(ctx->stream, c_w, 192, 1, 1, R, vv);
+          tc::launch_invalidate_jobs(ctx->stream, vv, 1, 1, R, nullptr, nullptr, 0, c_ok);
+        }
+        tc::launch_scatter_bytes(ctx->stream, c_ok, d_maps, R, d_ok);
+        k.check(hipStreamSynchronize(ctx->stream), "stream sync");  // the host maps go out of scope
+      }
+      if (n_fallback) *n_fallback = F;
+    }
+  }
   k.end_timing();
   return k.finish();
 }

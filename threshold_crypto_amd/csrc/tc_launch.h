@@ -93,7 +93,9 @@ void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* p
 // (msm_code_bytes), tables of msm_table_bytes_g1
 size_t msm_table_bytes_g1(size_t n, size_t B);
 void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B, int32_t* tbl,
-                   uint8_t* codes, uint8_t* out, uint8_t* status);
+                   uint8_t* codes, uint8_t* out, uint8_t* status, int nbits = 128);
+// random scalars for the batch validation of G1 values: a + b x^2 with a (odd), b from 32-bit draws of ChaCha20(seed, i)
+void launch_rlc_scalars_g1(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr);
 
 // opt-in operand validation (k_check.hip): valid[i] for point i = (record i / take, sample i % take) of
 // records of n_per_job points `stride` bytes apart; launch_invalidate_jobs fails the jobs that own an

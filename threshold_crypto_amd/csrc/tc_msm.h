@@ -204,7 +204,36 @@ TC_HD G1Affine msm_load_entry_g1(const int32_t* e) {
 // k (8 canonical words, < r) -> the 65 column codes of the base-4 sign-aligned form above, written `stride` bytes apart:
 // bits 0..2 table index, bit 3 = subtract (columns 0 .. 63); column 64: the index of the starting entry (0 or 3).
 // Returns true when r - k was recoded instead of k (k even; k1 = k mod x^2 must be odd): the caller negates the bases.
-TC_HD bool msm_g1_recode(const uint32_t* k, uint8_t* codes, size_t stride) {
+// nbits < 128 (even): SHORT scalars -- the caller promises k = k1 + k2 x^2 with k1 odd and k1, k2 < 2^nbits (the random
+// scalars of the batch validation of decryption shares); columns 0 .. nbits / 2 - 1 and the starting entry at column
+// nbits / 2, never flipped; *fits = false when the promise does not hold (the job fails).
+TC_HD bool msm_g1_recode(const uint32_t* k, uint8_t* codes, size_t stride, int nbits = 128, bool* fits = nullptr) {
+  if (nbits < 128) {
+    tc_u128 k1, k2;
+    glv_decompose(k, &k1, &k2);
+    const bool good = (k1 & 1) != 0 && (k1 >> nbits) == 0 && (k2 >> nbits) == 0;
+    if (fits) *fits = good;
+    if (!good) {
+      k1 = 1;
+      k2 = 0;
+    }
+    const tc_u128 neg = ~((k1 | 1) >> 1);
+    tc_u128 u = 0;
+    TC_NOUNROLL for (int i = 0; i < nbits; i++) {
+      const tc_u128 odd = k2 & 1;
+      u |= odd << i;
+      k2 = (k2 >> 1) + (odd & (neg >> i));
+    }
+    const int nc = nbits / 2;
+    TC_NOUNROLL for (int c = 0; c < nc; c++) {
+      const uint32_t n0 = (uint32_t)(neg >> (2 * c)) & 1u, n1 = (uint32_t)(neg >> (2 * c + 1)) & 1u;
+      const uint32_t u0 = (uint32_t)(u >> (2 * c)) & 1u, u1 = (uint32_t)(u >> (2 * c + 1)) & 1u;
+      codes[(size_t)c * stride] = (uint8_t)(u0 | (u1 << 1) | ((n0 == n1 ? 1u : 0u) << 2) | (n1 << 3));
+    }
+    codes[(size_t)nc * stride] = (uint8_t)(k2 ? 3 : 0);
+    return false;
+  }
+  if (fits) *fits = true;
   const bool flip = (k[0] & 1u) == 0;
   uint32_t kk[8];
   uint32_t borrow = 0;
@@ -233,7 +262,7 @@ TC_HD bool msm_g1_recode(const uint32_t* k, uint8_t* codes, size_t stride) {
 
 // Stage T in G1 for the chunk `c` of one job: tbl = (4 * chunks) shares x 8 entries x 32 words; codes: 65 columns x
 // (4 * chunks) shares, one byte each.
-TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes) {
+TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes, int nbits = 128) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G1Affine b0[kMsmChunk];
   G1Jac mult[2 * kMsmChunk];  // 2P, 3P
@@ -248,7 +277,10 @@ TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const ui
       ok &= limbs_lt_p<FrParams>(sc);
     }
     if (!ok) p = G1Affine::infinity();
-    const bool flip = msm_g1_recode(sc, codes + s, shares4);
+    if (s >= n && nbits < 128) sc[0] = 1;  // padding shares of the short-scalar mode: a valid short scalar (their point is the identity)
+    bool fits = true;
+    const bool flip = msm_g1_recode(sc, codes + s, shares4, nbits, &fits);
+    ok &= fits;
     p.y = Fq::select(flip, -p.y, p.y).norm();
     b0[k] = p;
     mult[2 * k] = jac_dbl(G1Jac::from_affine(p));
@@ -289,33 +321,33 @@ TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const ui
 
 // Stage L in G1 (one lane per part of a job): every special case of the addition handled -- the slow path and the
 // g++ reference of the fast form below
-TC_HD_NOINLINE G1Jac job_msm_ladder_g1_safe(size_t n, const int32_t* tbl, const uint8_t* codes, MsmPart part) {
+TC_HD_NOINLINE G1Jac job_msm_ladder_g1_safe(size_t n, const int32_t* tbl, const uint8_t* codes, MsmPart part, int top = 64) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G1Jac acc = G1Jac::infinity();
-  TC_NOUNROLL for (int col = 64; col >= 0; col--) {
-    if (col != 64) acc = jac_dbl(jac_dbl(acc));
+  TC_NOUNROLL for (int col = top; col >= 0; col--) {
+    if (col != top) acc = jac_dbl(jac_dbl(acc));
     const uint8_t* cc = codes + (size_t)col * shares4;
     TC_NOUNROLL for (size_t t = 0; t < part.trips; t++) {
       const bool take = part.s0 + t < part.s1;
       const size_t s = take ? part.s0 + t : part.s0;
       const uint32_t code = cc[s];
       G1Affine e = msm_load_entry_g1(tbl + (s * 8 + (code & 7)) * kMsmEntryWordsG1);
-      if (col != 64) e.y = Fq::select((code >> 3) & 1, -e.y, e.y);
+      if (col != top) e.y = Fq::select((code >> 3) & 1, -e.y, e.y);
       acc = G1Jac::select(take, jac_add_mixed(acc, e), acc);
     }
   }
   return acc;
 }
 template <bool SPLIT>
-TC_HD G1Jac job_msm_ladder_g1_part(size_t n, const int32_t* tbl, const uint8_t* codes, MsmPart part) {
+TC_HD G1Jac job_msm_ladder_g1_part(size_t n, const int32_t* tbl, const uint8_t* codes, MsmPart part, int top = 64) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   bool exc = false;
   G1Jac acc;
-  TC_NOUNROLL for (int col = 64; col >= 0; col--) {
+  TC_NOUNROLL for (int col = top; col >= 0; col--) {
     tc_fair();
     const uint8_t* cc = codes + (size_t)col * shares4;
     size_t t = 0;
-    if (col != 64) {
+    if (col != top) {
       acc = jac_dbl(jac_dbl(acc));
     } else {
       const G1Affine e0 = msm_load_entry_g1(tbl + (part.s0 * 8 + (size_t)(cc[part.s0] & 7)) * kMsmEntryWordsG1);
@@ -328,7 +360,7 @@ TC_HD G1Jac job_msm_ladder_g1_part(size_t n, const int32_t* tbl, const uint8_t* 
       const size_t s = take ? part.s0 + t : part.s0;
       const uint32_t code = cc[s];
       G1Affine e = msm_load_entry_g1(tbl + (s * 8 + (code & 7)) * kMsmEntryWordsG1);
-      if (col != 64) e.y = Fq::select((code >> 3) & 1, -e.y, e.y);
+      if (col != top) e.y = Fq::select((code >> 3) & 1, -e.y, e.y);
       if (SPLIT) {
         bool hit = false;
         const G1Jac sum = jac_add_mixed_generic(acc, e, hit);
@@ -339,7 +371,7 @@ TC_HD G1Jac job_msm_ladder_g1_part(size_t n, const int32_t* tbl, const uint8_t* 
       }
     }
   }
-  if (wave_any(exc)) acc = G1Jac::select(exc, job_msm_ladder_g1_safe(n, tbl, codes, part), acc);
+  if (wave_any(exc)) acc = G1Jac::select(exc, job_msm_ladder_g1_safe(n, tbl, codes, part, top), acc);
   return acc;
 }
 

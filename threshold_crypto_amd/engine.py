@@ -376,6 +376,27 @@ class Engine:
                    _ptr(share), _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(ok))
         return ok
 
+    def verify_decryption_shares_rlc(self, pk_shares, shares, u, v, off, w, seed=None):
+        """Decryption-share validation by one random linear combination per ciphertext (opt-in; see tc_amd.h): returns
+        (ok (B, N), number of ciphertexts that fell back to per-share checks)."""
+        import os
+        dev = self._mode(pk_shares, shares, u, v, off, w)
+        self._arg(pk_shares, (None, G1_BYTES), "u8", "pk_shares")
+        N = pk_shares.shape[0]
+        self._arg(u, (None, G1_BYTES), "u8", "u")
+        B = u.shape[0]
+        self._arg(shares, (B, N, G1_BYTES), "u8", "shares")
+        self._arg(w, (B, G2_BYTES), "u8", "w")
+        self._msgs(v, off, B)
+        seed = bytes(seed) if seed is not None else os.urandom(32)
+        if len(seed) != 32:
+            raise ValueError("seed: 32 bytes")
+        ok = self._empty(dev, (B, N), ref=shares)
+        nfb = ctypes.c_uint64(0)
+        self._call("tc_verify_decryption_shares_rlc_batch", _ptr(pk_shares), N, _ptr(shares), _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, seed,
+                   _ptr(ok), ctypes.byref(nfb))
+        return ok, int(nfb.value)
+
     # -- membership tests -----------------------------------------------------------------------------
     def g1_subgroup_check(self, pts):
         """ok[j] = pts[j] is a valid encoding of a point of G1 (on the curve, order r)"""

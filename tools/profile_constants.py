@@ -9,7 +9,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 units = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-KERNELS = {"combine_g2_t3": ("k_combine_fast<tc::Fq2>", "k_combine<tc::Fq2>"), "pairing_check": ("k_pairing_check",)}
+# per key: alternatives in order of preference; an alternative is one kernel or a tuple of kernels whose counters are summed
+# (the pairing check runs as k_miller_loop + k_final_exp since round 3)
+KERNELS = {"combine_g2_t3": ("k_combine_fast<tc::Fq2>", "k_combine<tc::Fq2>"), "pairing_check": (("k_miller_loop", "k_final_exp"), "k_pairing_check")}
 vals = {}
 for line in open(src):
     f = line.rstrip("\n").split(",")
@@ -19,17 +21,19 @@ for line in open(src):
 out = {"static_mad_share": {"fq2p_mul_call": round(588 / 732, 3), "fq2p_sqr_call": round(392 / 522, 3), "fq_mul_call": round(392 / 479, 3),
                             "is": "v_mad / all instructions of the out-of-line multiplier bodies (llvm-objdump of the shipped code object)"}}
 for key, names in KERNELS.items():
-    for name in names:
-        k = "tc::" + name
-        if (k, "FETCH_SIZE") in vals:
-            fetch_kb, write_kb = vals[(k, "FETCH_SIZE")], vals[(k, "WRITE_SIZE")]
-            out[key] = {"kernel": name, "units": units, "source": os.path.relpath(src, ROOT),
+    for alt in names:
+        parts = alt if isinstance(alt, tuple) else (alt,)
+        ks = ["tc::" + n for n in parts]
+        if all((k, "FETCH_SIZE") in vals for k in ks):
+            tot = lambda c: sum(vals.get((k, c), 0) for k in ks)
+            fetch_kb, write_kb = tot("FETCH_SIZE"), tot("WRITE_SIZE")
+            out[key] = {"kernel": " + ".join(parts), "units": units, "source": os.path.relpath(src, ROOT),
                         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
                         "traffic_bytes": int((2 * fetch_kb + write_kb) * 1024),
-                        "sq_insts_valu": int(vals.get((k, "SQ_INSTS_VALU"), 0)),
-                        "sq_wait_any_frac": round(vals.get((k, "SQ_WAIT_ANY"), 0) / max(vals.get((k, "SQ_WAVE_CYCLES"), 1), 1), 4),
-                        "sq_insts_lds": int(vals.get((k, "SQ_INSTS_LDS"), 0)),
-                        "sq_insts_scratch": int(vals.get((k, "SQ_INSTS_VMEM_RD"), 0) + vals.get((k, "SQ_INSTS_VMEM_WR"), 0))}
+                        "sq_insts_valu": int(tot("SQ_INSTS_VALU")),
+                        "sq_wait_any_frac": round(tot("SQ_WAIT_ANY") / max(tot("SQ_WAVE_CYCLES"), 1), 4),
+                        "sq_insts_lds": int(tot("SQ_INSTS_LDS")),
+                        "sq_insts_scratch": int(tot("SQ_INSTS_VMEM_RD") + tot("SQ_INSTS_VMEM_WR"))}
             break
 json.dump(out, open(os.path.join(ROOT, "profiles", "profile_constants.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
