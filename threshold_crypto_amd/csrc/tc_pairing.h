@@ -74,33 +74,49 @@ TC_HD void miller_ell(Fq12& f, const LineCoeffs& l, const G1Affine& p) {
   f = f.mul_by_014(l.c2, l.c1.scale(p.x), l.c0.scale(p.y));
 }
 
+// Where the loop finds its operands: the caller's arrays (registers).  (r03 experiment, profiles/r03_pairing_forms.txt: a
+// provider that re-read the G1 coordinates from LDS and the G2 points from HBM rows wherever the loop uses them -- 112 of
+// the loop's 280 live registers per lane no longer live -- made the kernel 4 % SLOWER; the provider interface stays.)
+struct MillerArrayOps {
+  const G1Affine* ps;
+  const G2Affine* qs;
+  TC_HD Fq px(int k) const { return ps[k].x; }
+  TC_HD Fq py(int k) const { return ps[k].y; }
+  TC_HD G2Affine q(int k) const { return qs[k]; }
+};
+
+// f *= line evaluated at the G1 point of pair k  (the `ell` of pairing 0.16)
+template <class OPS>
+TC_HD void miller_ell_ops(Fq12& f, const LineCoeffs& l, const OPS& ops, int k) {
+  f = f.mul_by_014(l.c2, l.c1.scale(ops.px(k)), l.c0.scale(ops.py(k)));
+}
+
 // f *= product of the lines of all pairs.  Two lines are multiplied with each other first (6 Fq2
 // products) and f by the result (17) -- 23 instead of the 2 x 13 of two sparse multiplications.
 // `fresh` (wave-uniform): f is still 1, the product of the two lines simply becomes f.
-template <int NP>
-TC_HD void miller_apply_lines(Fq12& f, const LineCoeffs* l, const G1Affine* ps, const bool* skip, bool fresh = false) {
+template <int NP, class OPS>
+TC_HD void miller_apply_lines(Fq12& f, const LineCoeffs* l, const OPS& ops, const bool* skip, bool fresh = false) {
   if (NP == 2) {
     if (!skip[0] && !skip[1]) {
-      const Fq12 lp = Fq12::line_product(l[0].c2, l[0].c1.scale(ps[0].x), l[0].c0.scale(ps[0].y), l[1].c2,
-                                         l[1].c1.scale(ps[1].x), l[1].c0.scale(ps[1].y));
+      const Fq12 lp = Fq12::line_product(l[0].c2, l[0].c1.scale(ops.px(0)), l[0].c0.scale(ops.py(0)), l[1].c2,
+                                         l[1].c1.scale(ops.px(1)), l[1].c0.scale(ops.py(1)));
       if (fresh) f = lp;
       else f = f.mul_by_line_product(lp);
       return;
     }
   }
   TC_UNROLL for (int k = 0; k < NP; k++)
-    if (!skip[k]) miller_ell(f, l[k], ps[k]);
+    if (!skip[k]) miller_ell_ops(f, l[k], ops, k);
 }
 
-// Product Miller loop over NP pairs (NP = 2 for every check on the path).
-template <int NP>
-TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
+// Product Miller loop over NP pairs (NP = 2 for every check on the path).  skip[k]: pair k has an operand at infinity.
+template <int NP, class OPS>
+TC_HD Fq12 miller_loop_ops(const OPS& ops, const bool* skip) {
   Fq12 f = Fq12::one();
   G2Jac r[NP];
-  bool skip[NP];
   TC_UNROLL for (int k = 0; k < NP; k++) {
-    skip[k] = ps[k].inf || qs[k].inf;
-    r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
+    const G2Affine q = ops.q(k);
+    r[k] = G2Jac{q.x, q.y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
   }
   // nothing to accumulate (every pair has an identity operand): the product of pairings is 1.
   // (Also keeps the bare squarings of the loop below, whose outputs are only carry-normalised,
@@ -114,18 +130,24 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
     tc_fair();
     TC_UNROLL for (int k = 0; k < NP; k++)
       if (!skip[k]) l[k] = miller_doubling_step(r[k]);
-    miller_apply_lines<NP>(f, l, ps, skip, i == 61);
+    miller_apply_lines<NP>(f, l, ops, skip, i == 61);
     if ((xs >> i) & 1ull) {
       TC_UNROLL for (int k = 0; k < NP; k++)
-        if (!skip[k]) l[k] = miller_addition_step(r[k], qs[k]);
-      miller_apply_lines<NP>(f, l, ps, skip);
+        if (!skip[k]) l[k] = miller_addition_step(r[k], ops.q(k));
+      miller_apply_lines<NP>(f, l, ops, skip);
     }
     f = f.sqr();
   }
   TC_UNROLL for (int k = 0; k < NP; k++)
     if (!skip[k]) l[k] = miller_doubling_step(r[k]);
-  miller_apply_lines<NP>(f, l, ps, skip);
+  miller_apply_lines<NP>(f, l, ops, skip);
   return f.conj();  // x < 0
+}
+template <int NP>
+TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
+  bool skip[NP];
+  TC_UNROLL for (int k = 0; k < NP; k++) skip[k] = ps[k].inf || qs[k].inf;
+  return miller_loop_ops<NP>(MillerArrayOps{ps, qs}, skip);
 }
 
 // Three compressed cyclotomic elements back to Fq12 with ONE shared inversion (Montgomery's trick).
