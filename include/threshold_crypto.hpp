@@ -488,6 +488,52 @@ inline std::vector<std::vector<bool>> verify_shares_rlc_batch(const std::vector<
   return out;
 }
 
+// PublicKey::verify (src/lib.rs:115-117) for many (signature, message) pairs under ONE key through one random linear
+// combination per group of 64 jobs (tc_verify_sig_rlc_batch, opt-in; groups that fail are re-checked job by job)
+inline std::vector<bool> verify_rlc_batch(const PublicKey& pk, const std::vector<Signature>& sigs, const Messages& msgs,
+                                          const std::array<std::uint8_t, 32>& seed, std::uint64_t* n_fallback = nullptr,
+                                          Engine& e = Engine::instance()) {
+  const std::size_t B = sigs.size();
+  if (B != msgs.size()) throw std::invalid_argument("one message per signature");
+  std::vector<std::uint8_t> sg(B * 192 + 1), ok(B + 1);
+  for (std::size_t j = 0; j < B; j++) std::memcpy(&sg[j * 192], sigs[j].g2.data(), 192);
+  std::uint64_t nfb = 0;
+  if (B) e.check(tc_verify_sig_rlc_batch(e.ctx(), pk.g1.data(), sg.data(), msgs.data(), msgs.off.data(), B, 0, seed.data(), ok.data(), &nfb));
+  if (n_fallback) *n_fallback = nfb;
+  std::vector<bool> out(B);
+  for (std::size_t j = 0; j < B; j++) out[j] = ok[j] != 0;
+  return out;
+}
+// The loop of examples/threshold_enc.rs over PublicKeyShare::verify_decryption_share (src/lib.rs:182-186) for B ciphertexts
+// x N nodes through one random linear combination per ciphertext (tc_verify_decryption_shares_rlc_batch, opt-in)
+inline std::vector<std::vector<bool>> verify_decryption_shares_rlc_batch(const std::vector<PublicKeyShare>& pk_shares,
+                                                                         const std::vector<std::vector<DecryptionShare>>& shares,
+                                                                         const std::vector<Ciphertext>& cts,
+                                                                         const std::array<std::uint8_t, 32>& seed,
+                                                                         std::uint64_t* n_fallback = nullptr, Engine& e = Engine::instance()) {
+  const std::size_t N = pk_shares.size(), B = cts.size();
+  if (shares.size() != B) throw std::invalid_argument("one share row per ciphertext");
+  std::vector<std::uint8_t> pk(N * 96 + 1), sh(B * N * 96 + 1), u(B * 96 + 1), w(B * 192 + 1), ok(B * N + 1);
+  Messages v;
+  for (std::size_t i = 0; i < N; i++) std::memcpy(&pk[i * 96], pk_shares[i].pk.g1.data(), 96);
+  for (std::size_t j = 0; j < B; j++) {
+    if (shares[j].size() != N) throw std::invalid_argument("every ciphertext needs one share per key");
+    for (std::size_t i = 0; i < N; i++) std::memcpy(&sh[(j * N + i) * 96], shares[j][i].g1.data(), 96);
+    std::memcpy(&u[j * 96], cts[j].u.data(), 96);
+    std::memcpy(&w[j * 192], cts[j].w.data(), 192);
+    v.push(cts[j].v.data(), cts[j].v.size());
+  }
+  std::uint64_t nfb = 0;
+  if (B && N)
+    e.check(tc_verify_decryption_shares_rlc_batch(e.ctx(), pk.data(), N, sh.data(), u.data(), v.data(), v.off.data(), w.data(), B, seed.data(), ok.data(),
+                                                  &nfb));
+  if (n_fallback) *n_fallback = nfb;
+  std::vector<std::vector<bool>> out(B, std::vector<bool>(N));
+  for (std::size_t j = 0; j < B; j++)
+    for (std::size_t i = 0; i < N; i++) out[j][i] = ok[j * N + i] != 0;
+  return out;
+}
+
 // Poly::commitment (src/poly.rs:372-377) / BivarPoly::commitment (:625-632): coefficient * g1 for every Fr
 // coefficient, fixed-base on the device (LDS window table of the generator)
 inline std::vector<G1Bytes> commitment(const std::vector<FrBytes>& coeff, Engine& e = Engine::instance()) {

@@ -135,6 +135,32 @@ int main(int argc, char** argv) {
       }
     auto gsig = grp.combine_signatures(4, gidx, gsh, gst);
     for (std::size_t j = 0; j < jobs.size(); j++) CHECK(gst[j] == 0 && gsig[j] == combined[j]);
+    auto moved = grp.transfer_bytes();
+    CHECK(moved.first >= gsh.size() && moved.second >= combined.size() * 192);
+    threw = false;
+    try { gidx.pop_back(); grp.combine_signatures(4, gidx, gsh, gst); } catch (const GpuError&) { threw = true; }
+    CHECK(threw);  // sizes that do not match n are refused before the C ABI sees them
+    // -- round 3: same-key signature batches and decryption shares by random linear combination ------------------------
+    std::vector<Signature> swapped(combined.begin(), combined.end());
+    swapped[11] = combined[12];
+    nfb = 0;
+    auto okr = verify_rlc_batch(pk_set.public_key(), swapped, m, seed, &nfb);
+    for (std::size_t j = 0; j < swapped.size(); j++) CHECK(okr[j] == (j != 11));
+    CHECK(nfb == 64);  // the group of 64 jobs that holds job 11 was re-checked job by job
+    std::vector<Ciphertext> cts = {ct, ct};
+    std::vector<std::vector<DecryptionShare>> drows(2);
+    for (std::uint32_t i = 0; i < n; i++) {
+      auto d = shares[i].decrypt_share(ct);
+      CHECK(d.has_value());
+      drows[0].push_back(*d);
+      drows[1].push_back(*d);
+    }
+    drows[1][4] = drows[1][6];  // node 4 hands in node 6's share for the second ciphertext
+    nfb = 0;
+    auto okd = verify_decryption_shares_rlc_batch(pks, drows, cts, seed, &nfb);
+    CHECK(nfb == 1);
+    for (std::size_t j = 0; j < 2; j++)
+      for (std::uint32_t i = 0; i < n; i++) CHECK(okd[j][i] == !(j == 1 && i == 4));
   }
   std::puts("CPP-API-OK");
   return 0;

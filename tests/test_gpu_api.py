@@ -153,6 +153,35 @@ def test_share_validation_loop_of_threshold_sig_example(rnd):
     assert [p.raw for p in pk_shares] == [o.g1_uncompressed(o.public_key(sk_set.secret_key_share(i).fr)) for i in range(n)]
 
 
+def test_opt_in_rlc_paths_through_the_api_mirror(rnd):
+    """The two round-3 random-linear-combination paths from the reference's vocabulary: PublicKey.verify_batch(rlc=True)
+    (many signatures under one key) and PublicKeyShare.verify_decryption_shares_rlc (the loop of
+    examples/threshold_enc.rs); same booleans as the per-item methods, a liar caught in both."""
+    t, n = 2, 5
+    sk_set = random_sk_set(t, rnd)
+    pk_set = sk_set.public_keys()
+    sk = SecretKey(rnd.randrange(o.R))
+    pk = sk.public_key()
+    msgs = [b"block %d" % i for i in range(70)]
+    sigs = [sk.sign(m) for m in msgs]
+    sigs[41] = sk.sign(b"something else")
+    want = pk.verify_batch(sigs, msgs)
+    assert want.tolist() == [i != 41 for i in range(70)]
+    assert (pk.verify_batch(sigs, msgs, rlc=True) == want).all()
+    pk_master = o.g1_from_uncompressed(pk_set.public_key().raw, check=False)
+    cts = []
+    for j in range(3):
+        u, v, w = o.encrypt_with_r(pk_master, rnd.randrange(1, o.R), b"ciphertext %d" % j)
+        cts.append(Ciphertext(o.g1_uncompressed(u), v, o.g2_uncompressed(w)))
+    pk_shares = pk_set.public_key_shares(list(range(n)))
+    shares = [[sk_set.secret_key_share(i).decrypt_share(ct) for i in range(n)] for ct in cts]
+    shares[1][2] = shares[1][3]                                   # node 2 hands in somebody else's share
+    ok = api.PublicKeyShare.verify_decryption_shares_rlc(pk_shares, shares, cts)
+    for j in range(3):
+        for i in range(n):
+            assert ok[j, i] == pk_shares[i].verify_decryption_share(shares[j][i], cts[j]) == (not (j == 1 and i == 2))
+
+
 def test_larger_threshold_general_path(engine, rnd):
     """t = 9 (three Straus chunks, general Lagrange path) and indices beyond the fast path's range."""
     t = 9

@@ -222,11 +222,16 @@ class PublicKey(_G1Value):
             raise ValueError("one hash point per signature")
         return e.verify_g2(_u8(self.raw), _stack([s.raw for s in sigs], 192), _stack(hashes, 192)).astype(bool)
 
-    def verify_batch(self, sigs, msgs, engine=None):
+    def verify_batch(self, sigs, msgs, engine=None, rlc=False, seed=None):
+        """PublicKey::verify for many (signature, message) pairs under THIS key.  rlc=True: the opt-in random linear
+        combination per group of 64 jobs (tc_verify_sig_rlc_batch; groups that fail are re-checked job by job, so the
+        booleans are the per-job ones up to 2^-63); `seed`: 32 secret random bytes drawn after the signatures arrived."""
         e = engine or default_engine()
         if len(sigs) != len(msgs):
             raise ValueError("one message per signature")
         flat, off = pack_messages([bytes(m) for m in msgs])
+        if rlc:
+            return e.verify_sig_rlc(_u8(self.raw), _stack([s.raw for s in sigs], 192), flat, off, seed=seed)[0].astype(bool)
         return e.verify_sig(_u8(self.raw), _stack([s.raw for s in sigs], 192), flat, off).astype(bool)
 
 
@@ -246,6 +251,21 @@ class PublicKeyShare(PublicKey):
         return e.verify_decryption_share(_stack([p.raw for p in pk_shares], 96), _stack([s.raw for s in shares], 96),
                                          _stack([c.u for c in cts], 96), v, off,
                                          _stack([c.w for c in cts], 192)).astype(bool)
+
+    @staticmethod
+    def verify_decryption_shares_rlc(pk_shares, shares, cts, engine=None, seed=None):
+        """The loop of examples/threshold_enc.rs over verify_decryption_share for B ciphertexts x N nodes by ONE random
+        linear combination per ciphertext (opt-in, tc_verify_decryption_shares_rlc_batch): pk_shares: the N key shares,
+        shares[j][i]: node i's decryption share of cts[j]; returns a (B, N) boolean array."""
+        e = engine or default_engine()
+        N = len(pk_shares)
+        if len(shares) != len(cts) or any(len(row) != N for row in shares):
+            raise ValueError("one row of N decryption shares per ciphertext")
+        v, off = pack_messages([c.v for c in cts])
+        sh = np.stack([_stack([s.raw for s in row], 96) for row in shares])
+        ok, _ = e.verify_decryption_shares_rlc(_stack([p.raw for p in pk_shares], 96), sh, _stack([c.u for c in cts], 96), v, off,
+                                               _stack([c.w for c in cts], 192), seed=seed)
+        return ok.astype(bool)
 
     @staticmethod
     def verify_batch_shares(pk_shares, sig_shares, msgs, engine=None):

@@ -236,10 +236,9 @@ int tc_group_create(tc_group** out, const int* devices, int ndev) {
   }
   // duplicate device ids (several ranks on ONE GPU) are accepted so that the sharding / threading logic can be
   // exercised on a single-GPU box; the exchange steps then use device-to-device copies instead of RCCL
-  for (int r = 0; r < ndev; r++) {
-    g->workers.push_back(new Worker());
-    g->workers[r]->th = std::thread(worker_main, g, r);
-  }
+  // (all Worker objects exist before the first thread starts: a worker reads g->workers[r] on entry)
+  for (int r = 0; r < ndev; r++) g->workers.push_back(new Worker());
+  for (int r = 0; r < ndev; r++) g->workers[r]->th = std::thread(worker_main, g, r);
   *out = g;
   return TC_OK;
 }
