@@ -236,6 +236,64 @@ while time.time() < t_end:
     if (rok != rexp).any() or nfb != int((rexp.min(axis=1) == 0).sum()):
         fail("verify_shares_rlc", rounds, int(np.flatnonzero((rok != rexp).any(axis=1))[0]) if (rok != rexp).any() else -1, "nfb=%d" % nfb)
     checked += Bg * (ng + 2 + Nr)
+    # ---- round-3 entries: same-key signature batches and decryption shares by random linear combination, G1 linear
+    # combinations through the two-stage kernels -------------------------------------------------------------------------------
+    Bs = min(B, 40)
+    sm = msgs[:Bs]
+    sflat, soff = pack_messages(sm)
+    ssig = np.zeros((Bs, 192), np.uint8)
+    shash = np.zeros((Bs, 192), np.uint8)
+    sexp = np.ones(Bs, np.uint8)
+    for j in range(Bs):
+        hj = c_oracle.hash_g2(sm[j])
+        shash[j] = u8(hj)
+        r_ = rnd.random()
+        good = r_ < 0.9
+        enc = c_oracle.g2_mul(fr((sk0 + (0 if good else 1)) % o.R), hj)[1]
+        if r_ > 0.97:
+            enc, good = maybe_corrupt(enc), None
+        ssig[j] = u8(enc)
+        sexp[j] = int(c_oracle.pairing_check(pk0, hj, G1U, enc) == 1)
+    grp = rnd.choice([0, 4, 7, 64])
+    sok, nfb = e.verify_g2_rlc(u8(pk0), ssig, shash, group=grp, seed=rbytes(32))
+    if (sok != sexp).any():
+        fail("verify_g2_rlc", rounds, int(np.flatnonzero(sok != sexp)[0]), "group=%d" % grp)
+    sok, nfb = e.verify_sig_rlc(u8(pk0), ssig, sflat, soff, group=grp, seed=rbytes(32))
+    if (sok != sexp).any():
+        fail("verify_sig_rlc", rounds, int(np.flatnonzero(sok != sexp)[0]), "group=%d" % grp)
+    Bd, Nd = min(B, 12), rnd.choice([1, 3, 10])
+    dsk = [rnd.randrange(1, o.R) for _ in range(Nd)]
+    dpk = np.stack([u8(c_oracle.g1_mul(fr(k), G1U)[1]) for k in dsk])
+    dm = msgs[:Bd]
+    dflat, doff = pack_messages(dm)
+    du = np.zeros((Bd, 96), np.uint8); dw = np.zeros((Bd, 192), np.uint8); dsh = np.zeros((Bd, Nd, 96), np.uint8)
+    dexp = np.zeros((Bd, Nd), np.uint8)
+    for j in range(Bd):
+        rj = rnd.randrange(1, o.R)
+        uj = c_oracle.g1_mul(fr(rj), G1U)[1]
+        du[j] = u8(uj)
+        rc, hj = c_oracle.hash_g1_g2(uj, dm[j])
+        dw[j] = u8(c_oracle.g2_mul(fr((rj + (0 if rnd.random() < 0.9 else 1)) % o.R), hj)[1])
+        for i_ in range(Nd):
+            dsh[j, i_] = u8(c_oracle.g1_mul(fr((dsk[i_] + (0 if rnd.random() < 0.9 else 1)) % o.R), uj)[1])
+            dexp[j, i_] = int(c_oracle.pairing_check(bytes(dsh[j, i_]), hj, bytes(dpk[i_]), bytes(dw[j])) == 1)
+    dok, nfb = e.verify_decryption_shares_rlc(dpk, dsh, du, dflat, doff, dw, seed=rbytes(32))
+    if (dok != dexp).any():
+        fail("verify_decryption_shares_rlc", rounds, int(np.flatnonzero((dok != dexp).any(axis=1))[0]))
+    nl = rnd.choice([8, 9, 13, 20])
+    lsc = [[rnd.choice([0, 1, 2, o.R - 1, rnd.randrange(o.R), rnd.randrange(1 << 64)]) for _ in range(nl)] for _ in range(Bd)]
+    lpt = [[maybe_corrupt(rnd.choice(pool1)) for _ in range(nl)] for _ in range(Bd)]
+    lout, lst = e.lincomb_g1(np.stack([np.stack([u8(fr(k)) for k in row]) for row in lsc]), np.stack([np.stack([u8(p) for p in row]) for row in lpt]))
+    for j in range(Bd):
+        acc, bad_ = None, False
+        for k_, p_ in zip(lsc[j], lpt[j]):
+            rc, term = c_oracle.g1_mul(fr(k_), p_)
+            bad_ = bad_ or rc != 0
+            if rc == 0:
+                acc = o.E1.add(acc, o.g1_from_uncompressed(term, check=False))
+        if (lst[j] != 0) != bad_ or (not bad_ and bytes(lout[j]) != o.g1_uncompressed(acc)):
+            fail("lincomb_g1", rounds, j, "n=%d" % nl)
+    checked += 2 * Bs + Bd * (Nd + 1)
     # ---- compressed round trip ------------------------------------------------------------------------
     c2, stc = e.g2_compress(np.stack([u8(p) for p in pts2]))
     d2, std = e.g2_decompress(c2)

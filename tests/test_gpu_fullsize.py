@@ -493,3 +493,39 @@ def test_config5_one_gpu_slice_properties(engine):
         shares = [c.g2_mul(bytes(km.sk_table[int(i)]), bytes(hashes[j]))[1] for i in res["idx"][j]]
         rc, want = c.combine_g2(67, [int(i) for i in res["idx"][j]], shares)
         assert rc == 0 and want == res["sig"][j].tobytes()
+
+
+def test_pairing_forms_agree_on_a_planted_batch():
+    """The three forms of the pairing check (k_pairing.hip: four lanes per check, two lanes per check as two kernels, the
+    fused two-lane kernel) are picked by batch size; forced one after the other (TC_PAIRING_FORM, one process each) they
+    must return the SAME booleans on 20 000 checks with every 7th signature replaced by its neighbour's, an operand at
+    infinity and an undecodable one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import hashlib, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from threshold_crypto_amd.engine import Engine
+from threshold_crypto_amd.workload import ThresholdSigWorkload
+B = 20000
+e = Engine(0)
+e.set_input_checks(False)
+wl = ThresholdSigWorkload(e, 1, 3, B)
+sig, st = e.combine_g2(1, wl.idx, wl.shares)
+bad = sig.copy()
+bad[::7] = sig[(np.arange(0, B, 7) + 1) %% B]
+bad[5] = 0; bad[5, 0] = 0x40          # the identity as a signature
+bad[9, 17] ^= 0x10                    # undecodable
+ok = e.verify_g2(wl.master_pk, bad, wl.hashes)
+want = np.ones(B, np.uint8); want[::7] = 0; want[5] = 0; want[9] = 0
+assert (ok == want).all(), np.flatnonzero(ok != want)[:10]
+print("FORM-OK", hashlib.sha256(ok.tobytes()).hexdigest())
+""" % root
+    digests = set()
+    for form in ("quad", "pair", "fused"):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, TC_PAIRING_FORM=form))
+        assert out.returncode == 0 and "FORM-OK" in out.stdout, (form, out.stderr[-1500:])
+        digests.add(out.stdout.split("FORM-OK")[1].strip())
+    assert len(digests) == 1
