@@ -206,7 +206,9 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     ranks_info = {"world_size": 1, "backend": None, "launched_by": os.environ.get("TC_BENCH_LAUNCHED_BY", "direct")}
-    if world > 1:
+    # started by a launcher (RANK/WORLD_SIZE in the environment): join its rendezvous -- also as the only rank, so that
+    # `torch.distributed.run --nproc-per-node 1 bench.py` takes every collective of the N-rank run through RCCL
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if harness:
@@ -253,7 +255,7 @@ def main(argv=None):
         if harness:
             result["test_harness"] = eng.version() + ": rank start-up / sharding / collectives exercised, NOT a measurement"
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if ranks_info["backend"] is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
@@ -272,8 +274,8 @@ def run_config2(args, eng, dev, rank, world, peak):
     import numpy as np
     import torch
     from threshold_crypto_amd.workload import ThresholdSigWorkload, ThresholdEncWorkload
-    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range, total_count, max_over_ranks
-    if world > 1:
+    from threshold_crypto_amd.parallel import broadcast_key_set, shard_range, total_count, max_over_ranks, joined
+    if joined(world):
         import torch.distributed as dist
     harness = getattr(eng, "is_test_harness", False)
     cuda = dev.type == "cuda"
@@ -298,7 +300,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         eng.sync()
         if cuda:
             torch.cuda.synchronize()
-        if world > 1:
+        if joined(world):
             dist.barrier()
             if cuda:
                 torch.cuda.synchronize()

@@ -294,3 +294,32 @@ def test_bench_line_contract():
     s = d["streaming"]
     assert s["overlapped"] is True and s["contexts"] == 2 and s["value"] > 0
     assert d["sustained"]["seconds"] >= 0.15 and d["config3"]["kernel_ms"] > 0
+
+
+@pytest.mark.parametrize("config", [2, 5])
+def test_bench_under_the_launcher_runs_its_collectives_over_rccl(config):
+    """The driver's multi-GPU command shape with the one GPU this box has: `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1`.  bench.py joins the launcher's rendezvous with backend nccl (= RCCL) bound to its device, so the
+    key-set broadcast, the barriers around the timed region, the MAX of the region, the valid-count all-reduce and the
+    record all-gather all run through RCCL on the GPU -- the code path of the N-rank run, which this box cannot start."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    extra = ["--batch", "8192", "--no-extras", "--sustain-seconds", "0.2"] if config == 2 else ["--config", "5", "--batch", "2048"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29551 + config), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["ranks"]["backend"] == "nccl" and d["ranks"]["world_size"] == 1 and len(d["ranks"]["devices"]) == 1
+    assert d["ranks"]["rccl_version"] not in (None, "unknown") and "external launcher" in d["ranks"]["launched_by"]
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    if config == 5:
+        assert d["valid_total_all_ranks"] == 2048 and d["rank_records_start_jobs_valid_digest"][0][:3] == [0, 2048, 2048]
+    else:
+        assert d["verified_all"] is True

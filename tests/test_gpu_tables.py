@@ -175,7 +175,7 @@ def test_comb_signing_many_signers_vs_oracle(engine, wl):
     pts[6, 100] ^= 1                                 # not on the curve any more
     out, st = engine.sign_shares_g2(sk, idx, pts)
     assert st.shape == (B, n) and out.shape == (B, n, 192)
-    for j in (0, 1, 2, 3, 4, 5, 95, B - 1):
+    for j in (0, 1, 2, 3, 4, 5, 95, 96, 97, 511, 512, 4095, 4096, 4097, B - 2, B - 1):
         for s in range(n):
             if j == 4 and s == 7:
                 assert st[j, s] == 3 and bytes(out[j, s]) == bytes(inf)

@@ -244,6 +244,25 @@ def test_bench_gpus_2_config5_on_two_ranks():
     assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[0, 2, 2], [2, 2, 2]]
 
 
+def test_bench_under_a_launcher_joins_the_rendezvous_even_as_the_only_rank():
+    """The driver's N>1 command shape (`python -m torch.distributed.run ... bench.py --gpus N`) with N = 1: bench.py joins the
+    launcher's rendezvous and takes every collective (key-set broadcast, barriers, MAX of the timed region, the count
+    all-reduce) through the process group -- the same run goes through RCCL on a one-GPU box (tests/test_gpu_api.py)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "3", "--t", "1", "--signers", "3",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    d = lines[0]
+    assert len(lines) == 1 and d["n_gpus"] == 1 and d["ranks"]["backend"] == "gloo" and d["ranks"]["devices"] == ["cpu:0"]
+    assert "external launcher" in d["ranks"]["launched_by"] and d["verified_all"] is True
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """--gpus N on a node with fewer GPUs fails loudly instead of reporting an N-GPU number (this container has none)."""
     import torch

@@ -140,7 +140,7 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
         eng.sync()
         if cuda:
             torch.cuda.synchronize()
-        if world > 1:
+        if parallel.joined(world):
             import torch.distributed as dist
             dist.barrier()
             if cuda:

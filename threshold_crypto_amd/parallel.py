@@ -19,11 +19,22 @@ def shard_range(total, world, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def joined(world):
+    """True when this process takes part in collectives: more than one rank, or one rank that a launcher started
+    and that joined the rendezvous (bench.py does, so `torch.distributed.run --nproc-per-node 1` drives every
+    collective below through RCCL on a one-GPU box)."""
+    if world > 1:
+        return True
+    import sys
+    td = sys.modules.get("torch.distributed")
+    return bool(td is not None and td.is_available() and td.is_initialized())
+
+
 def broadcast_key_set(tensor, world, src=0):
     """Rank `src` holds key-set material (the PublicKeySet commitment, (t+1) x 96 B; for on-device signing also
     the N x 32 B table of secret key shares); every rank gets a copy in place.  (t+1)*96 B at t=67 is 6.5 KB, the
     share table at N=200 6.4 KB: latency-bound, one call per key set."""
-    if world <= 1:
+    if not joined(world):
         return tensor
     import torch.distributed as dist
     dist.broadcast(tensor, src=src)
@@ -32,7 +43,7 @@ def broadcast_key_set(tensor, world, src=0):
 
 def total_count(local_count, world, device=None):
     """Sum of per-rank counts (1 x int64 all-reduce)."""
-    if world <= 1:
+    if not joined(world):
         return int(local_count)
     import torch
     import torch.distributed as dist
@@ -43,7 +54,7 @@ def total_count(local_count, world, device=None):
 
 def max_over_ranks(value, world, device=None):
     """Max of a per-rank float (the bench contract's MAX over ranks of the timed region)."""
-    if world <= 1:
+    if not joined(world):
         return float(value)
     import torch
     import torch.distributed as dist
@@ -61,7 +72,7 @@ def gather_records(record, world, device=None):
     """All-gather of one small int64 record per rank (e.g. [start, count, valid, digest]); returns a list of
     lists, rank order."""
     rec = [int(x) for x in record]
-    if world <= 1:
+    if not joined(world):
         return [rec]
     import torch
     import torch.distributed as dist
