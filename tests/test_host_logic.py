@@ -208,6 +208,13 @@ def test_committed_bench_lines_are_self_consistent():
 
 
 # ---- bench.py --gpus N starts N ranks itself ---------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _run_bench(*argv, timeout=900):
     import json
     import subprocess
@@ -252,7 +259,7 @@ def test_bench_under_a_launcher_joins_the_rendezvous_even_as_the_only_rank():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29547",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "1", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "3", "--t", "1", "--signers", "3",
            "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
