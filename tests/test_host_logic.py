@@ -165,7 +165,7 @@ def test_committed_bench_lines_are_self_consistent():
     # round 3: the headline is K steps on ONE stream (per-launch event times measured inside the timed region), the two-contexts
     # figure is the `streaming` object; a mechanical reader's check kernel_ms <= ms_per_step holds; every leg of configs 2-4
     # carries its own roofline
-    d = json.loads([l for l in open(os.path.join(root, "profiles", "r03_b_bench.txt")) if l.startswith("{")][-1])
+    d = json.loads([l for l in open(os.path.join(root, "profiles", "r03_c_bench.txt")) if l.startswith("{")][-1])
     B = d["config"]["batch_per_gpu"]
     assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 == d["ranks"]["world_size"] and d["vs_baseline"] is None
     assert d["config"]["overlapped"] is False and d["config"]["steps_in_flight"] == 1
@@ -184,10 +184,10 @@ def test_committed_bench_lines_are_self_consistent():
     assert d["config4"]["roofline"]["executed_macs_per_unit"] == macs["verify_g2"] + macs["hash_g1_g2"] + macs["combine_g1_t3_fast"]
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] / d["cpu_baseline"]["value"] > 100
     prof = json.load(open(os.path.join(root, "profiles", "profile_constants.json")))
-    assert prof["combine_g2_t3"]["source"] == "profiles/r03_b_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
+    assert prof["combine_g2_t3"]["source"] == "profiles/r03_c_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
     # (the line embeds the constants of the capture BEFORE it -- the capture that goes with it produces the next ones)
     assert d["roofline"]["traffic"] > 50 * d["roofline"]["algorithmic_bytes_per_launch"] and "profiles/" in d["roofline"]["traffic_is"]
-    summary = open(os.path.join(root, "profiles", "r03_b_rocprofv3_summary.csv")).read()
+    summary = open(os.path.join(root, "profiles", "r03_c_rocprofv3_summary.csv")).read()
     for k in ("k_combine_fast<tc::Fq2>", "k_miller_loop", "k_final_exp", "k_hash_g2", "k_hash_g1_g2", "k_g2_mul_shared", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
         assert k in summary, k
     # frac reproducible from the profile within 5 %: executed multiply-adds / the profile's average duration

@@ -291,33 +291,80 @@ TC_HD void glv_decompose(const uint32_t* k, tc_u128* k1, tc_u128* k2) {
   *k2 = (tc_u128)d[3] * BLS_X_ABS + d[2];
 }
 
-// [k] P for P in G1, k < r: joint 128-step ladder over the affine table {P, -phi(P), P - phi(P)}
+// k (8 canonical LE words, k <= r) in the base-4 sign-aligned form of the 2-dimensional decomposition:
+//     k' = k1 + k2 x^2,  k1 odd:   k1 = sum_i s_i 2^i,  k2 = sum_i s_i u_i 2^i   (i = 0 .. 128, s_i = +-1, s_128 = +1, u_i in {0, 1})
+// k' = k when k is odd, r - k otherwise (r is odd, x^2 is even, so k1 = k' mod x^2 is odd): returns true in that case and the
+// caller negates the base point.  *neg: bit i set <=> s_i = -1 (i < 128); *u: the u_i (i < 128); *top = u_128.
+TC_HD bool glv_recode_sign_aligned(const uint32_t* k, tc_u128* neg_out, tc_u128* u_out, bool* top) {
+  const bool flip = (k[0] & 1u) == 0;
+  uint32_t kk[8];
+  uint32_t borrow = 0;
+  TC_UNROLL for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)FR_P[i] - k[i] - borrow;
+    borrow = (uint32_t)(t >> 63);
+    kk[i] = flip ? (uint32_t)t : k[i];
+  }
+  tc_u128 k1, k2;
+  glv_decompose(kk, &k1, &k2);
+  const tc_u128 neg = ~((k1 | 1) >> 1);
+  tc_u128 u = 0;
+  TC_NOUNROLL for (int i = 0; i < 128; i++) {
+    const tc_u128 odd = k2 & 1;
+    u |= odd << i;
+    k2 = (k2 >> 1) + (odd & (neg >> i));
+  }
+  *neg_out = neg;
+  *u_out = u;
+  *top = k2 != 0;
+  return flip;
+}
+
+// [k] P for P in G1, k < r: the columns of the sign-aligned form two at a time (base 4).  Columns 2c and 2c+1 contribute
+//     4^c sigma (A P + B phi'),  phi' = -phi(P) = [x^2] P,  sigma = s_{2c+1},  A = 2 + e in {1, 3},  B = e u_{2c} + 2 u_{2c+1},
+//     e = s_{2c} s_{2c+1}:   one of { P, P - phi', P + 2 phi', P + phi', 3P, 3P + phi', 3P + 2 phi', 3P + 3 phi' }
+// (index u_{2c} + 2 u_{2c+1}, + 4 when e = +1), added or subtracted; column 128 starts the accumulator with P or P + phi'.
+// 64 steps of two doublings and ONE mixed addition -- 128 doublings + 64 additions + a 7-addition table instead of the 128
+// doublings + 128 additions of the binary joint ladder (a wave takes the addition of a column whenever one of its lanes
+// does).  The table is brought to one common Z without an inversion (tc_curve.h jac_batch_to_common_z: its entries are
+// affine points of an isomorphic curve, the result gets the common Z back).  Same recoding as the two-stage G1 kernels
+// (tc_msm.h msm_g1_recode), which keep their tables in HBM.
 TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   if (p.inf) return G1Jac::infinity();
-  tc_u128 k1, k2;
-  glv_decompose(k, &k1, &k2);
-  G1Affine tbl[4];
-  tbl[1] = p;
-  tbl[2] = g1_phi(p);
-  tbl[2].y = (-tbl[2].y);  // -phi(P) = [x^2] P
-  // P - phi(P) keeps its Jacobian (X, Y); the other two entries are scaled to its Z (tc_curve.h
-  // jac_batch_to_common_z explains the isomorphic-curve argument)
-  const G1Jac sum = jac_add_affine(p, tbl[2]);
-  const bool sum_inf = sum.is_inf();
-  const Fq zc = Fq::select(sum_inf, Fq::one(), sum.z);
+  tc_u128 neg, u;
+  bool top;
+  const bool flip = glv_recode_sign_aligned(k, &neg, &u, &top);
+  G1Affine b = p;
+  b.y = Fq::select(flip, -p.y, p.y).norm();
+  const G1Jac p2 = jac_dbl(G1Jac::from_affine(b));
+  const G1Jac p3 = jac_add_mixed(p2, b);
+  const Fq beta = Fq::from_limbs(G1_BETA);
+  const G1Affine m1{b.x * beta, b.y, false};                  // phi(P) = -phi'(P)
+  const G1Affine f1{m1.x, (-b.y).norm(), false};              // phi'(P)
+  const G1Jac f2{p2.x * beta, (-p2.y).norm(), p2.z};          // phi'(2P) = 2 phi'(P)
+  const G1Jac f3{p3.x * beta, (-p3.y).norm(), p3.z};          // phi'(3P)
+  G1Jac e[7];
+  e[0] = jac_add_affine(b, m1);    // 1: P - phi'
+  e[1] = jac_add_mixed(f2, b);     // 2: P + 2 phi'
+  e[2] = jac_add_affine(b, f1);    // 3: P + phi'
+  e[3] = p3;                       // 4: 3P
+  e[4] = jac_add_mixed(p3, f1);    // 5: 3P + phi'
+  e[5] = jac_add(p3, f2);          // 6: 3P + 2 phi'
+  e[6] = jac_add(p3, f3);          // 7: 3P + 3 phi'
+  G1Affine tbl[8];
+  const Fq zc = jac_batch_to_common_z<Fq, 8>(e, tbl + 1, 7);
   const Fq zc2 = zc.sqr();
-  const Fq zc3 = zc2 * zc;
-  tbl[3] = G1Affine{sum.x, sum.y, sum_inf};
-  tbl[1] = affine_scale_z(tbl[1], zc2, zc3);
-  tbl[2] = affine_scale_z(tbl[2], zc2, zc3);
-  // (the branch-free generic addition of the G2 ladders does not pay here: with a `started` flag and its selects this
-  // one-wave-per-SIMD kernel measured 20 % slower)
-  G1Jac acc = G1Jac::infinity();
-  TC_NOUNROLL for (int bit = 127; bit >= 0; bit--) {
+  tbl[0] = affine_scale_z(b, zc2, zc2 * zc);
+  G1Jac acc = G1Jac::from_affine(tbl[top ? 3 : 0]);
+  TC_NOUNROLL for (int c = 63; c >= 0; c--) {
     tc_fair();
-    acc = jac_dbl(acc);
-    const uint32_t m = (uint32_t)((k1 >> bit) & 1) | ((uint32_t)((k2 >> bit) & 1) << 1);
-    if (m) acc = jac_add_mixed(acc, tbl[m]);
+    acc = jac_dbl(jac_dbl(acc));
+    const uint32_t n = (uint32_t)(neg >> 126) & 3u, w = (uint32_t)(u >> 126) & 3u;  // bit 1: column 2c+1, bit 0: column 2c
+    neg <<= 2;
+    u <<= 2;
+    const bool sub = (n >> 1) != 0;
+    G1Affine t = tbl[w | ((((n >> 1) ^ n) & 1u) ? 0u : 4u)];
+    t.y = Fq::select(sub, -t.y, t.y);
+    acc = jac_add_mixed(acc, t);
   }
   acc.z = coord_norm(acc.z * zc);
   return acc;

@@ -6,7 +6,7 @@ cd $R; export TMPDIR=/tmp; mkdir -p gpurun_out
 for p in stats fetch write sq1 sq2; do rm -rf gpurun_out/prof_${tag}_$p; done
 timeout 900 python bench.py "$@" > gpurun_out/bench_${tag}.txt 2>gpurun_out/bench_${tag}.err
 cd /tmp
-B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 --sustain-seconds 0 --profile-run $*"   # profiled launches do not overlap: per-launch durations
+B="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --in-flight 1 --sustain-seconds 0 --profile-run $*"   # profiled launches do not overlap: per-launch durations
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_stats -- $B > $R/gpurun_out/prof_${tag}_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${tag}_fetch -- $B > $R/gpurun_out/prof_${tag}_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${tag}_write -- $B > $R/gpurun_out/prof_${tag}_write.log 2>&1
