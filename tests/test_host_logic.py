@@ -251,6 +251,23 @@ def test_bench_gpus_2_config5_on_two_ranks():
     assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[0, 2, 2], [2, 2, 2]]
 
 
+def test_bench_gpus_8_rank_logic_on_gloo():
+    """The driver's largest shape, `bench.py --gpus 8`: eight ranks (gloo, host build) -- contiguous shards of the global job range, one
+    record per rank gathered in rank order, counts summed over all eight, for config 2 and config 5."""
+    out, lines = _run_bench("--gpus", "8", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "2", "--t", "1", "--signers", "3",
+                            "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = lines[0]
+    assert len(lines) == 1 and d["n_gpus"] == 8 and d["ranks"]["devices"] == ["cpu:%d" % r for r in range(8)]
+    assert d["verified_all"] is True and d["pairing_verify_valid_count_all_ranks"] == 8 and d["config"]["batch_per_gpu"] == 2
+    out, lines = _run_bench("--gpus", "8", "--config", "5", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "1", "--t", "8",
+                            "--signers", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = lines[0]
+    assert len(lines) == 1 and d["n_gpus"] == 8 and d["valid_total_all_ranks"] == 8
+    assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[r, 1, 1] for r in range(8)]
+
+
 def test_bench_under_a_launcher_joins_the_rendezvous_even_as_the_only_rank():
     """The driver's N>1 command shape (`python -m torch.distributed.run ... bench.py --gpus N`) with N = 1: bench.py joins the
     launcher's rendezvous and takes every collective (key-set broadcast, barriers, MAX of the timed region, the count
