@@ -142,7 +142,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="contexts (one HIP stream each) of the `streaming` leg of config 2; 1 = skip that leg")
-    ap.add_argument("--sustain-seconds", type=float, default=1.2, help="length of the `sustained` leg of config 2 (0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the `sustained` leg of config 2 (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (general path, configs 3 and 4, PCIe-inclusive rate)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 captures (tools/capture_r03.sh): skip the legs that launch the headline kernels on OTHER work "
