@@ -9,7 +9,10 @@ index order into free slots.  C = 1372 chains of W = 2.03 ms of lone-wave work (
 Answer: no -- the makespan stays W / 0.667 for every segment count.  1372 runners + 676 waiters fill the 2048 slots, a runner
 sits beside another runner with probability 0.67, and with 1372 chains some chain is paired in EVERY segment; re-placement at
 random evens out the MEAN (0.78 of the lone speed), not the slowest chain.  Only a scheduler that places the laggards alone
-would (persistent workers + a least-progress-first queue): priced in DESIGN.md 5.2, not built."""
+would (persistent workers + a least-progress-first queue) -- and the second model below says what that is worth: a greedy
+least-progress-first assignment at every segment boundary (laggards onto SIMDs whose other slot is idle, the most advanced
+chains paired) ends the ladder phase at 2.75-2.8 ms instead of 3.04 (-8 %, about -5 % of the whole launch): priced in
+DESIGN.md 5.2, not built."""
 import sys
 
 
@@ -46,7 +49,50 @@ def sim(C, S, W, nsimd=1024, paired=0.667, dt=0.002):
     return t
 
 
+def sim_least_progress_first(C, S, W, nsimd=1024, paired=0.667, dt=0.002):
+    seg = W / S
+    prog = [0] * C
+    running = [False] * C
+    slots = [[None, None] for _ in range(nsimd)]
+    t, done = 0.0, 0
+    while done < C:
+        idle = sorted((c for c in range(C) if not running[c] and prog[c] < S), key=lambda c: prog[c])
+        if idle:
+            empty = [i for i in range(nsimd) if slots[i][0] is None and slots[i][1] is None]
+            half = [(i, k) for i in range(nsimd) for k in range(2) if slots[i][k] is None and slots[i][1 - k] is not None]
+            for c in idle:
+                if empty:
+                    i = empty.pop()
+                    slots[i][0] = [c, seg]
+                    half.append((i, 1))
+                    running[c] = True
+                elif half:
+                    i, k = half.pop(0)
+                    slots[i][k] = [c, seg]
+                    running[c] = True
+        for i in range(nsimd):
+            a, b = slots[i]
+            rate = paired if (a is not None and b is not None) else 1.0
+            if a is not None:
+                a[1] -= rate * dt
+            if b is not None:
+                b[1] -= rate * dt
+        t += dt
+        for i in range(nsimd):
+            for k in range(2):
+                w = slots[i][k]
+                if w is not None and w[1] <= 0:
+                    prog[w[0]] += 1
+                    running[w[0]] = False
+                    slots[i][k] = None
+                    if prog[w[0]] == S:
+                        done += 1
+    return t
+
+
 if __name__ == "__main__":
     W = float(sys.argv[1]) if len(sys.argv) > 1 else 2.03
     for S in (1, 2, 4, 8):
         print({"segments": S, "makespan_ms": round(sim(1372, S, W), 3), "one_wave_per_chain_ms": round(W / 0.667, 3)})
+    for S in (4, 8):
+        print({"policy": "least progress first", "segments": S, "makespan_ms": round(sim_least_progress_first(1372, S, W), 3)})
