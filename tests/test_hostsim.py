@@ -528,6 +528,27 @@ def test_checked_decompress(L, rnd):
     assert L.hs_decompress_g2(bytes(bad), buf(192)) == 3
 
 
+def test_g1_base4_sign_aligned_ladder_edges(L, rnd):
+    """tc_gls.h g1_mul_glv (r03: 64 steps of two doublings + one mixed addition over the 8-entry common-Z table, k even =>
+    r - k recoded and the base negated): tiny scalars (the accumulator meets table entries: guarded additions), the neighbours of
+    x^2, 2 x^2, 3 x^2 + 3 (digit boundaries of k1 + k2 x^2), 2^127 / 2^128, r - small, and random ones -- against Oracle B."""
+    import c_oracle as c
+    c.load()
+    X = o.BLS_X if o.BLS_X > 0 else -o.BLS_X
+    x2 = X * X
+    ks = [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, o.R - 1, o.R - 2, o.R - 3, o.R - 4, x2 - 2, x2 - 1, x2, x2 + 1, x2 + 2, 2 * x2, 3 * x2, 3 * x2 + 3,
+          x2 * x2 % o.R, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, 1 << 127, (1 << 127) - 1, X, X + 1, X - 1, (o.R - 1) // 2, (o.R + 1) // 2,
+          o.R - x2, o.R - x2 - 1, o.R - x2 + 1]
+    ks += [rnd.randrange(o.R) for _ in range(60)] + [rnd.randrange(1 << 64) for _ in range(10)] + [o.R - rnd.randrange(1 << 64) for _ in range(10)]
+    pb = o.g1_uncompressed(o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)))
+    for k in ks:
+        out = buf(96)
+        assert L.hs_g1_mul(o.fr_to_bytes(k), pb, out) == 0
+        assert out.raw == c.g1_mul(o.fr_to_bytes(k), pb)[1], hex(k)
+    out = buf(96)
+    assert L.hs_g1_mul(o.fr_to_bytes(5), o.g1_uncompressed(None), out) == 0 and out.raw == o.g1_uncompressed(None)
+
+
 def test_g1_glv_and_phi_subgroup_test(L, rnd):
     """G1 GLV multiplication at the decomposition boundaries, and the phi-based membership test
     (phi(P) = [-x^2]P, Scott 2021/1130) against points of EVERY prime order dividing the G1
