@@ -585,7 +585,9 @@ def run_config2(args, eng, dev, rank, world, peak):
                    "input_checks": "off: every operand is an output of the library's own kernels (known members); "
                                    "extras.combine_with_input_checks_per_s has them on",
                    "timed_region_is": "K steps queued on ONE context (one HIP stream: launches do not overlap), barrier + "
-                                      "synchronize on both sides, MAX over ranks"},
+                                      "synchronize on both sides, MAX over ranks",
+                   "comparable_with": "round 2's BENCH value (17.6 M) was the two-contexts figure: compare it with streaming.value; "
+                                      "round 2's sequential.value (13.3 M) is what `value` is now"},
         "streaming": streaming,
         "sustained": sustained,
         "general_path": general,
