@@ -138,6 +138,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--t", type=int, default=None)
     ap.add_argument("--signers", type=int, default=None)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="--config 5 on ONE GPU: run the N rank slices of an N-rank job one after the other (8 x 131 072 = the BASELINE batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2,
@@ -157,6 +159,8 @@ def parse_args(argv=None):
         ap.error("--backend gloo and --test-engine go together (there is no CPU compute path in the product)")
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.emulate_world and (args.config != 5 or args.gpus != 1):
+        ap.error("--emulate-world belongs to --config 5 on one GPU")
     return args
 
 

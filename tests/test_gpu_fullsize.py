@@ -474,14 +474,15 @@ def test_large_threshold_g1_combination_full_batch(engine):
 
 
 def test_config5_one_gpu_slice_properties(engine):
-    """BASELINE config 5 (t=67, N=200): one GPU's share of the 1 048 576-job batch (131 072 jobs; the other seven
-    run the same code on other job indices) -- sign on the device, combine, verify; size-independent properties on
+    """BASELINE config 5's flow (t=67, N=200) on a 16 384-job batch -- below the sizes where one lane pair per job fills the
+    GPU, so the comb / ladder kernels run in their SPLIT small-batch forms (the full 8 x 131 072 batch is
+    test_config5_full_batch_eight_slices_on_one_gpu) -- sign on the device, combine, verify; size-independent properties on
     EVERY job: no status errors, every signature verifies and equals the master key's own signature of the job's hash
-    point; six jobs (first, middle, last) are also recomputed by Oracle B.  TC_TEST_CONFIG5_JOBS shrinks it for local iterations."""
+    point; six jobs (first, middle, last) are also recomputed by Oracle B."""
     import os
     import torch
     from threshold_crypto_amd import config5
-    B = int(os.environ.get("TC_TEST_CONFIG5_JOBS", "131072"))
+    B = int(os.environ.get("TC_TEST_CONFIG5_SMALL_JOBS", "16384"))
     res = config5.run_pipeline(engine, 67, 200, B, 0, 1, device=torch.device("cuda", 0), steps=1,
                                sync=lambda: (engine.sync(), torch.cuda.synchronize()))
     assert res["status_errors"] == 0 and res["valid_local"] == B == res["valid_total"]
@@ -493,6 +494,45 @@ def test_config5_one_gpu_slice_properties(engine):
         shares = [c.g2_mul(bytes(km.sk_table[int(i)]), bytes(hashes[j]))[1] for i in res["idx"][j]]
         rc, want = c.combine_g2(67, [int(i) for i in res["idx"][j]], shares)
         assert rc == 0 and want == res["sig"][j].tobytes()
+
+
+def test_config5_full_batch_eight_slices_on_one_gpu(engine):
+    """BASELINE config 5 at its STATED size -- t = 67, N = 200, 1 048 576 jobs -- through HIP: the eight rank slices of the
+    8-GPU job (global jobs [131 072 r, 131 072 (r + 1)), each with the subsets and messages a real rank r derives) run one
+    after the other on this GPU (config5.run_emulated_world; combine_signatures src/lib.rs:608-615 on every job).  On EVERY
+    job of every slice: no status errors, the signature verifies and equals the master key's own signature of the job's hash
+    point; the first, middle and last job of every slice are recomputed by Oracle B.  Then the same eight slices at the
+    reduced size of the 8-rank gloo / host-build run must reproduce that run's per-rank digests
+    (tests/golden/config5_world8_reduced.json).  TC_TEST_CONFIG5_JOBS shrinks the slices for local iterations."""
+    import json
+    import os
+    import torch
+    from threshold_crypto_amd import config5
+    B = int(os.environ.get("TC_TEST_CONFIG5_JOBS", "131072"))
+    dev = torch.device("cuda", 0)
+    sync = lambda: (engine.sync(), torch.cuda.synchronize())
+    seen = []
+
+    def on_slice(res):
+        r = res["rank"]
+        assert res["status_errors"] == 0 and res["valid_local"] == B, (r, res["status_errors"], res["valid_local"])
+        msk = res["secret_key_set"].poly[0]
+        msig, st = engine.g2_mul(torch.from_numpy(u8(msk.to_bytes(32, "little"))[None].copy()).cuda(), res["hashes"])
+        assert not st.any() and bool((msig[:, 0].cpu() == torch.from_numpy(res["sig"])).all()), r
+        km = res["key_material"]
+        for j in (0, B // 2, B - 1):
+            h = bytes(res["hashes"][j].cpu().numpy())
+            shares = [c.g2_mul(bytes(km.sk_table[int(i)]), h)[1] for i in res["idx"][j]]
+            rc, want = c.combine_g2(67, [int(i) for i in res["idx"][j]], shares)
+            assert rc == 0 and want == res["sig"][j].tobytes(), (r, j)
+        seen.append((res["start"], res["jobs"]))
+
+    emu = config5.run_emulated_world(engine, 67, 200, B, 8, device=dev, sync=sync, on_slice=on_slice)
+    assert seen == [(r * B, B) for r in range(8)] and emu["valid_total"] == 8 * B and emu["status_errors"] == 0
+    assert len({rec[3] for rec in emu["records"]}) == 8            # eight different slices
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_world8_reduced.json")))
+    small = config5.run_emulated_world(engine, gold["t"], gold["N"], gold["batch_per_rank"], gold["world"], device=dev, sync=sync)
+    assert small["records"] == gold["records"]
 
 
 def test_pairing_forms_agree_on_a_planted_batch():

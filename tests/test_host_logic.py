@@ -268,6 +268,26 @@ def test_bench_gpus_8_rank_logic_on_gloo():
     assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[r, 1, 1] for r in range(8)]
 
 
+def test_config5_emulated_world_equals_the_eight_rank_run():
+    """config5.run_emulated_world (every rank slice of an 8-rank job through ONE engine, one after the other -- how one GPU runs
+    BASELINE config 5 at its stated 1 048 576 jobs) cuts the same slices and produces the same signatures as eight real ranks:
+    its per-slice records equal the committed records of the 8-rank gloo run (tests/golden/config5_world8_reduced.json,
+    tools/gen_config5_digests.py), and `bench.py --config 5 --emulate-world 8` reports them on one rank."""
+    import json
+    from threshold_crypto_amd import config5
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "config5_world8_reduced.json")))
+    emu = config5.run_emulated_world(HostSimEngine(), gold["t"], gold["N"], gold["batch_per_rank"], gold["world"])
+    assert emu["records"] == gold["records"] and emu["status_errors"] == 0 and emu["valid_total"] == gold["world"] * gold["batch_per_rank"]
+    out, lines = _run_bench("--config", "5", "--emulate-world", "8", "--backend", "gloo", "--test-engine", "hostsim", "--batch", "2", "--t", "8",
+                            "--signers", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["config"]["emulated_world"] == 8 and d["config"]["batch_per_gpu"] == 16
+    assert d["rank_records_start_jobs_valid_digest"] == gold["records"] and d["valid_total_all_ranks"] == 16
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+
+
 def test_bench_under_a_launcher_joins_the_rendezvous_even_as_the_only_rank():
     """The driver's N>1 command shape (`python -m torch.distributed.run ... bench.py --gpus N`) with N = 1: bench.py joins the
     launcher's rendezvous and takes every collective (key-set broadcast, barriers, MAX of the timed region, the count

@@ -82,18 +82,26 @@ def run_step(engine, t, sk_table, idx, hashes, master_pk):
     return sig, st0, st, ok, tuple(ms)
 
 
-def run_pipeline(engine, t, N, B, rank, world, device=None, steps=1, warmup=0, sync=None):
+def run_pipeline(engine, t, N, B, rank, world, device=None, steps=1, warmup=0, sync=None, emulated=None):
     """The whole per-rank flow (shared by bench.py --config 5 and the gloo CPU test).  Returns a dict; rank 0's
-    holds the gathered per-rank records."""
+    holds the gathered per-rank records.
+
+    emulated = (KeyMaterial, SecretKeySet): this process plays rank `rank` of a `world`-rank job BY ITSELF (run_emulated_world
+    below: every slice of the BASELINE batch through one GPU, one after the other) -- the slice is cut from the global job
+    range exactly as on a real rank, the key material is the one rank 0 made, and no collective runs."""
     import torch
     to_dev = (lambda x: x.to(device)) if device is not None else (lambda x: x)
     to_np = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
     sync = sync or (lambda: None)
     start, stop = parallel.shard_range(B * world, world, rank)       # weak scaling: B jobs per rank
     km = sks = None
-    if rank == 0:
-        km, sks = KeyMaterial.create(engine, t, N)
-    km = distribute_key_material(km, t, N, rank, world, to_dev, to_np)
+    if emulated is not None:
+        km, sks = emulated
+        world = 1                                                     # collectives below: this process alone
+    else:
+        if rank == 0:
+            km, sks = KeyMaterial.create(engine, t, N)
+        km = distribute_key_material(km, t, N, rank, world, to_dev, to_np)
     master_pk = to_dev(torch.from_numpy(km.commit[0].copy())) if device is not None else km.commit[0].copy()
     sk_table = to_dev(torch.from_numpy(km.sk_table)) if device is not None else km.sk_table
     from .engine import pack_messages
@@ -125,6 +133,30 @@ def run_pipeline(engine, t, N, B, rank, world, device=None, steps=1, warmup=0, s
             "sig": sig_np, "hashes": hashes, "idx": idx_np, "key_material": km, "secret_key_set": sks, "master_pk": master_pk}
 
 
+def run_emulated_world(engine, t, N, B, world, device=None, steps=1, warmup=0, sync=None, keep=(), on_slice=None):
+    """All `world` slices of a `world`-rank config-5 job through ONE engine, one after the other: BASELINE config 5 at its
+    stated 1 048 576 jobs (world = 8, B = 131 072) on a single GPU.  Rank r's slice is global jobs [r B, (r + 1) B), with
+    the subsets and messages a real rank r derives; the key material is created once (rank 0's) and handed on as the
+    broadcast would.  on_slice(res) sees every slice's full result (signatures, hash points, subsets) before the large
+    arrays are dropped (unless named in `keep`); returns the per-slice records and the totals."""
+    emu = KeyMaterial.create(engine, t, N)
+    slices, seconds, valid, errors = [], 0.0, 0, 0
+    for r in range(world):
+        res = run_pipeline(engine, t, N, B, r, world, device=device, steps=steps, warmup=warmup, sync=sync, emulated=emu)
+        assert (res["start"], res["jobs"]) == (r * B, B)
+        if on_slice is not None:
+            on_slice(res)
+        seconds += res["seconds"]
+        valid += res["valid_local"]
+        errors += res["status_errors"]
+        rec = res["records"][0]
+        slim = {k: v for k, v in res.items() if k in ("rank", "start", "jobs", "seconds", "phase_ms", "status_errors", "valid_local") or k in keep}
+        slim["record"] = rec
+        slices.append(slim)
+    return {"slices": slices, "seconds": seconds, "steps": steps, "jobs": B * world, "valid_total": valid, "status_errors": errors,
+            "records": [s["record"] for s in slices], "key_material": emu[0], "secret_key_set": emu[1]}
+
+
 def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
     """bench.py --config 5: 131 072 jobs per GPU by default (x 8 GPUs = the BASELINE batch).  cpu_baseline: the
     caller's oracle leg (bench.py owns every use of oracle/; this package never imports it)."""
@@ -149,23 +181,47 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
     eng.set_timing(True)
     if hasattr(eng, "set_input_checks"):
         eng.set_input_checks(False)   # the shares and hash points are made on the device by the library itself: known members
-    res = run_pipeline(eng, t, N, B, rank, world, device=dev if cuda else None, steps=args.steps, warmup=args.warmup, sync=sync)
-    assert res["status_errors"] == 0 and res["valid_local"] == B, "config 5: %d status errors, %d of %d verified" % (
-        res["status_errors"], res["valid_local"], B)
-    # size-independent property on every job of the rank: the combination equals the master key's own signature
-    km = res["key_material"]
-    if rank == 0:
+    emu_world = getattr(args, "emulate_world", 0) or 0
+
+    def check_master_signature(res):
+        # size-independent property on every job of the slice: the combination equals the master key's own signature
         master_sk = res["secret_key_set"].poly[0]
         msk = torch.from_numpy(np.frombuffer(master_sk.to_bytes(32, "little"), dtype=np.uint8)[None].copy())
         msig, _ = eng.g2_mul(msk.to(dev) if cuda else msk.numpy(), res["hashes"])
         msig = msig.cpu() if hasattr(msig, "cpu") else torch.from_numpy(np.asarray(msig))
         assert bool((msig[:, 0] == torch.from_numpy(res["sig"])).all().item()), "combine != master-key signature"
+
+    if emu_world:
+        # BASELINE config 5 at its stated batch on ONE GPU: the `emu_world` rank slices one after the other
+        assert world == 1, "--emulate-world runs every slice on one rank"
+
+        first = {}
+
+        def on_slice(r):
+            if r["rank"] == 0:      # what the cpu_baseline leg samples (bench.py)
+                first.update(idx=r["idx"][:256].copy(), hashes=r["hashes"][:256], sig=r["sig"][:256].copy())
+            assert r["status_errors"] == 0 and r["valid_local"] == B, "config 5 slice %d: %d status errors, %d of %d verified" % (
+                r["rank"], r["status_errors"], r["valid_local"], B)
+            check_master_signature(r)
+        emu = run_emulated_world(eng, t, N, B, emu_world, device=dev if cuda else None, steps=args.steps, warmup=args.warmup, sync=sync,
+                                 on_slice=on_slice)
+        res = {"phase_ms": [m for s in emu["slices"] for m in s["phase_ms"]], "seconds": emu["seconds"] / emu_world,
+               "valid_total": emu["valid_total"], "records": emu["records"], "key_material": emu["key_material"],
+               "secret_key_set": emu["secret_key_set"], **first}
+    else:
+        res = run_pipeline(eng, t, N, B, rank, world, device=dev if cuda else None, steps=args.steps, warmup=args.warmup, sync=sync)
+        assert res["status_errors"] == 0 and res["valid_local"] == B, "config 5: %d status errors, %d of %d verified" % (
+            res["status_errors"], res["valid_local"], B)
+        if rank == 0:
+            check_master_signature(res)
     if rank != 0:
         return None
     ms = np.array(res["phase_ms"], dtype=np.float64).mean(axis=0)
     if harness:
         ms = np.maximum(ms, 1e-9)   # nothing is timed per kernel in the test harness
-    step_s = res["seconds"] / args.steps
+    step_s = res["seconds"] / args.steps            # one slice's step (emulated world: the mean over the slices)
+    slices_per_step = emu_world or world            # slices one "whole job" step holds
+    whole_step_s = step_s * (emu_world or 1)        # emulated: the slices run one after the other on this GPU
     legs = {
         "combine": roofline("k_lagrange_all + k_msm_tables + k_msm_ladder", "combine_g2_t67_msm", "combine_g2_t67", "combine_g2", t, B,
                             float(ms[1]), peak),
@@ -177,12 +233,15 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
     }
     cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline and world == 1 and not harness) else None
     return {
-        "metric": "threshold signatures (sign t+1 shares + combine + verify)/sec", "value": round(B * world / step_s, 1),
+        "metric": "threshold signatures (sign t+1 shares + combine + verify)/sec", "value": round(B * slices_per_step / whole_step_s, 1),
         "unit": "threshold_signatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(whole_step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i32 limbs (Fq = 14 x 28-bit signed, Montgomery R=2^392; 64-bit column accumulators)", "data": "synthetic",
-        "config": {"workload": "t=%d,N=%d,batch=%d per GPU (x%d GPUs): shares signed on device, combined, verified" % (t, N, B, world),
-                   "t": t, "N": N, "batch_per_gpu": B, "parallelism": "jobs sharded, dp%d" % world},
+        "config": {"workload": ("t=%d,N=%d,batch=%d = %d rank slices of %d jobs run one after the other on ONE GPU: shares signed on device, "
+                                "combined, verified" % (t, N, B * emu_world, emu_world, B)) if emu_world else
+                               "t=%d,N=%d,batch=%d per GPU (x%d GPUs): shares signed on device, combined, verified" % (t, N, B, world),
+                   "t": t, "N": N, "batch_per_gpu": B * (emu_world or 1), "parallelism": "jobs sharded, dp%d" % world,
+                   "emulated_world": emu_world or None},
         "combine_signatures_per_s": round(B * world / (ms[1] * 1e-3), 1),
         "share_signs_per_s": round((t + 1) * B * world / (ms[0] * 1e-3), 1),
         "pairing_verifies_per_s": round(B * world / (ms[2] * 1e-3), 1),
