@@ -154,6 +154,15 @@ int hs_combine_g1(int t, const uint64_t* idx, const uint8_t* shares, uint8_t* ou
 int hs_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
   return job_pairing_check(a, b, c, d);
 }
+// the prepared form (tc_pairing.h): stage P writes the 68 x 5 line-product coefficients, stage M reads them back, then the
+// final exponentiation -- the three kernels of k_pairing.hip one after the other
+int hs_pairing_check_prepared(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
+  std::vector<Fq2> mem(kMillerSteps * kLineProductCoeffs);
+  const Fq2Rows rows{mem.data()};
+  DirectIO ia{a, 0, nullptr}, ib{b, 0, nullptr}, ic{c, 0, nullptr}, id{d, 0, nullptr};
+  if (!job_miller_lines_io(true, ia, ib, ic, id, rows)) return 0;
+  return job_final_exp_is_one(miller_accumulate(rows));
+}
 // GT value of FE(ML(a,b)) : 12 x 48 B big-endian in tower order c0.c0.c0, c0.c0.c1, c0.c1.c0 ...
 // the four-lanes-per-check form (tc_quad.h): the two pairs of the quad as two host threads
 int hs_pairing_check_quad(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {

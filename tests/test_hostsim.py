@@ -474,6 +474,9 @@ for t, ids in [(3, [1, 4, 6, 9]), (5, [0, 2, 3, 6, 9, 11]), (3, [2**40, 1, 2, 3]
     out = buf(96); assert L.hs_combine_g1(t, (ctypes.c_uint64 * (t + 1))(*ids), b"".join(o.g1_uncompressed(s) for s in sh1), out) == 0
 a = rnd.randrange(o.R)
 assert L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(Q2), o.g1_uncompressed(o.G1_GEN), o.g2_uncompressed(o.E2.mul(Q2, a))) == 1
+assert L.hs_pairing_check_prepared(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(Q2), o.g1_uncompressed(o.G1_GEN), o.g2_uncompressed(o.E2.mul(Q2, a))) == 1
+assert L.hs_pairing_check_prepared(o.g1_uncompressed(None), o.g2_uncompressed(Q2), o.g1_uncompressed(o.G1_GEN), o.g2_uncompressed(o.E2.mul(Q2, a))) == 0
+assert L.hs_pairing_check_prepared(o.g1_uncompressed(None), o.g2_uncompressed(Q2), o.g1_uncompressed(o.G1_GEN), o.g2_uncompressed(None)) == 1
 for m in (b"", b"bound check", bytes(200)):
     out = buf(192); L.hs_hash_g2(m, len(m), out); assert out.raw == o.g2_uncompressed(o.hash_g2(m))
 out = buf(192); assert L.hs_hash_g1_g2(o.g1_uncompressed(P), b"x" * 70, 70, out) == 0
@@ -873,3 +876,5 @@ def test_quad_pairing_check_matches_oracle(L, rnd):
     cases += [((bytes(bad), g2(Q), g1(P), g2(Q)), 0), ((g1(P), g2(Q), g1(P), b"\xff" * 192), 0)]
     for ops, want in cases:
         assert L.hs_pairing_check_quad(*ops) == want == L.hs_pairing_check(*ops)
+        # ... and the prepared form (stage P -> line products in memory -> stage M -> final exponentiation)
+        assert L.hs_pairing_check_prepared(*ops) == want

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_check(const uin
 // allocation; the Miller value travels through HBM in the lane-pair row layout: word w of lane l of wave v at
 // fbuf[(v * kFq12Words + w) * 64 + l] -- every store / load instruction moves one full 256-byte row.
 constexpr int kFq12Words = 6 * FQ_LIMBS;  // per lane: one coefficient of each of the six Fq2
+constexpr size_t kQuadMaxBatchDecl = 16384;  // (= kQuadMaxBatch below)
 #if TC_PAIR
 __device__ __forceinline__ void fq12_store_rows(int32_t* __restrict__ rows, const Fq12& f) {
   const Fq2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -81,6 +82,45 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_final_exp(const int32_t
   if (j < B && pair_leader() && ok[j]) ok[j] = r;
 }
 
+// ---- the Miller loop as two kernels: prepared line products in HBM (tc_pairing.h) ---------------------------------------
+// k_miller_lines (stage P: the two Miller points, their lines, the product of the two lines of a step) writes 68 x 5 Fq2
+// coefficients per check into the wave's row block -- word w of lane l of wave v at lines[(v * kLineWords + w) * 64 + l],
+// 256-byte rows, 39 KB per check --, k_miller_accumulate (stage M: the Fq12 accumulator) streams them back and leaves the
+// Miller value for k_final_exp.
+constexpr int kLineWords = kMillerSteps * kLineProductCoeffs * FQ_LIMBS;  // per lane
+#ifndef TC_WAVES_MILLER_P
+#define TC_WAVES_MILLER_P TC_WAVES_G2
+#endif
+#ifndef TC_WAVES_MILLER_M
+#define TC_WAVES_MILLER_M TC_WAVES_G2
+#endif
+#if TC_PAIR
+__global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_P) void k_miller_lines(const uint8_t* __restrict__ a, size_t sa,
+                                                         const uint8_t* __restrict__ b, size_t sb,
+                                                         const uint8_t* __restrict__ c, size_t sc,
+                                                         const uint8_t* __restrict__ d, size_t sd, size_t B,
+                                                         int32_t* __restrict__ lines, uint8_t* __restrict__ ok) {
+  using IO1 = WaveRowIO<96, kG2Lanes>;
+  using IO2 = WaveRowIO<192, kG2Lanes>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[IO2::BYTES];
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const bool live = j < B;
+  const size_t jj = live ? j : 0;
+  IO1 ia{lds, live ? a + jj * sa : nullptr, 0, nullptr}, ic{lds, live ? c + jj * sc : nullptr, 0, nullptr};
+  IO2 ib{lds, live ? b + jj * sb : nullptr, 0, nullptr}, id{lds, live ? d + jj * sd : nullptr, 0, nullptr};
+  const bool good = job_miller_lines_io(live, ia, ib, ic, id, Fq2Rows{lines + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x});
+  if (live && pair_leader()) ok[j] = good ? 1 : 0;  // 0: an operand did not decode; the later kernels keep it
+}
+
+__global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_M) void k_miller_accumulate(const int32_t* __restrict__ lines, int32_t* __restrict__ fbuf) {
+  const Fq12 f = miller_accumulate(Fq2Rows{const_cast<int32_t*>(lines) + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x});
+  fq12_store_rows(fbuf + (size_t)blockIdx.x * kFq12Words * 64 + threadIdx.x, f);
+}
+#else
+__global__ void k_miller_lines(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, size_t, size_t, int32_t*, uint8_t*) {}
+__global__ void k_miller_accumulate(const int32_t*, int32_t*) {}
+#endif
+
 // ---- four lanes per check (tc_quad.h) -----------------------------------------------------------------------------------
 // Pair A of a quad stages and decodes (a, b), pair B (c, d): two passes through the LDS row buffer with a PAIR as the
 // staging unit (32 rows per wave), each pair parses one G1 and one G2 record.
@@ -102,20 +142,26 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_quad(const uint
   if (live && (threadIdx.x & (kQuadLanes - 1)) == 0) ok[j] = r;
 }
 
-size_t pairing_ws_words(size_t B) { return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64; }
+// checks per pass of the prepared form: its line buffer (39 KB per check) is sized for one tile, larger batches run tile by tile
+constexpr size_t kPreparedTile = 65536;
+size_t pairing_ws_words(size_t B) {
+  const size_t tile = B < kPreparedTile ? B : kPreparedTile;
+  return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64 + (B > kQuadMaxBatchDecl ? (size_t)grid_for(tile * kG2Lanes) * kLineWords * 64 : 0);
+}
 
 // Which form runs (measured on MI355X, profiles/r03_pairing_forms.txt): four lanes per check up to kQuadMaxBatch checks
 // -- the batch alone cannot give every SIMD two waves of the lane-pair kernels, and a check finishes in about 0.6 of the
 // time (6.9 instead of 10.9 ms at 4 096 checks, 8.5 instead of 11.4 ms at 16 384); two lanes per check above it, where the
 // quad form's exchanges and duplicated linear work cost more than its lower register pressure gains (27.0 against 22.4 ms
 // at 65 536).  TC_PAIRING_FORM = quad | pair | fused overrides the choice for experiments.
-constexpr size_t kQuadMaxBatch = 16384;
+constexpr size_t kQuadMaxBatch = kQuadMaxBatchDecl;
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws) {
   if (!B) return;
   static const char* form = getenv("TC_PAIRING_FORM");
   const bool fused = form && form[0] == 'f';
   const bool quad = form ? form[0] == 'q' : B <= kQuadMaxBatch;
+  const bool one_loop = form && form[0] == 'p';  // r03's two-kernel form: Miller loop with its point arithmetic, final exponentiation
   if (quad) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(grid_for(B * kQuadLanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
@@ -124,7 +170,21 @@ void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uin
     hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
   }
-  hipLaunchKernelGGL(k_miller_loop, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
+  if (one_loop || B <= kQuadMaxBatch) {
+    hipLaunchKernelGGL(k_miller_loop, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
+    hipLaunchKernelGGL(k_final_exp, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, (const int32_t*)ws, B, ok);
+    return;
+  }
+  // prepared form: lines (stage P) -> accumulator (stage M) tile by tile through one line buffer, then ONE final exponentiation launch
+  int32_t* lines = ws + (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64;
+  for (size_t lo = 0; lo < B; lo += kPreparedTile) {
+    const size_t cnt = (B - lo < kPreparedTile) ? B - lo : kPreparedTile;
+    const unsigned grid = grid_for(cnt * kG2Lanes);
+    int32_t* fb = ws + (size_t)grid_for(lo * kG2Lanes) * kFq12Words * 64;
+    hipLaunchKernelGGL(k_miller_lines, dim3(grid), dim3(kBlock), 0, st, a + lo * sa, sa, b + lo * sb, sb, c + lo * sc, sc, d + lo * sd, sd, cnt,
+                       lines, ok + lo);
+    hipLaunchKernelGGL(k_miller_accumulate, dim3(grid), dim3(kBlock), 0, st, (const int32_t*)lines, fb);
+  }
   hipLaunchKernelGGL(k_final_exp, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, (const int32_t*)ws, B, ok);
 }
 

@@ -411,6 +411,31 @@ TC_HD bool job_miller_io(bool live, IOA& a, IOB& b, IOC& c, IOD& d, Fq12& f) {
   f = miller_loop<2>(ps, qs);
   return ok;
 }
+// The Miller loop itself in two stages that meet in memory (tc_pairing.h: prepared line products): stage P ...
+template <class IOA, class IOB, class IOC, class IOD>
+TC_HD bool job_miller_lines_io(bool live, IOA& a, IOB& b, IOC& c, IOD& d, const Fq2Rows& rows) {
+  G1Affine pa = G1Affine::infinity(), pc = G1Affine::infinity();
+  G2Affine qb = G2Affine::infinity(), qd = G2Affine::infinity();
+  bool ok = live;
+  const uint8_t* e = a.operand(0);
+  if (live) ok &= g1_decode_uncompressed(e, pa);
+  e = b.operand(0);
+  if (live) ok &= g2_decode_uncompressed(e, qb);
+  e = c.operand(0);
+  if (live) ok &= g1_decode_uncompressed(e, pc);
+  e = d.operand(0);
+  if (live) ok &= g2_decode_uncompressed(e, qd);
+  if (!ok) {  // the value of an empty product; the caller reports the job as failed
+    pa = pc = G1Affine::infinity();
+    qb = qd = G2Affine::infinity();
+  }
+  const G1Affine ps[2] = {pa, G1Affine{pc.x, (-pc.y), pc.inf}};
+  const G2Affine qs[2] = {qb, qd};
+  const bool skip[2] = {ps[0].inf || qs[0].inf, ps[1].inf || qs[1].inf};
+  miller_prepare_lines(MillerArrayOps{ps, qs}, skip, rows);
+  return ok;
+}
+// ... stage M: miller_accumulate(rows) ...
 // ... and the final exponentiation with the comparison
 TC_HD uint8_t job_final_exp_is_one(const Fq12& f) { return final_exponentiation(f) == Fq12::one() ? 1 : 0; }
 

@@ -150,6 +150,104 @@ TC_HD Fq12 miller_loop(const G1Affine* ps, const G2Affine* qs) {
   return miller_loop_ops<NP>(MillerArrayOps{ps, qs}, skip);
 }
 
+// =====================================================================================================================
+// The same product Miller loop as TWO stages that meet in memory (k_pairing.hip: k_miller_lines, k_miller_accumulate) --
+// the split pairing 0.16 makes between G2Prepared and miller_loop (what /root/reference/src/lib.rs:109, :185, :511 reach
+// through PEngine::pairing), carried one step further:
+//   stage P  G2 point arithmetic only: the 68 steps (63 doublings, 5 additions) of BOTH Miller points.  Per step the two
+//            lines are evaluated at their G1 points and multiplied WITH EACH OTHER (6 Fq2 products); the five non-trivial
+//            Fq2 coefficients of that product are what goes to memory: lines prepared for THIS check.
+//   stage M  the Fq12 accumulator only:  f <- f * (line product)  per step,  f <- f^2  per loop iteration.  Neither the
+//            Miller points nor any operand of the check is live there.
+// As ONE loop the live set was accumulator (84 registers per lane) + two Miller points (84) + four operands (112) before
+// a single temporary: 2 238 spilled registers, 25.7 GB of scratch traffic per 65 536 checks.
+constexpr int kMillerSteps = 68;         // 63 doublings + 5 additions (|x| >> 1 has five set bits below its leading one)
+constexpr int kLineProductCoeffs = 5;    // c0 = (a0, a1, a2), c1 = (0, b1, b2)
+
+// Where the prepared coefficients live.  Device (lane-pair build): this lane's column of the wave's row block -- word w
+// of lane l at p[w * 64 + l], so every store / load instruction moves one full 256-byte row.  Host build (test harness): a
+// plain array.
+#if TC_PAIR
+struct Fq2Rows {
+  int32_t* p;
+  TC_HD void put(int k, const Fq2& v) const {
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) p[(k * FQ_LIMBS + i) * 64] = v.m.l[i];
+  }
+  TC_HD Fq2 get(int k) const {
+    Fq2 r;
+    TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = p[(k * FQ_LIMBS + i) * 64];
+    return r;
+  }
+};
+#else
+struct Fq2Rows {
+  Fq2* p;
+  TC_HD void put(int k, const Fq2& v) const { p[k] = v; }
+  TC_HD Fq2 get(int k) const { return p[k]; }
+};
+#endif
+
+// one step of stage P: both points advance, their lines meet in one product.  A skipped pair (an operand at infinity)
+// contributes the unit line; its point arithmetic runs on a harmless stand-in.
+template <bool ADD, class OPS>
+TC_HD void miller_lines_step(G2Jac* r, const OPS& ops, const bool* skip, const Fq2Rows& rows, int s) {
+  LineCoeffs l[2];
+  TC_UNROLL for (int k = 0; k < 2; k++) {
+    l[k] = ADD ? miller_addition_step(r[k], ops.q(k)) : miller_doubling_step(r[k]);
+    l[k].c2 = Fq2::select(skip[k], Fq2::one(), l[k].c2);
+    l[k].c1 = Fq2::select(skip[k], Fq2::zero(), l[k].c1);
+    l[k].c0 = Fq2::select(skip[k], Fq2::zero(), l[k].c0);
+  }
+  const Fq12 lp = Fq12::line_product(l[0].c2, l[0].c1.scale(ops.px(0)), l[0].c0.scale(ops.py(0)), l[1].c2,
+                                     l[1].c1.scale(ops.px(1)), l[1].c0.scale(ops.py(1)));
+  const int k = s * kLineProductCoeffs;
+  rows.put(k + 0, lp.c0.c0);
+  rows.put(k + 1, lp.c0.c1.norm());
+  rows.put(k + 2, lp.c0.c2.norm());
+  rows.put(k + 3, lp.c1.c1.norm());
+  rows.put(k + 4, lp.c1.c2);
+}
+
+template <class OPS>
+TC_HD void miller_prepare_lines(const OPS& ops, const bool* skip, const Fq2Rows& rows) {
+  G2Jac r[2];
+  TC_UNROLL for (int k = 0; k < 2; k++) {
+    const G2Affine q = ops.q(k);
+    r[k] = G2Jac{q.x, q.y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
+  }
+  const uint64_t xs = BLS_X_ABS >> 1;
+  int s = 0;
+  TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
+    tc_fair();
+    miller_lines_step<false>(r, ops, skip, rows, s++);
+    if ((xs >> i) & 1ull) miller_lines_step<true>(r, ops, skip, rows, s++);
+  }
+  miller_lines_step<false>(r, ops, skip, rows, s++);
+}
+
+TC_HD Fq12 miller_line_product_at(const Fq2Rows& rows, int s) {
+  const int k = s * kLineProductCoeffs;
+  Fq12 l;
+  l.c0 = Fq6{rows.get(k + 0), rows.get(k + 1), rows.get(k + 2)};
+  l.c1 = Fq6{Fq2::zero(), rows.get(k + 3), rows.get(k + 4)};
+  return l;
+}
+
+// stage M: the accumulator over the prepared line products (the loop of miller_loop_ops without its point arithmetic)
+TC_HD Fq12 miller_accumulate(const Fq2Rows& rows) {
+  const uint64_t xs = BLS_X_ABS >> 1;
+  int s = 0;
+  Fq12 f = miller_line_product_at(rows, s++);  // f = 1 times the first product
+  TC_NOUNROLL for (int i = 61; i >= 0; i--) {
+    tc_fair();
+    if (i != 61) f = f.mul_by_line_product(miller_line_product_at(rows, s++));
+    if ((xs >> i) & 1ull) f = f.mul_by_line_product(miller_line_product_at(rows, s++));
+    f = f.sqr();
+  }
+  f = f.mul_by_line_product(miller_line_product_at(rows, s++));
+  return f.conj();  // x < 0
+}
+
 // Three compressed cyclotomic elements back to Fq12 with ONE shared inversion (Montgomery's trick).
 //   z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2),   or  2 z4 z5 / z3  when z2 = 0;
 //   z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1.
