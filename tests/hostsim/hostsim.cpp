@@ -157,7 +157,7 @@ int hs_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_t* c, const
 // the prepared form (tc_pairing.h): stage P writes the 68 x 5 line-product coefficients, stage M reads them back, then the
 // final exponentiation -- the three kernels of k_pairing.hip one after the other
 int hs_pairing_check_prepared(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
-  std::vector<Fq2> mem(kMillerSteps * kLineProductCoeffs);
+  std::vector<Fq2> mem(kMillerRowSlots);
   const Fq2Rows rows{mem.data()};
   DirectIO ia{a, 0, nullptr}, ib{b, 0, nullptr}, ic{c, 0, nullptr}, id{d, 0, nullptr};
   if (!job_miller_lines_io(true, ia, ib, ic, id, rows)) return 0;

@@ -536,7 +536,8 @@ def test_config5_full_batch_eight_slices_on_one_gpu(engine):
 
 
 def test_pairing_forms_agree_on_a_planted_batch():
-    """The three forms of the pairing check (k_pairing.hip: four lanes per check, two lanes per check as two kernels, the
+    """The four forms of the pairing check (k_pairing.hip: four lanes per check; two lanes per check in the prepared form --
+    line products in HBM between k_miller_lines and k_miller_accumulate --; r03's Miller loop + final exponentiation; the
     fused two-lane kernel) are picked by batch size; forced one after the other (TC_PAIRING_FORM, one process each) they
     must return the SAME booleans on 20 000 checks with every 7th signature replaced by its neighbour's, an operand at
     infinity and an undecodable one."""
@@ -564,7 +565,7 @@ assert (ok == want).all(), np.flatnonzero(ok != want)[:10]
 print("FORM-OK", hashlib.sha256(ok.tobytes()).hexdigest())
 """ % root
     digests = set()
-    for form in ("quad", "pair", "fused"):
+    for form in ("quad", "lines", "pair", "fused"):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, TC_PAIRING_FORM=form))
         assert out.returncode == 0 and "FORM-OK" in out.stdout, (form, out.stderr[-1500:])
         digests.add(out.stdout.split("FORM-OK")[1].strip())

@@ -34,7 +34,6 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_check(const uin
 // allocation; the Miller value travels through HBM in the lane-pair row layout: word w of lane l of wave v at
 // fbuf[(v * kFq12Words + w) * 64 + l] -- every store / load instruction moves one full 256-byte row.
 constexpr int kFq12Words = 6 * FQ_LIMBS;  // per lane: one coefficient of each of the six Fq2
-constexpr size_t kQuadMaxBatchDecl = 16384;  // (= kQuadMaxBatch below)
 #if TC_PAIR
 __device__ __forceinline__ void fq12_store_rows(int32_t* __restrict__ rows, const Fq12& f) {
   const Fq2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_final_exp(const int32_t
 // coefficients per check into the wave's row block -- word w of lane l of wave v at lines[(v * kLineWords + w) * 64 + l],
 // 256-byte rows, 39 KB per check --, k_miller_accumulate (stage M: the Fq12 accumulator) streams them back and leaves the
 // Miller value for k_final_exp.
-constexpr int kLineWords = kMillerSteps * kLineProductCoeffs * FQ_LIMBS;  // per lane
+constexpr int kLineWords = kMillerRowSlots * FQ_LIMBS;  // per lane: operands, one parked line, 68 x 5 product coefficients
 #ifndef TC_WAVES_MILLER_P
 #define TC_WAVES_MILLER_P TC_WAVES_G2
 #endif
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_P) void k_miller_lines(cons
                                                          const uint8_t* __restrict__ b, size_t sb,
                                                          const uint8_t* __restrict__ c, size_t sc,
                                                          const uint8_t* __restrict__ d, size_t sd, size_t B,
-                                                         int32_t* __restrict__ lines, uint8_t* __restrict__ ok) {
+                                                         int32_t* lines, uint8_t* __restrict__ ok) {  // (lines: read back through laundered pointers, tc_pairing.h rows_after: no restrict)
   using IO1 = WaveRowIO<96, kG2Lanes>;
   using IO2 = WaveRowIO<192, kG2Lanes>;
   __shared__ __attribute__((aligned(16))) uint8_t lds[IO2::BYTES];
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_P) void k_miller_lines(cons
   if (live && pair_leader()) ok[j] = good ? 1 : 0;  // 0: an operand did not decode; the later kernels keep it
 }
 
-__global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_M) void k_miller_accumulate(const int32_t* __restrict__ lines, int32_t* __restrict__ fbuf) {
+__global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_M) void k_miller_accumulate(const int32_t* lines, int32_t* __restrict__ fbuf) {
   const Fq12 f = miller_accumulate(Fq2Rows{const_cast<int32_t*>(lines) + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x});
   fq12_store_rows(fbuf + (size_t)blockIdx.x * kFq12Words * 64 + threadIdx.x, f);
 }
@@ -142,35 +141,43 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_quad(const uint
   if (live && (threadIdx.x & (kQuadLanes - 1)) == 0) ok[j] = r;
 }
 
-// checks per pass of the prepared form: its line buffer (39 KB per check) is sized for one tile, larger batches run tile by tile
+// Which form runs (TC_PAIRING_FORM = quad | lines | pair | fused overrides the choice for experiments):
+//   four lanes per check (k_pairing_quad) up to kQuadMaxBatch checks -- the batch alone cannot give every SIMD two waves of
+//     the lane-pair kernels, and a check finishes in about 0.6 of the time (6.9 instead of 10.9 ms at 4 096 checks, 8.5
+//     instead of 11.4 ms at 16 384: profiles/r03_pairing_forms.txt);
+//   above it the PREPARED form: k_miller_lines -> k_miller_accumulate -> k_final_exp (r04; 206 / 142 / 4 spilled registers,
+//     12.99 ms for the two Miller kernels against 13.1-13.2 ms for the one loop with its 2 238: profiles/r04_pairing_*);
+//   `pair` = r03's k_miller_loop + k_final_exp, `fused` = r02's single kernel.
+constexpr size_t kQuadMaxBatch = 16384;
+enum PairingForm { kFormQuad, kFormLines, kFormPair, kFormFused };
+static PairingForm pairing_form(size_t B) {
+  static const char* form = getenv("TC_PAIRING_FORM");
+  if (form && form[0] == 'q') return kFormQuad;
+  if (form && form[0] == 'l') return kFormLines;
+  if (form && form[0] == 'p') return kFormPair;
+  if (form && form[0] == 'f') return kFormFused;
+  return B <= kQuadMaxBatch ? kFormQuad : kFormLines;
+}
+// checks per pass of the prepared form: its line buffer (40 KB per check) is sized for one tile, larger batches run tile by tile
 constexpr size_t kPreparedTile = 65536;
 size_t pairing_ws_words(size_t B) {
   const size_t tile = B < kPreparedTile ? B : kPreparedTile;
-  return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64 + (B > kQuadMaxBatchDecl ? (size_t)grid_for(tile * kG2Lanes) * kLineWords * 64 : 0);
+  return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64 + (pairing_form(B) == kFormLines ? (size_t)grid_for(tile * kG2Lanes) * kLineWords * 64 : 0);
 }
 
-// Which form runs (measured on MI355X, profiles/r03_pairing_forms.txt): four lanes per check up to kQuadMaxBatch checks
-// -- the batch alone cannot give every SIMD two waves of the lane-pair kernels, and a check finishes in about 0.6 of the
-// time (6.9 instead of 10.9 ms at 4 096 checks, 8.5 instead of 11.4 ms at 16 384); two lanes per check above it, where the
-// quad form's exchanges and duplicated linear work cost more than its lower register pressure gains (27.0 against 22.4 ms
-// at 65 536).  TC_PAIRING_FORM = quad | pair | fused overrides the choice for experiments.
-constexpr size_t kQuadMaxBatch = kQuadMaxBatchDecl;
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws) {
   if (!B) return;
-  static const char* form = getenv("TC_PAIRING_FORM");
-  const bool fused = form && form[0] == 'f';
-  const bool quad = form ? form[0] == 'q' : B <= kQuadMaxBatch;
-  const bool one_loop = form && form[0] == 'p';  // r03's two-kernel form: Miller loop with its point arithmetic, final exponentiation
-  if (quad) {
+  const PairingForm form = pairing_form(B);
+  if (form == kFormQuad) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(grid_for(B * kQuadLanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
   }
-  if (fused || !ws) {
+  if (form == kFormFused || !ws) {
     hipLaunchKernelGGL(k_pairing_check, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
   }
-  if (one_loop || B <= kQuadMaxBatch) {
+  if (form == kFormPair) {
     hipLaunchKernelGGL(k_miller_loop, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ws, ok);
     hipLaunchKernelGGL(k_final_exp, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, (const int32_t*)ws, B, ok);
     return;

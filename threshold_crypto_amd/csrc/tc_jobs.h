@@ -432,7 +432,7 @@ TC_HD bool job_miller_lines_io(bool live, IOA& a, IOB& b, IOC& c, IOD& d, const 
   const G1Affine ps[2] = {pa, G1Affine{pc.x, (-pc.y), pc.inf}};
   const G2Affine qs[2] = {qb, qd};
   const bool skip[2] = {ps[0].inf || qs[0].inf, ps[1].inf || qs[1].inf};
-  miller_prepare_lines(MillerArrayOps{ps, qs}, skip, rows);
+  miller_prepare_lines(ps, qs, skip, rows);
   return ok;
 }
 // ... stage M: miller_accumulate(rows) ...

@@ -178,59 +178,138 @@ struct Fq2Rows {
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = p[(k * FQ_LIMBS + i) * 64];
     return r;
   }
+  // an Fq value both lanes of the pair hold (G1 coordinates): each lane keeps its own copy in its own column
+  TC_HD void put_fq(int k, const Fq& v) const { put(k, Fq2{v}); }
+  TC_HD Fq get_fq(int k) const { return get(k).m; }
 };
 #else
 struct Fq2Rows {
   Fq2* p;
   TC_HD void put(int k, const Fq2& v) const { p[k] = v; }
   TC_HD Fq2 get(int k) const { return p[k]; }
+  TC_HD void put_fq(int k, const Fq& v) const { p[k] = Fq2{v, Fq::zero()}; }
+  TC_HD Fq get_fq(int k) const { return p[k].c0; }
 };
 #endif
 
+// Row slots of a lane's block: the operands of the check (G1 coordinates, the affine G2 points: read where a step uses
+// them instead of being held in 112 registers for the whole loop), the first pair's line of the current step (parked while
+// the second pair's point advances), then the 68 x 5 line-product coefficients stage M reads.
+constexpr int kRowPx = 0, kRowPy = 2, kRowQx = 4, kRowQy = 6, kRowLine = 8, kRowProducts = 11;
+constexpr int kMillerRowSlots = kRowProducts + kMillerSteps * kLineProductCoeffs;
+
+TC_HD Fq2Rows rows_after(const Fq2Rows& rows, const Fq2& v);
+
 // one step of stage P: both points advance, their lines meet in one product.  A skipped pair (an operand at infinity)
 // contributes the unit line; its point arithmetic runs on a harmless stand-in.
-template <bool ADD, class OPS>
-TC_HD void miller_lines_step(G2Jac* r, const OPS& ops, const bool* skip, const Fq2Rows& rows, int s) {
-  LineCoeffs l[2];
+template <bool ADD>
+TC_HD void miller_lines_step(G2Jac* r, const bool* skip, const Fq2Rows& rows, int s) {
+  Fq2 e0, e1, e4;
   TC_UNROLL for (int k = 0; k < 2; k++) {
-    l[k] = ADD ? miller_addition_step(r[k], ops.q(k)) : miller_doubling_step(r[k]);
-    l[k].c2 = Fq2::select(skip[k], Fq2::one(), l[k].c2);
-    l[k].c1 = Fq2::select(skip[k], Fq2::zero(), l[k].c1);
-    l[k].c0 = Fq2::select(skip[k], Fq2::zero(), l[k].c0);
+    LineCoeffs l;
+    if (ADD) {
+      const Fq2Rows rq = rows_after(rows, r[k].z);
+      l = miller_addition_step(r[k], G2Affine{rq.get(kRowQx + k), rq.get(kRowQy + k), false});
+    } else {
+      l = miller_doubling_step(r[k]);
+    }
+    const Fq2Rows rp = rows_after(rows, l.c2);
+    e0 = Fq2::select(skip[k], Fq2::one(), l.c2);
+    e1 = Fq2::select(skip[k], Fq2::zero(), l.c1.scale(rp.get_fq(kRowPx + k)));
+    e4 = Fq2::select(skip[k], Fq2::zero(), l.c0.scale(rp.get_fq(kRowPy + k)));
+    if (k == 0) {
+      rows.put(kRowLine + 0, e0);
+      rows.put(kRowLine + 1, e1);
+      rows.put(kRowLine + 2, e4);
+    }
   }
-  const Fq12 lp = Fq12::line_product(l[0].c2, l[0].c1.scale(ops.px(0)), l[0].c0.scale(ops.py(0)), l[1].c2,
-                                     l[1].c1.scale(ops.px(1)), l[1].c0.scale(ops.py(1)));
-  const int k = s * kLineProductCoeffs;
-  rows.put(k + 0, lp.c0.c0);
-  rows.put(k + 1, lp.c0.c1.norm());
-  rows.put(k + 2, lp.c0.c2.norm());
-  rows.put(k + 3, lp.c1.c1.norm());
-  rows.put(k + 4, lp.c1.c2);
+  // (d0 + d1 v + d4 v w) (e0 + e1 v + e4 v w), Fq12::line_product with the first line read back where it is used
+  const int k = kRowProducts + s * kLineProductCoeffs;
+  const Fq2Rows ra = rows_after(rows, e4);
+  const Fq2 d0 = ra.get(kRowLine + 0);
+  const Fq2 t0 = d0 * e0;
+  const Fq2 d4 = ra.get(kRowLine + 2);
+  const Fq2 t3 = d4 * e4;
+  rows.put(k + 0, (t0 + t3.mul_xi()).norm());
+  const Fq2 u = (d0 + d4) * (e0 + e4) - t0 - t3;
+  rows.put(k + 3, u.norm());
+  const Fq2Rows rb = rows_after(rows, u);
+  const Fq2 d1 = rb.get(kRowLine + 1);
+  const Fq2 t1 = d1 * e1;
+  rows.put(k + 2, t1);
+  const Fq2 w = (d1 + rb.get(kRowLine + 2)) * (e1 + e4) - t1 - t3;
+  rows.put(k + 4, w.norm());
+  const Fq2Rows rc = rows_after(rows, w);
+  const Fq2 t2 = (rc.get(kRowLine + 0) + d1) * (e0 + e1) - t0 - t1;
+  rows.put(k + 1, t2.norm());
 }
 
-template <class OPS>
-TC_HD void miller_prepare_lines(const OPS& ops, const bool* skip, const Fq2Rows& rows) {
+// qs: the two affine G2 points, ps: the two G1 points (the second already negated)
+TC_HD void miller_prepare_lines(const G1Affine* ps, const G2Affine* qs, const bool* skip, const Fq2Rows& rows) {
   G2Jac r[2];
   TC_UNROLL for (int k = 0; k < 2; k++) {
-    const G2Affine q = ops.q(k);
-    r[k] = G2Jac{q.x, q.y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
+    rows.put_fq(kRowPx + k, ps[k].x);
+    rows.put_fq(kRowPy + k, ps[k].y);
+    rows.put(kRowQx + k, qs[k].x);
+    rows.put(kRowQy + k, qs[k].y);
+    r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
   }
   const uint64_t xs = BLS_X_ABS >> 1;
   int s = 0;
   TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
     tc_fair();
-    miller_lines_step<false>(r, ops, skip, rows, s++);
-    if ((xs >> i) & 1ull) miller_lines_step<true>(r, ops, skip, rows, s++);
+    miller_lines_step<false>(r, skip, rows, s++);
+    if ((xs >> i) & 1ull) miller_lines_step<true>(r, skip, rows, s++);
   }
-  miller_lines_step<false>(r, ops, skip, rows, s++);
+  miller_lines_step<false>(r, skip, rows, s++);
 }
 
 TC_HD Fq12 miller_line_product_at(const Fq2Rows& rows, int s) {
-  const int k = s * kLineProductCoeffs;
+  const int k = kRowProducts + s * kLineProductCoeffs;
   Fq12 l;
   l.c0 = Fq6{rows.get(k + 0), rows.get(k + 1), rows.get(k + 2)};
   l.c1 = Fq6{Fq2::zero(), rows.get(k + 3), rows.get(k + 4)};
   return l;
+}
+
+// The loads of stage M are pinned BEHIND the value they are first needed after (an empty asm that makes the row pointer
+// "depend" on that value): left alone, the scheduler hoists all 70 loads of a step to the top of the iteration, finds no
+// registers for them beside the accumulator, and copies them from HBM straight into scratch.
+TC_HD Fq2Rows rows_after(const Fq2Rows& rows, const Fq2& v) {  // (declared above)
+#if TC_PAIR && defined(__HIP_DEVICE_COMPILE__)
+  int32_t* p = rows.p;
+  asm volatile("" : "+v"(p) : "v"(v.m.l[0]));
+  return Fq2Rows{p};
+#else
+  (void)v;
+  return rows;
+#endif
+}
+
+// f <- f * (line product of step s), the coefficients streamed from their rows where the Karatsuba product over Fq6 uses
+// them: (a0, a1, a2) for t0 = f.c0 * l.c0, (b1, b2) for t1 = f.c1 * l.c1, and all five once more for the middle product
+// -- 70 more words per step out of L2 instead of 70 registers held across eleven multiplications.
+TC_FQ12_ATTR Fq12 miller_mul_by_line_product_rows(const Fq12& f, const Fq2Rows& rows, int s) {
+  const int k = kRowProducts + s * kLineProductCoeffs;
+  Fq6 t0;
+  {
+    const Fq6 a{rows.get(k + 0), rows.get(k + 1), rows.get(k + 2)};
+    t0 = f.c0 * a;
+  }
+  Fq6 t1;
+  {
+    const Fq2Rows r1 = rows_after(rows, t0.c2);
+    const Fq2 b1 = r1.get(k + 3), b2 = r1.get(k + 4);
+    t1 = f.c1.mul_by_12(b1, b2);
+  }
+  Fq12 r;
+  {
+    const Fq2Rows r2 = rows_after(rows, t1.c2);
+    const Fq6 m{r2.get(k + 0), (r2.get(k + 1) + r2.get(k + 3)).norm(), (r2.get(k + 2) + r2.get(k + 4)).norm()};
+    r.c1 = (f.c0 + f.c1).norm() * m - t0 - t1;
+  }
+  r.c0 = t0 + t1.mul_by_v();
+  return r.norm();
 }
 
 // stage M: the accumulator over the prepared line products (the loop of miller_loop_ops without its point arithmetic)
@@ -240,11 +319,11 @@ TC_HD Fq12 miller_accumulate(const Fq2Rows& rows) {
   Fq12 f = miller_line_product_at(rows, s++);  // f = 1 times the first product
   TC_NOUNROLL for (int i = 61; i >= 0; i--) {
     tc_fair();
-    if (i != 61) f = f.mul_by_line_product(miller_line_product_at(rows, s++));
-    if ((xs >> i) & 1ull) f = f.mul_by_line_product(miller_line_product_at(rows, s++));
+    if (i != 61) f = miller_mul_by_line_product_rows(f, rows_after(rows, f.c0.c0), s++);
+    if ((xs >> i) & 1ull) f = miller_mul_by_line_product_rows(f, rows_after(rows, f.c0.c0), s++);
     f = f.sqr();
   }
-  f = f.mul_by_line_product(miller_line_product_at(rows, s++));
+  f = miller_mul_by_line_product_rows(f, rows_after(rows, f.c0.c0), s++);
   return f.conj();  // x < 0
 }
 
