@@ -158,7 +158,7 @@ int hs_pairing_check(const uint8_t* a, const uint8_t* b, const uint8_t* c, const
 // final exponentiation -- the three kernels of k_pairing.hip one after the other
 int hs_pairing_check_prepared(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d) {
   std::vector<Fq2> mem(kMillerRowSlots);
-  const Fq2Rows rows{mem.data()};
+  const Fq2Rows rows = Fq2Rows::at(mem.data());
   DirectIO ia{a, 0, nullptr}, ib{b, 0, nullptr}, ic{c, 0, nullptr}, id{d, 0, nullptr};
   if (!job_miller_lines_io(true, ia, ib, ic, id, rows)) return 0;
   return job_final_exp_is_one(miller_accumulate(rows));

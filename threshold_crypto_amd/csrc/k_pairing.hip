@@ -107,12 +107,12 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_P) void k_miller_lines(cons
   const size_t jj = live ? j : 0;
   IO1 ia{lds, live ? a + jj * sa : nullptr, 0, nullptr}, ic{lds, live ? c + jj * sc : nullptr, 0, nullptr};
   IO2 ib{lds, live ? b + jj * sb : nullptr, 0, nullptr}, id{lds, live ? d + jj * sd : nullptr, 0, nullptr};
-  const bool good = job_miller_lines_io(live, ia, ib, ic, id, Fq2Rows{lines + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x});
+  const bool good = job_miller_lines_io(live, ia, ib, ic, id, Fq2Rows::at(lines + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x));
   if (live && pair_leader()) ok[j] = good ? 1 : 0;  // 0: an operand did not decode; the later kernels keep it
 }
 
 __global__ __launch_bounds__(kBlock, TC_WAVES_MILLER_M) void k_miller_accumulate(const int32_t* lines, int32_t* __restrict__ fbuf) {
-  const Fq12 f = miller_accumulate(Fq2Rows{const_cast<int32_t*>(lines) + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x});
+  const Fq12 f = miller_accumulate(Fq2Rows::at(const_cast<int32_t*>(lines) + (size_t)blockIdx.x * kLineWords * 64 + threadIdx.x));
   fq12_store_rows(fbuf + (size_t)blockIdx.x * kFq12Words * 64 + threadIdx.x, f);
 }
 #else

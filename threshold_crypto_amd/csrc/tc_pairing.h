@@ -168,8 +168,16 @@ constexpr int kLineProductCoeffs = 5;    // c0 = (a0, a1, a2), c1 = (0, b1, b2)
 // of lane l at p[w * 64 + l], so every store / load instruction moves one full 256-byte row.  Host build (test harness): a
 // plain array.
 #if TC_PAIR
+#if defined(__HIP_DEVICE_COMPILE__)
+// (explicitly GLOBAL: a pointer that went through rows_after's empty asm is no longer known to point into global memory,
+// and a generic pointer makes every access a flat_load that also has to wait for the LDS counter)
+typedef __attribute__((address_space(1))) int32_t* RowPtr;
+#else
+typedef int32_t* RowPtr;
+#endif
 struct Fq2Rows {
-  int32_t* p;
+  RowPtr p;
+  TC_HD static Fq2Rows at(int32_t* q) { return Fq2Rows{(RowPtr)q}; }
   TC_HD void put(int k, const Fq2& v) const {
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) p[(k * FQ_LIMBS + i) * 64] = v.m.l[i];
   }
@@ -185,6 +193,7 @@ struct Fq2Rows {
 #else
 struct Fq2Rows {
   Fq2* p;
+  TC_HD static Fq2Rows at(Fq2* q) { return Fq2Rows{q}; }
   TC_HD void put(int k, const Fq2& v) const { p[k] = v; }
   TC_HD Fq2 get(int k) const { return p[k]; }
   TC_HD void put_fq(int k, const Fq& v) const { p[k] = Fq2{v, Fq::zero()}; }
@@ -193,75 +202,88 @@ struct Fq2Rows {
 #endif
 
 // Row slots of a lane's block: the operands of the check (G1 coordinates, the affine G2 points: read where a step uses
-// them instead of being held in 112 registers for the whole loop), the first pair's line of the current step (parked while
-// the second pair's point advances), then the 68 x 5 line-product coefficients stage M reads.
-constexpr int kRowPx = 0, kRowPy = 2, kRowQx = 4, kRowQy = 6, kRowLine = 8, kRowProducts = 11;
+// them instead of being held in 112 registers for the whole loop), the 68 scaled lines of the FIRST pair (stage P runs the
+// two Miller points one after the other: pass 1 leaves the first pair's lines here, pass 2 multiplies each with the second
+// pair's line of the same step), then the 68 x 5 line-product coefficients stage M reads.
+constexpr int kRowPx = 0, kRowPy = 2, kRowQx = 4, kRowQy = 6, kRowFirst = 8, kRowProducts = kRowFirst + 3 * 68;
 constexpr int kMillerRowSlots = kRowProducts + kMillerSteps * kLineProductCoeffs;
 
 TC_HD Fq2Rows rows_after(const Fq2Rows& rows, const Fq2& v);
 
-// one step of stage P: both points advance, their lines meet in one product.  A skipped pair (an operand at infinity)
-// contributes the unit line; its point arithmetic runs on a harmless stand-in.
+// one step of one Miller point: the point advances, its line is evaluated at the pair's G1 point: (e0, e1 v, e4 v w).  A
+// skipped pair (an operand at infinity) contributes the unit line; its point arithmetic runs on a harmless stand-in.
 template <bool ADD>
-TC_HD void miller_lines_step(G2Jac* r, const bool* skip, const Fq2Rows& rows, int s) {
-  Fq2 e0, e1, e4;
-  TC_UNROLL for (int k = 0; k < 2; k++) {
-    LineCoeffs l;
-    if (ADD) {
-      const Fq2Rows rq = rows_after(rows, r[k].z);
-      l = miller_addition_step(r[k], G2Affine{rq.get(kRowQx + k), rq.get(kRowQy + k), false});
-    } else {
-      l = miller_doubling_step(r[k]);
-    }
-    const Fq2Rows rp = rows_after(rows, l.c2);
-    e0 = Fq2::select(skip[k], Fq2::one(), l.c2);
-    e1 = Fq2::select(skip[k], Fq2::zero(), l.c1.scale(rp.get_fq(kRowPx + k)));
-    e4 = Fq2::select(skip[k], Fq2::zero(), l.c0.scale(rp.get_fq(kRowPy + k)));
-    if (k == 0) {
-      rows.put(kRowLine + 0, e0);
-      rows.put(kRowLine + 1, e1);
-      rows.put(kRowLine + 2, e4);
-    }
+TC_HD void miller_point_step(G2Jac& r, int k, bool skip, const Fq2Rows& rows, Fq2& e0, Fq2& e1, Fq2& e4) {
+  LineCoeffs l;
+  if (ADD) {
+    const Fq2Rows rq = rows_after(rows, r.z);
+    l = miller_addition_step(r, G2Affine{rq.get(kRowQx + k), rq.get(kRowQy + k), false});
+  } else {
+    l = miller_doubling_step(r);
   }
-  // (d0 + d1 v + d4 v w) (e0 + e1 v + e4 v w), Fq12::line_product with the first line read back where it is used
-  const int k = kRowProducts + s * kLineProductCoeffs;
+  const Fq2Rows rp = rows_after(rows, l.c2);
+  e0 = Fq2::select(skip, Fq2::one(), l.c2);
+  e1 = Fq2::select(skip, Fq2::zero(), l.c1.scale(rp.get_fq(kRowPx + k)));
+  e4 = Fq2::select(skip, Fq2::zero(), l.c0.scale(rp.get_fq(kRowPy + k)));
+}
+
+// pass 1: the first pair's line of step s goes to its rows
+template <bool ADD>
+TC_HD void miller_first_step(G2Jac& r, bool skip, const Fq2Rows& rows, int s) {
+  Fq2 e0, e1, e4;
+  miller_point_step<ADD>(r, 0, skip, rows, e0, e1, e4);
+  rows.put(kRowFirst + 3 * s + 0, e0);
+  rows.put(kRowFirst + 3 * s + 1, e1);
+  rows.put(kRowFirst + 3 * s + 2, e4);
+}
+
+// pass 2: the second pair's line of step s times the first pair's (read back where the product uses it):
+// (d0 + d1 v + d4 v w) (e0 + e1 v + e4 v w), the six Fq2 products of Fq12::line_product
+template <bool ADD>
+TC_HD void miller_second_step(G2Jac& r, bool skip, const Fq2Rows& rows, int s) {
+  Fq2 e0, e1, e4;
+  miller_point_step<ADD>(r, 1, skip, rows, e0, e1, e4);
+  const int k = kRowProducts + s * kLineProductCoeffs, d = kRowFirst + 3 * s;
   const Fq2Rows ra = rows_after(rows, e4);
-  const Fq2 d0 = ra.get(kRowLine + 0);
+  const Fq2 d0 = ra.get(d + 0), d1 = ra.get(d + 1), d4 = ra.get(d + 2);
   const Fq2 t0 = d0 * e0;
-  const Fq2 d4 = ra.get(kRowLine + 2);
+  const Fq2 t1 = d1 * e1;
   const Fq2 t3 = d4 * e4;
   rows.put(k + 0, (t0 + t3.mul_xi()).norm());
-  const Fq2 u = (d0 + d4) * (e0 + e4) - t0 - t3;
-  rows.put(k + 3, u.norm());
-  const Fq2Rows rb = rows_after(rows, u);
-  const Fq2 d1 = rb.get(kRowLine + 1);
-  const Fq2 t1 = d1 * e1;
   rows.put(k + 2, t1);
-  const Fq2 w = (d1 + rb.get(kRowLine + 2)) * (e1 + e4) - t1 - t3;
-  rows.put(k + 4, w.norm());
-  const Fq2Rows rc = rows_after(rows, w);
-  const Fq2 t2 = (rc.get(kRowLine + 0) + d1) * (e0 + e1) - t0 - t1;
-  rows.put(k + 1, t2.norm());
+  rows.put(k + 1, ((d0 + d1) * (e0 + e1) - t0 - t1).norm());
+  rows.put(k + 3, ((d0 + d4) * (e0 + e4) - t0 - t3).norm());
+  rows.put(k + 4, ((d1 + d4) * (e1 + e4) - t1 - t3).norm());
+}
+
+template <int PASS>
+TC_HD void miller_lines_pass(const G2Affine& q, bool skip, const Fq2Rows& rows) {
+  G2Jac r{q.x, q.y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
+  const uint64_t xs = BLS_X_ABS >> 1;
+  int s = 0;
+  TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
+    tc_fair();
+    if (PASS == 0) miller_first_step<false>(r, skip, rows, s++);
+    else miller_second_step<false>(r, skip, rows, s++);
+    if ((xs >> i) & 1ull) {
+      if (PASS == 0) miller_first_step<true>(r, skip, rows, s++);
+      else miller_second_step<true>(r, skip, rows, s++);
+    }
+  }
+  if (PASS == 0) miller_first_step<false>(r, skip, rows, s++);
+  else miller_second_step<false>(r, skip, rows, s++);
 }
 
 // qs: the two affine G2 points, ps: the two G1 points (the second already negated)
 TC_HD void miller_prepare_lines(const G1Affine* ps, const G2Affine* qs, const bool* skip, const Fq2Rows& rows) {
-  G2Jac r[2];
   TC_UNROLL for (int k = 0; k < 2; k++) {
     rows.put_fq(kRowPx + k, ps[k].x);
     rows.put_fq(kRowPy + k, ps[k].y);
     rows.put(kRowQx + k, qs[k].x);
     rows.put(kRowQy + k, qs[k].y);
-    r[k] = G2Jac{qs[k].x, qs[k].y, Fq2::one().dbl().norm()};  // (x : y : 1), third coordinate doubled
   }
-  const uint64_t xs = BLS_X_ABS >> 1;
-  int s = 0;
-  TC_NOUNROLL for (int i = 61; i >= 0; i--) {  // bit 62 is the leading one
-    tc_fair();
-    miller_lines_step<false>(r, skip, rows, s++);
-    if ((xs >> i) & 1ull) miller_lines_step<true>(r, skip, rows, s++);
-  }
-  miller_lines_step<false>(r, skip, rows, s++);
+  miller_lines_pass<0>(qs[0], skip[0], rows);
+  miller_lines_pass<1>(qs[1], skip[1], rows_after(rows, Fq2::zero()));
 }
 
 TC_HD Fq12 miller_line_product_at(const Fq2Rows& rows, int s) {
@@ -277,7 +299,7 @@ TC_HD Fq12 miller_line_product_at(const Fq2Rows& rows, int s) {
 // registers for them beside the accumulator, and copies them from HBM straight into scratch.
 TC_HD Fq2Rows rows_after(const Fq2Rows& rows, const Fq2& v) {  // (declared above)
 #if TC_PAIR && defined(__HIP_DEVICE_COMPILE__)
-  int32_t* p = rows.p;
+  RowPtr p = rows.p;
   asm volatile("" : "+v"(p) : "v"(v.m.l[0]));
   return Fq2Rows{p};
 #else
