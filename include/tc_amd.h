@@ -148,6 +148,29 @@ int tc_g2_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uin
 /* PublicKeySet::decrypt src/lib.rs:618-626: out bytes[off[j]..off[j+1]] = xor_with_hash(combine_g1, v_j) */
 int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
                      const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status);
+/* `T: IntoFr` beyond u64.  combine_signatures / decrypt are generic over the index type (src/lib.rs:608-622): besides
+ * u64 / usize it may be Fr itself or a negative i32 / i64 (src/into_fr.rs:10-14, 28-56: -(|x|) mod r).  idx_fr: B x n_per_job
+ * abscissae as 32 B LE canonical Fr values (the IntoFr image; the interpolation point is idx_fr + 1, src/lib.rs:769-773), in
+ * the iteration order of the reference's map.  A batch whose first t+1 abscissae per job all fit 64 bits runs the u64
+ * kernels (small-index fast path included); otherwise every job takes the general path with coefficients from Fr
+ * arithmetic.  A non-canonical abscissa (>= r) fails its job with TC_JOB_INVALID_ENCODING. */
+int tc_combine_g2_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares, size_t B, uint8_t* out,
+                           uint8_t* status);
+int tc_combine_g1_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares, size_t B, uint8_t* out,
+                           uint8_t* status);
+int tc_decrypt_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares_g1, const uint8_t* v,
+                        const uint64_t* off, size_t B, uint8_t* out, uint8_t* status);
+/* Wire-level forms of the two combiners.  Shares arrive as they travel -- SignatureShare / Signature::to_bytes, 96 B
+ * compressed G2 (src/lib.rs:255-259), DecryptionShare's 48 B compressed G1 (src/serde_impl.rs:174-218) -- and pass through the
+ * CHECKED decode of from_bytes (src/lib.rs:140-146, 246-252: flags, range, on the curve, order-r subgroup) on the device:
+ * only the first t+1 samples of a job, exactly the ones interpolate() uses; a job that owns an undecodable or non-member
+ * share gets TC_JOB_INVALID_ENCODING and the identity.  tc_combine_signatures_wire_batch returns Signature::to_bytes of
+ * the combined signature (96 B per job); tc_decrypt_wire_batch the plaintext bytes.  One call = decode + membership +
+ * combine + encode on the device; the context's input-check switch does not apply (the decode IS the check). */
+int tc_combine_signatures_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares96, size_t B,
+                                     uint8_t* out96, uint8_t* status);
+int tc_decrypt_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares48, const uint8_t* v,
+                          const uint64_t* off, size_t B, uint8_t* out, uint8_t* status);
 /* out[j] = data[j] ^ keystream(g1[j])                       fn xor_with_hash, src/lib.rs:710-715 */
 int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                            uint8_t* out, uint8_t* status);

@@ -1615,4 +1615,62 @@ EXPORT int or_g2_decompress(const uint8_t *in96, uint8_t *out192) {
   return 0;
 }
 
+/* Wire-level PublicKeySet::combine_signatures (what a caller of the reference does with bytes off the network): each of the
+ * first t+1 shares through Signature::from_bytes (src/lib.rs:246-252: checked decode above), interpolate (src/lib.rs:719-767),
+ * Signature::to_bytes (src/lib.rs:255-259).  rc: 0, 1 = NotEnoughShares, 3 = FromBytesError::Invalid (out = the identity). */
+EXPORT int or_combine_signatures_wire(size_t t, size_t n, const u64 *idx, const uint8_t *shares96, uint8_t *out96) {
+  tc_init();
+  memset(out96, 0, 96);
+  out96[0] = 0xc0;
+  if (n <= t) return 1;
+  uint8_t *dec = (uint8_t *)malloc((t + 1) * 192);
+  int rc = 0;
+  for (size_t k = 0; k <= t && !rc; k++) rc = or_g2_decompress(shares96 + k * 96, dec + k * 192);
+  uint8_t sig[192];
+  if (!rc) rc = or_combine_g2(t, t + 1, idx, dec, sig);
+  if (!rc) rc = or_g2_compress(sig, out96);
+  free(dec);
+  return rc;
+}
+/* Wire-level PublicKeySet::decrypt: the decryption shares in their 48-byte compressed form (src/serde_impl.rs:174-218) */
+EXPORT int or_decrypt_wire(size_t t, size_t n, const u64 *idx, const uint8_t *shares48, const uint8_t *v, size_t len, uint8_t *out) {
+  tc_init();
+  memset(out, 0, len);
+  if (n <= t) return 1;
+  uint8_t *dec = (uint8_t *)malloc((t + 1) * 96);
+  int rc = 0;
+  for (size_t k = 0; k <= t && !rc; k++) rc = or_g1_decompress(shares48 + k * 48, dec + k * 96);
+  if (!rc) rc = or_threshold_decrypt(t, t + 1, idx, dec, v, len, out);
+  free(dec);
+  return rc;
+}
+typedef struct {
+  size_t t, n, lo, hi;
+  const u64 *idx;
+  const uint8_t *shares;
+  uint8_t *out;
+  int *rc;
+} wire_job;
+static void *wire_worker(void *arg) {
+  wire_job *j = (wire_job *)arg;
+  for (size_t k = j->lo; k < j->hi; k++)
+    j->rc[k] = or_combine_signatures_wire(j->t, j->n, j->idx + k * j->n, j->shares + k * j->n * 96, j->out + k * 96);
+  return NULL;
+}
+EXPORT void or_combine_signatures_wire_batch(size_t t, size_t n, const u64 *idx, const uint8_t *shares96, size_t B, uint8_t *out96, int *rc,
+                                             int nthreads) {
+  tc_init();
+  if (nthreads < 1) nthreads = 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  wire_job *jobs = (wire_job *)malloc(sizeof(wire_job) * (size_t)nthreads);
+  for (int i = 0; i < nthreads; i++) {
+    wire_job w = {t, n, B * (size_t)i / (size_t)nthreads, B * (size_t)(i + 1) / (size_t)nthreads, idx, shares96, out96, rc};
+    jobs[i] = w;
+    pthread_create(&th[i], NULL, wire_worker, &jobs[i]);
+  }
+  for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  free(th);
+  free(jobs);
+}
+
 EXPORT void or_sha3_256(const uint8_t *msg, size_t len, uint8_t *out32) { sha3_256(msg, len, out32); }

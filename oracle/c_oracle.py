@@ -59,6 +59,10 @@ def load():
         _lib.or_ciphertext_verify_batch.restype = None
         _lib.or_threshold_decrypt_batch.argtypes = [sz, sz, vp, vp, vp, sz, sz, vp, vp, ctypes.c_int]
         _lib.or_threshold_decrypt_batch.restype = None
+        _lib.or_combine_signatures_wire.argtypes = [sz, sz, vp, cp, cp]
+        _lib.or_decrypt_wire.argtypes = [sz, sz, vp, cp, cp, sz, cp]
+        _lib.or_combine_signatures_wire_batch.argtypes = [sz, sz, vp, vp, sz, vp, vp, ctypes.c_int]
+        _lib.or_combine_signatures_wire_batch.restype = None
     return _lib
 
 
@@ -221,6 +225,29 @@ def threshold_decrypt_batch(t, idx, shares, v, length, nthreads):
     idx, shares, v = np.ascontiguousarray(idx), np.ascontiguousarray(shares), np.ascontiguousarray(v)
     load().or_threshold_decrypt_batch(t, n, idx.ctypes.data, shares.ctypes.data, v.ctypes.data, length, B, out.ctypes.data,
                                       rc.ctypes.data, nthreads)
+    return out, rc
+
+
+def combine_signatures_wire(t, ids, shares96):
+    """(rc, 96 B Signature::to_bytes) from the first t+1 of the 96-byte compressed shares (checked decode)"""
+    out = _buf(96)
+    return load().or_combine_signatures_wire(t, len(ids), _idx(ids), b"".join(bytes(s) for s in shares96), out), out.raw
+
+
+def decrypt_wire(t, ids, shares48, v):
+    out = _buf(max(len(v), 1))
+    rc = load().or_decrypt_wire(t, len(ids), _idx(ids), b"".join(bytes(s) for s in shares48), bytes(v), len(v), out)
+    return rc, out.raw[:len(v)]
+
+
+def combine_signatures_wire_batch(t, idx, shares96, nthreads):
+    """idx: (B, n) uint64, shares96: (B, n, 96) uint8 -> (out (B, 96) uint8, rc (B,) int32)"""
+    import numpy as np
+    B, n = idx.shape
+    out = np.zeros((B, 96), dtype=np.uint8)
+    rc = np.zeros(B, dtype=np.int32)
+    idx, shares96 = np.ascontiguousarray(idx), np.ascontiguousarray(shares96)
+    load().or_combine_signatures_wire_batch(t, n, idx.ctypes.data, shares96.ctypes.data, B, out.ctypes.data, rc.ctypes.data, nthreads)
     return out, rc
 
 

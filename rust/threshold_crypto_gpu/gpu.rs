@@ -28,8 +28,8 @@
 use crate::error::{Error, FromBytesError, Result};
 use crate::poly::{BivarCommitment, Commitment, Poly};
 use crate::{
-    Ciphertext, DecryptionShare, Fr, G1Affine, G2Affine, PublicKey, PublicKeySet, PublicKeyShare, SecretKey, SecretKeySet, SecretKeyShare,
-    Signature, SignatureShare, G1, G2,
+    Ciphertext, DecryptionShare, Fr, G1Affine, G2Affine, IntoFr, PublicKey, PublicKeySet, PublicKeyShare, SecretKey, SecretKeySet,
+    SecretKeyShare, Signature, SignatureShare, G1, G2, PK_SIZE, SIG_SIZE,
 };
 use ff::{PrimeField, PrimeFieldRepr};
 use group::{CurveAffine, CurveProjective, EncodedPoint};
@@ -127,11 +127,33 @@ fn pack_messages<M: AsRef<[u8]>>(msgs: &[M]) -> (Vec<u8>, Vec<u64>) {
     }
     (flat, off)
 }
+/// Per-job status -> the reference's error type.  The typed entry points below only hand over values that already passed
+/// `from_bytes` / were produced by the crate, so TC_JOB_INVALID_ENCODING (an undecodable or non-member point operand) cannot
+/// come back from them: it is a bug, not an `Error` -- and it must not be reported as `DuplicateEntry`.  The wire-level
+/// functions, whose inputs are raw bytes, map it to `FromBytesError::Invalid` (`WireError::Invalid`).
 fn status_to_result<T>(st: u8, v: T) -> Result<T> {
     match st {
         TC_JOB_OK => Ok(v),
         TC_JOB_NOT_ENOUGH_SHARES => Err(Error::NotEnoughShares),
-        _ => Err(Error::DuplicateEntry),
+        TC_JOB_DUPLICATE_ENTRY => Err(Error::DuplicateEntry),
+        TC_JOB_INVALID_ENCODING => panic!("libtc_amd: TC_JOB_INVALID_ENCODING for an operand that was a valid group element"),
+        other => panic!("libtc_amd: unknown job status {}", other),
+    }
+}
+/// Errors of the wire-level entry points: the reference's `Error` for the threshold logic, `FromBytesError::Invalid` for a
+/// share that does not decode or is no group member (src/error.rs:37-41).
+#[derive(Debug, PartialEq)]
+pub enum WireError {
+    Threshold(Error),
+    Invalid(FromBytesError),
+}
+fn wire_status_to_result<T>(st: u8, v: T) -> std::result::Result<T, WireError> {
+    match st {
+        TC_JOB_OK => Ok(v),
+        TC_JOB_NOT_ENOUGH_SHARES => Err(WireError::Threshold(Error::NotEnoughShares)),
+        TC_JOB_DUPLICATE_ENTRY => Err(WireError::Threshold(Error::DuplicateEntry)),
+        TC_JOB_INVALID_ENCODING => Err(WireError::Invalid(FromBytesError::Invalid)),
+        other => panic!("libtc_amd: unknown job status {}", other),
     }
 }
 
@@ -232,9 +254,31 @@ impl PublicKeySet {
     fn commit_bytes(&self) -> Vec<u8> {
         self.commit.coeff.iter().flat_map(|c| g1_bytes(c).to_vec()).collect()
     }
-    /// Batch form of `combine_signatures` (src/lib.rs:608-615).  `jobs[j]` iterates `(index, share)` in the order the
-    /// single-item method would see it (BTreeMap order); every job holds the same number of shares.
-    pub fn combine_signatures_batch<'a, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<Result<Signature>>
+    /// Batch form of `combine_signatures` (src/lib.rs:608-615), generic over the index type like the original (`T: IntoFr`:
+    /// u64 / usize, Fr, negative i32 / i64 -- src/into_fr.rs).  `jobs[j]` iterates `(index, share)` in the order the
+    /// single-item method would see it (BTreeMap order); every job holds the same number of shares.  The abscissae travel as
+    /// Fr values (tc_combine_g2_fr_batch); a batch whose indices all fit 64 bits runs the u64 kernels inside the library.
+    pub fn combine_signatures_batch<'a, T, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<Result<Signature>>
+    where
+        T: IntoFr,
+        I: Clone + IntoIterator<Item = (T, &'a SignatureShare)>,
+    {
+        let t = self.threshold();
+        let n = jobs.first().map(|j| j.clone().into_iter().count()).unwrap_or(0);
+        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n * FR_BYTES), Vec::with_capacity(jobs.len() * n * G2_BYTES));
+        for job in jobs {
+            for (i, s) in job.clone() {
+                idx.extend_from_slice(&fr_bytes(&i.into_fr()));
+                shares.extend_from_slice(&g2_bytes(&(s.0).0));
+            }
+        }
+        assert_eq!(idx.len(), jobs.len() * n * FR_BYTES, "every job must hold the same number of shares");
+        let (mut out, mut st) = (vec![0u8; jobs.len() * G2_BYTES], vec![0u8; jobs.len()]);
+        gpu.check(unsafe { tc_combine_g2_fr_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        st.iter().enumerate().map(|(j, &s)| status_to_result(s, Signature(g2_from(&out[j * G2_BYTES..(j + 1) * G2_BYTES])))).collect()
+    }
+    /// The same for plain u64 indices without the detour through Fr (tc_combine_g2_batch).
+    pub fn combine_signatures_batch_u64<'a, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<Result<Signature>>
     where
         I: Clone + IntoIterator<Item = (u64, &'a SignatureShare)>,
     {
@@ -252,27 +296,76 @@ impl PublicKeySet {
         gpu.check(unsafe { tc_combine_g2_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
         st.iter().enumerate().map(|(j, &s)| status_to_result(s, Signature(g2_from(&out[j * G2_BYTES..(j + 1) * G2_BYTES])))).collect()
     }
-    /// Batch form of `decrypt` (src/lib.rs:618-626): per job the shares of one ciphertext; returns the plaintexts.
-    pub fn decrypt_batch<'a, I>(&self, gpu: &Gpu, jobs: &[I], cts: &[Ciphertext]) -> Vec<Result<Vec<u8>>>
+    /// Wire-level `combine_signatures`: the shares as they arrive (`SignatureShare::to_bytes`, 96 bytes each; checked decode of
+    /// `from_bytes`, src/lib.rs:246-252, ON the device), the combined signature as `Signature::to_bytes` (src/lib.rs:255-259).
+    pub fn combine_signatures_wire_batch(&self, gpu: &Gpu, jobs: &[Vec<(u64, [u8; SIG_SIZE])>]) -> Vec<std::result::Result<[u8; SIG_SIZE], WireError>> {
+        let t = self.threshold();
+        let n = jobs.first().map(|j| j.len()).unwrap_or(0);
+        assert!(jobs.iter().all(|j| j.len() == n), "every job must hold the same number of shares");
+        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * SIG_SIZE));
+        for job in jobs {
+            for (i, s) in job {
+                idx.push(*i);
+                shares.extend_from_slice(s);
+            }
+        }
+        let (mut out, mut st) = (vec![0u8; jobs.len() * SIG_SIZE], vec![0u8; jobs.len()]);
+        gpu.check(unsafe { tc_combine_signatures_wire_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        st.iter()
+            .enumerate()
+            .map(|(j, &s)| {
+                let mut sig = [0u8; SIG_SIZE];
+                sig.copy_from_slice(&out[j * SIG_SIZE..(j + 1) * SIG_SIZE]);
+                wire_status_to_result(s, sig)
+            })
+            .collect()
+    }
+    /// Batch form of `decrypt` (src/lib.rs:618-626), generic over `T: IntoFr`: per job the shares of one ciphertext; returns the
+    /// plaintexts.
+    pub fn decrypt_batch<'a, T, I>(&self, gpu: &Gpu, jobs: &[I], cts: &[Ciphertext]) -> Vec<Result<Vec<u8>>>
     where
-        I: Clone + IntoIterator<Item = (u64, &'a DecryptionShare)>,
+        T: IntoFr,
+        I: Clone + IntoIterator<Item = (T, &'a DecryptionShare)>,
     {
+        assert_eq!(jobs.len(), cts.len(), "one ciphertext per share set");
         let t = self.threshold();
         let n = jobs.first().map(|j| j.clone().into_iter().count()).unwrap_or(0);
-        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * G1_BYTES));
+        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n * FR_BYTES), Vec::with_capacity(jobs.len() * n * G1_BYTES));
         for job in jobs {
             for (i, s) in job.clone() {
-                idx.push(i);
+                idx.extend_from_slice(&fr_bytes(&i.into_fr()));
                 shares.extend_from_slice(&g1_bytes(&s.0));
+            }
+        }
+        assert_eq!(idx.len(), jobs.len() * n * FR_BYTES, "every job must hold the same number of shares");
+        let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
+        let (flat, off) = pack_messages(&vs);
+        let (mut out, mut st) = (vec![0u8; flat.len()], vec![0u8; jobs.len()]);
+        gpu.check(unsafe {
+            tc_decrypt_fr_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
+        });
+        st.iter().enumerate().map(|(j, &s)| status_to_result(s, out[off[j] as usize..off[j + 1] as usize].to_vec())).collect()
+    }
+    /// Wire-level `decrypt`: the decryption shares in their 48-byte compressed form (checked decode on the device).
+    pub fn decrypt_wire_batch(&self, gpu: &Gpu, jobs: &[Vec<(u64, [u8; PK_SIZE])>], cts: &[Ciphertext]) -> Vec<std::result::Result<Vec<u8>, WireError>> {
+        assert_eq!(jobs.len(), cts.len(), "one ciphertext per share set");
+        let t = self.threshold();
+        let n = jobs.first().map(|j| j.len()).unwrap_or(0);
+        assert!(jobs.iter().all(|j| j.len() == n), "every job must hold the same number of shares");
+        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * PK_SIZE));
+        for job in jobs {
+            for (i, s) in job {
+                idx.push(*i);
+                shares.extend_from_slice(s);
             }
         }
         let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
         let (flat, off) = pack_messages(&vs);
         let (mut out, mut st) = (vec![0u8; flat.len()], vec![0u8; jobs.len()]);
         gpu.check(unsafe {
-            tc_decrypt_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
+            tc_decrypt_wire_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
         });
-        st.iter().enumerate().map(|(j, &s)| status_to_result(s, out[off[j] as usize..off[j + 1] as usize].to_vec())).collect()
+        st.iter().enumerate().map(|(j, &s)| wire_status_to_result(s, out[off[j] as usize..off[j + 1] as usize].to_vec())).collect()
     }
     /// `public_key_share(i)` for many indices (src/lib.rs:570-573 -> Commitment::evaluate, src/poly.rs:497-508).
     pub fn public_key_shares(&self, gpu: &Gpu, indices: &[u64]) -> Vec<PublicKeyShare> {

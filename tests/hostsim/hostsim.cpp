@@ -112,6 +112,17 @@ int hs_lagrange(const uint64_t* idx, int t, int i, uint8_t* out32le) {
   memcpy(out32le, w, 32);
   return st;
 }
+// lambda_i from Fr abscissae (`T: IntoFr` beyond u64: tc_threshold.h lagrange_coeff_at_zero_fr, the body of k_lagrange_fr)
+int hs_lagrange_fr(const uint8_t* xs32le, int t, int i, uint8_t* out32le) {
+  std::vector<uint32_t> xs((size_t)(t + 1) * 8);
+  memcpy(xs.data(), xs32le, xs.size() * 4);
+  Fr l;
+  if (!lagrange_coeff_at_zero_fr(xs.data(), t, i, l)) return TC_JOB_DUPLICATE_ENTRY;
+  uint32_t w[8];
+  l.to_canonical(w);
+  memcpy(out32le, w, 32);
+  return 0;
+}
 void hs_fr_inverse_of_small(uint64_t d_abs, int d_neg, uint8_t* out32le) {
   uint32_t w[8];
   fr_inverse_of_small(d_abs, d_neg != 0, w);

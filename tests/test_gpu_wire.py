@@ -1,0 +1,211 @@
+"""GPU parity of the round-4 boundary entries, through the C ABI:
+
+  * the WIRE-LEVEL combiners (tc_combine_signatures_wire_batch / tc_decrypt_wire_batch): shares as they travel -- 96-byte
+    Signature::to_bytes, 48-byte compressed G1 -- through the checked decode of from_bytes
+    (/root/reference/src/lib.rs:140-146, 246-252) on the device, the combined signature back as Signature::to_bytes
+    (src/lib.rs:255-259).  Checker: Oracle B's g2_decompress -> combine -> g2_compress, job by job, at BASELINE config 2's
+    full batch with planted undecodable and non-member shares;
+  * `T: IntoFr` beyond u64 (tc_combine_g{1,2}_fr_batch, tc_decrypt_fr_batch): the reference's test_interpolate
+    (src/lib.rs:793-808, whose indices are i32) replayed with negative integers, field elements and 2^64-range values.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import c_oracle as c
+import tc_oracle as o
+from threshold_crypto_amd import api
+from threshold_crypto_amd.engine import pack_messages
+
+pytestmark = pytest.mark.gpu
+B_FULL = int(os.environ.get("TC_TEST_BASELINE_JOBS", "65536"))
+
+
+def u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+@pytest.fixture(scope="module")
+def rnd():
+    return random.Random(20260927)
+
+
+def non_member_g2(rnd):
+    """an on-curve point of E'(Fq2) outside the order-r subgroup (its cofactor is ~2^508: a random point never is inside)"""
+    while True:
+        P = o.g2_get_point_from_x((rnd.randrange(o.Q), rnd.randrange(o.Q)), True)
+        if P is not None and o.E2.mul(P, o.R) is not None:
+            return P
+
+
+def non_member_g1(rnd):
+    while True:
+        x = rnd.randrange(o.Q)
+        y2 = (x * x * x + 4) % o.Q
+        y = pow(y2, (o.Q + 1) // 4, o.Q)
+        if y * y % o.Q == y2 and o.E1.mul((x, y), o.R) is not None:
+            return (x, y)
+
+
+def test_wire_combine_edge_cases_vs_oracle(engine, rnd):
+    """70 jobs (a wave boundary inside), t = 2 of n = 5 shares each: valid jobs; an undecodable share (x >= q; the
+    uncompressed flag; a non-square x^3 + b); an on-curve NON-member; the identity as a share; garbage in the samples
+    BEYOND the first t + 1 (interpolate() never looks at them); both roots of one x (the sort bit matters).  Status and
+    bytes equal Oracle B's decompress -> combine -> compress for every job; failed jobs return the identity's encoding."""
+    t, n, B = 2, 5, 70
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    H = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(B)]
+    idx = np.array([sorted(rnd.sample(range(12), n)) for _ in range(B)], dtype=np.uint64)
+    sh = np.zeros((B, n, 96), dtype=np.uint8)
+    for j in range(B):
+        for k in range(n):
+            sh[j, k] = u8(o.g2_compressed(o.E2.mul(H[j], o.poly_evaluate(poly, int(idx[j, k]) + 1))))
+    sh[3, 1] = 0xFF                                            # x >= q (flags say compressed, not infinity)
+    sh[5, 0, 0] &= 0x7F                                        # the compressed flag missing
+    bad_x = None
+    while bad_x is None:                                       # x with x^3 + b a non-square: no point at all
+        cand = (rnd.randrange(o.Q), rnd.randrange(o.Q))
+        if o.g2_get_point_from_x(cand, True) is None:
+            bad_x = cand
+    enc = bytearray(bad_x[1].to_bytes(48, "big") + bad_x[0].to_bytes(48, "big"))
+    enc[0] |= 0x80
+    sh[7, 2] = u8(bytes(enc))
+    sh[9, 1] = u8(o.g2_compressed(non_member_g2(rnd)))        # on the curve, outside G2
+    sh[11, 0] = u8(o.g2_compressed(None))                      # the identity IS a member
+    sh[13, 3:] = 0xAB                                          # beyond the first t+1 samples: never read
+    sh[15, 1, 0] ^= 0x20                                       # the other root: a different (valid) share
+    sh[64, 2] = 0                                              # first job of the second wave: all-zero bytes
+    out, st = engine.combine_signatures_wire(t, idx, sh)
+    for j in range(B):
+        rc, want = c.combine_signatures_wire(t, [int(i) for i in idx[j]], [bytes(x) for x in sh[j]])
+        assert rc == int(st[j]) and bytes(out[j]) == want, (j, rc, int(st[j]))
+    assert [int(st[j]) for j in (3, 5, 7, 9, 64)] == [3] * 5 and not st[[0, 11, 13, 15]].any()
+    assert bytes(out[3]) == bytes([0xC0]) + bytes(95)
+    assert bytes(out[0]) == o.g2_compressed(o.E2.mul(H[0], poly[0]))
+    # too few shares: NotEnoughShares for every job, as src/lib.rs:731-733
+    out, st = engine.combine_signatures_wire(t, idx[:, :2].copy(), sh[:, :2].copy())
+    assert (st == 1).all()
+    # the host-side mirror: bytes in, bytes out
+    pk_set = api.PublicKeySet([o.g1_uncompressed(o.E1.mul(o.G1_GEN, cf)) for cf in poly], _trusted=True)
+    sigs, st = pk_set.combine_signatures_wire_batch([[(int(idx[j, k]), bytes(sh[j, k])) for k in range(n)] for j in (0, 1, 9)], engine=engine)
+    assert [int(s) for s in st] == [0, 0, 3] and sigs[0] == o.g2_compressed(o.E2.mul(H[0], poly[0]))
+
+
+def test_wire_decrypt_vs_oracle(engine, rnd):
+    """PublicKeySet::decrypt with 48-byte decryption shares: plaintexts and statuses equal Oracle B's
+    g1_decompress -> threshold_decrypt on 70 ciphertexts, incl. an undecodable and a non-member share."""
+    t, n, B = 3, 4, 70
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    pk = o.E1.mul(o.G1_GEN, poly[0])
+    idx = np.array([sorted(rnd.sample(range(10), n)) for _ in range(B)], dtype=np.uint64)
+    sh = np.zeros((B, n, 48), dtype=np.uint8)
+    vs = []
+    for j in range(B):
+        r = rnd.randrange(1, o.R)
+        u = o.E1.mul(o.G1_GEN, r)
+        msg = bytes(rnd.randrange(256) for _ in range(1 + j % 40))
+        vs.append(o.xor_with_hash(o.E1.mul(pk, r), msg))
+        for k in range(n):
+            sh[j, k] = u8(o.g1_compressed(o.E1.mul(u, o.poly_evaluate(poly, int(idx[j, k]) + 1))))
+    sh[4, 2] = 0xFF
+    sh[6, 0] = u8(o.g1_compressed(non_member_g1(rnd)))
+    v, off = pack_messages(vs)
+    out, st = engine.decrypt_wire(t, idx, sh, v, off)
+    for j in range(B):
+        rc, want = c.decrypt_wire(t, [int(i) for i in idx[j]], [bytes(x) for x in sh[j]], vs[j])
+        assert rc == int(st[j]) and bytes(out[int(off[j]):int(off[j + 1])]) == want, j
+    assert int(st[4]) == 3 and int(st[6]) == 3 and st.sum() == 6
+
+
+def test_wire_combine_full_baseline_batch_vs_oracle(engine):
+    """BASELINE config 2 on the wire: 65 536 jobs x 4 compressed shares -> 65 536 compressed signatures, EVERY job against
+    Oracle B (from_bytes -> interpolate -> to_bytes on all host threads), with an undecodable share planted in every 4096th
+    job (+5) and a non-member in every 4096th (+9).  TC_TEST_BASELINE_JOBS shrinks it for local iterations."""
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    rnd = random.Random(7)
+    wl = ThresholdSigWorkload(engine, 3, 10, B_FULL)
+    B = B_FULL
+    comp, st = engine.g2_compress(np.ascontiguousarray(wl.shares.reshape(B * 4, 192)))
+    assert not st.any()
+    sh = comp.reshape(B, 4, 96).copy()
+    outsider = u8(o.g2_compressed(non_member_g2(rnd)))
+    sh[5::4096, 1] = 0xFF
+    sh[9::4096, 2] = outsider
+    out, st = engine.combine_signatures_wire(3, wl.idx, sh)
+    want, rc = c.combine_signatures_wire_batch(3, wl.idx, sh, c.host_threads())
+    assert (rc == st.astype(np.int32)).all() and (out == want).all()
+    bad = np.zeros(B, bool)
+    bad[5::4096] = True
+    bad[9::4096] = True
+    assert ((st == 3) == bad).all()
+
+
+# ---- `T: IntoFr` --------------------------------------------------------------------------------------------------------
+def fr_rows(ids):
+    return np.stack([np.stack([u8((i % o.R).to_bytes(32, "little")) for i in row]) for row in ids])
+
+
+def test_interpolate_with_into_fr_indices(engine, rnd):
+    """test_interpolate (src/lib.rs:793-808) for every degree 0..4, in BOTH groups, with the index types u64 cannot carry:
+    negative i32 / i64 values (-(|x|) mod r, src/into_fr.rs:28-56), field elements (src/into_fr.rs:10-14), 2^64 and above.
+    Each job interpolates (x - 1, comm.evaluate(x)) and must return comm.evaluate(0); Oracle A's interpolate -- which
+    takes any integer through into_fr_plus_1 -- recomputes every job.  A batch of plain small indices sent through the Fr
+    entry must equal the u64 entry's result (it runs the u64 kernels), and a non-canonical abscissa fails its job."""
+    for deg in range(5):
+        B = 6
+        poly = [rnd.randrange(o.R) for _ in range(deg + 1)]
+        rows = [[-(k + 2) for k in range(deg + 1)],                                     # negative integers
+                [rnd.randrange(o.R) for _ in range(deg + 1)],                           # field elements
+                [2 ** 64 + k for k in range(deg + 1)],                                  # beyond u64
+                [(-1) ** k * (3 * k + 1) for k in range(deg + 1)],                      # mixed signs
+                [o.R - 1 - 2 * k for k in range(deg + 1)],                              # r - 1: its interpolation point is 0 ...
+                [5 * k + 2 for k in range(deg + 1)]]                                    # ... and ordinary indices
+        idx_fr = fr_rows(rows)
+        for g2 in (False, True):
+            E, gen, enc = (o.E2, o.G2_GEN, o.g2_uncompressed) if g2 else (o.E1, o.G1_GEN, o.g1_uncompressed)
+            pts = [[E.mul(gen, o.poly_evaluate(poly, (i + 1) % o.R)) for i in row] for row in rows]
+            sh = np.stack([np.stack([u8(enc(p)) for p in row]) for row in pts])
+            out, st = (engine.combine_g2_fr if g2 else engine.combine_g1_fr)(deg, idx_fr, sh)
+            assert not st.any()
+            for j in range(B):
+                assert bytes(out[j]) == enc(E.mul(gen, poly[0])) == enc(o.interpolate(E, deg, list(zip(rows[j], pts[j])))), (deg, g2, j)
+            # the same small indices through the u64 entry
+            small = np.array([rows[5]] * 2, dtype=np.uint64)
+            o64, st64 = (engine.combine_g2 if g2 else engine.combine_g1)(deg, small, np.stack([sh[5]] * 2))
+            ofr, stfr = (engine.combine_g2_fr if g2 else engine.combine_g1_fr)(deg, fr_rows([rows[5]] * 2), np.stack([sh[5]] * 2))
+            assert not st64.any() and not stfr.any() and (o64 == ofr).all() and bytes(o64[0]) == bytes(out[5])
+        # a repeated abscissa is filtered BY VALUE from the denominator (src/lib.rs:757-762): whatever comes out equals the
+        # reference's construction, here Oracle A's
+        if deg >= 2:
+            dup = [[o.R - 5, 7, o.R - 5] + [100 + k for k in range(deg - 2)]]
+            pts = [[o.E1.mul(o.G1_GEN, o.poly_evaluate(poly, (i + 1) % o.R)) for i in dup[0]]]
+            outd, std = engine.combine_g1_fr(deg, fr_rows(dup), np.stack([np.stack([u8(o.g1_uncompressed(p)) for p in pts[0]])]))
+            assert not std.any() and bytes(outd[0]) == o.g1_uncompressed(o.interpolate(o.E1, deg, list(zip(dup[0], pts[0]))))
+        # a non-canonical abscissa (>= r) fails its own job only
+        bad = idx_fr.copy()
+        bad[1, 0] = 0xFF
+        out2, st2 = engine.combine_g1_fr(deg, bad, np.stack([np.stack([u8(o.g1_uncompressed(o.E1.mul(o.G1_GEN, o.poly_evaluate(poly, (i + 1) % o.R))))
+                                                                          for i in row]) for row in rows]))
+        assert int(st2[1]) == 3 and not st2[[0, 2, 3, 4, 5]].any()
+
+
+def test_api_mirror_takes_into_fr_keys(engine, rnd):
+    """PublicKeySet::combine_signatures / decrypt are generic over `T: IntoFr` (src/lib.rs:608-622): the host mirror takes
+    share maps keyed by negative integers and by Fr values, iterated in the key type's order like the reference's BTreeMap,
+    and returns the master key's signature / the plaintext; duplicate u64-range keys keep working."""
+    api.set_default_engine(engine)
+    t = 2
+    sk_set = api.SecretKeySet([rnd.randrange(o.R) for _ in range(t + 1)])
+    pk_set = sk_set.public_keys()
+    msg = b"IntoFr keys"
+    want = o.g2_uncompressed(o.sign(sk_set.poly[0], msg))
+    for keys in ([-5, -1, 7], [api.Fr(rnd.randrange(o.R)) for _ in range(3)], [2 ** 64, 3, -(2 ** 31)]):
+        shares = {k: sk_set.secret_key_share(k).sign(msg) for k in keys}
+        sig = pk_set.combine_signatures(shares)
+        assert sig.raw == want and pk_set.public_key().verify(sig, msg)
+    ct = pk_set.public_key().encrypt_with_r(rnd.randrange(1, o.R), b"secret")
+    for keys in ([-3, 4, 9], [api.Fr(12345), api.Fr(o.R - 7), api.Fr(6)]):
+        dshares = {k: sk_set.secret_key_share(k).decrypt_share_no_verify(ct) for k in keys}
+        assert pk_set.decrypt(dshares, ct) == b"secret"

@@ -780,6 +780,26 @@ def test_two_stage_msm_g1_short_scalar_mode(L, rnd):
     assert L.hs_msm_g1_nbits(n, enc, words([sc[0] + (1 << 32)] + sc[1:]), buf(96), 1, 32) == 3    # a 33-bit half
 
 
+def test_lagrange_from_fr_abscissae_matches_oracle(L, rnd):
+    """`T: IntoFr` beyond u64 (src/into_fr.rs:10-14, 28-56: Fr itself, negative i32 / i64 as -(|x|) mod r): the coefficients
+    k_lagrange_fr computes from 32-byte Fr abscissae equal the reference's construction (src/lib.rs:739-763) on into_fr(i) + 1
+    -- random field elements, negative integers, r - 1 (whose interpolation point is 0), a repeated abscissa (filtered by
+    value from the denominator, as at src/lib.rs:758), and plain small indices (same values as the u64 kernel)."""
+    cases = [[rnd.randrange(o.R) for _ in range(4)], [-1, -2, 5, 2 ** 64], [o.R - 1, 0, 1, 2], [3, 3, 9, 11], [0, 1, 2, 3],
+             [rnd.randrange(o.R) for _ in range(9)], [-(2 ** 63), 2 ** 63, 7]]
+    for ids in cases:
+        t = len(ids) - 1
+        xs = b"".join((i % o.R).to_bytes(32, "little") for i in ids)
+        want = o.lagrange_coeffs(t, [o.into_fr_plus_1(i) for i in ids])
+        for i in range(t + 1):
+            lam = buf(32)
+            assert L.hs_lagrange_fr(xs, t, i, lam) == 0 and int.from_bytes(lam.raw, "little") == want[i], (ids, i)
+        if all(0 <= i < 2 ** 64 for i in ids):
+            for i in range(t + 1):
+                lam = buf(32)
+                assert L.hs_lagrange((ctypes.c_uint64 * len(ids))(*ids), t, i, lam) == 0 and int.from_bytes(lam.raw, "little") == want[i]
+
+
 def test_lagrange_all_with_one_inversion_matches_oracle(L, rnd):
     """tc_threshold.h lagrange_all_at_zero == the reference's per-coefficient construction (src/lib.rs:739-763),
     including repeated indices (filtered by VALUE out of the denominator, :758) and u64 edge values."""

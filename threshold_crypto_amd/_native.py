@@ -37,6 +37,11 @@ PROTOTYPES = {
     "tc_g1_lincomb_batch": [_sz, _u8p, _u8p, _sz, _u8p, _u8p],
     "tc_g2_lincomb_batch": [_sz, _u8p, _u8p, _sz, _u8p, _u8p],
     "tc_decrypt_batch": [_sz, _sz, _u64p, _u8p, _u8p, _u64p, _sz, _u8p, _u8p],
+    "tc_combine_g2_fr_batch": [_sz, _sz, _u8p, _u8p, _sz, _u8p, _u8p],
+    "tc_combine_g1_fr_batch": [_sz, _sz, _u8p, _u8p, _sz, _u8p, _u8p],
+    "tc_decrypt_fr_batch": [_sz, _sz, _u8p, _u8p, _u8p, _u64p, _sz, _u8p, _u8p],
+    "tc_combine_signatures_wire_batch": [_sz, _sz, _u64p, _u8p, _sz, _u8p, _u8p],
+    "tc_decrypt_wire_batch": [_sz, _sz, _u64p, _u8p, _u8p, _u64p, _sz, _u8p, _u8p],
     "tc_xor_with_hash_batch": [_u8p, _u8p, _u64p, _sz, _u8p, _u8p],
     "tc_pairing_check_batch": [_u8p, _sz, _u8p, _sz, _u8p, _sz, _u8p, _sz, _sz, _u8p],
     "tc_verify_g2_batch": [_u8p, _sz, _u8p, _u8p, _sz, _u8p],

@@ -78,8 +78,50 @@ def _raise_status(st):
 
 
 def into_fr_plus_1(i):
-    """src/lib.rs:769-773 for the u64/usize IntoFr impls (src/into_fr.rs:16-26)."""
-    return (int(i) + 1) % _R
+    """src/lib.rs:769-773 for every IntoFr impl (src/into_fr.rs:10-56)."""
+    return ((i.v if isinstance(i, Fr) else int(i)) + 1) % _R
+
+
+class Fr:
+    """A scalar-field element as an index type: `impl IntoFr for Fr` (src/into_fr.rs:10-14).  Ordered by its canonical value,
+    like the derived Ord of pairing's Fr, so a dict keyed by Fr iterates as the reference's BTreeMap does."""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = int(v) % _R
+
+    def __int__(self):
+        return self.v
+
+    def __eq__(self, o):
+        return isinstance(o, Fr) and o.v == self.v
+
+    def __lt__(self, o):
+        return self.v < o.v
+
+    def __hash__(self):
+        return hash(("Fr", self.v))
+
+    def __repr__(self):
+        return "Fr(%#x)" % self.v
+
+
+def into_fr(i):
+    """IntoFr (src/into_fr.rs:10-56): Fr by value, u64 / usize by value, negative i32 / i64 as -(|x|) mod r."""
+    return i.v if isinstance(i, Fr) else int(i) % _R
+
+
+def _index_arrays(ordered, n):
+    """(u64 array, None) when every index is a plain integer in [0, 2^64) -- the u64 entries --, else (None, (B, n, 32) Fr
+    bytes) for the `T: IntoFr` entries (Fr keys, negative integers)."""
+    flat = [i for o in ordered for i, _ in o]
+    if all(not isinstance(i, Fr) and 0 <= int(i) < 2 ** 64 for i in flat):
+        return np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(ordered), n), None
+    fr = np.zeros((len(ordered), n, 32), dtype=np.uint8)
+    for j, o in enumerate(ordered):
+        for k, (i, _) in enumerate(o):
+            fr[j, k] = np.frombuffer(into_fr(i).to_bytes(32, "little"), dtype=np.uint8)
+    return None, fr
 
 
 def _require_members(engine, g2, rows):
@@ -441,13 +483,33 @@ class PublicKeySet:
         n = len(ordered[0])
         if any(len(o) != n for o in ordered):
             raise ValueError("all jobs of one batch must supply the same number of shares")
-        idx = np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(jobs), n)
+        idx, idx_fr = _index_arrays(ordered, n)
         sh = np.empty((len(jobs), max(n, 1), 192), dtype=np.uint8)
         for j, o in enumerate(ordered):
             for k, (_, s) in enumerate(o):
                 sh[j, k] = np.frombuffer(s.raw, dtype=np.uint8)
-        out, st = e.combine_g2(t, idx, sh[:, :n].copy() if n else sh[:, :0].copy())
+        sh = sh[:, :n].copy() if n else sh[:, :0].copy()
+        # `T: IntoFr` (src/lib.rs:608-611): u64-range integers take the u64 entry, Fr keys / negative integers the Fr entry
+        out, st = e.combine_g2(t, idx, sh) if idx_fr is None else e.combine_g2_fr(t, idx_fr, sh)
         return [Signature(out[j], _trusted=True) for j in range(len(jobs))], st
+
+    def combine_signatures_wire_batch(self, jobs, engine=None):
+        """The same on the wire forms: jobs hold (index, 96-byte SignatureShare::to_bytes) pairs; the shares pass the checked
+        decode of from_bytes (src/lib.rs:246-252) on the device and the result comes back as Signature::to_bytes
+        (src/lib.rs:255-259).  Returns ([bytes], status[])."""
+        e = engine or default_engine()
+        t = self.threshold()
+        ordered = [_ordered(j) for j in jobs]
+        n = len(ordered[0])
+        if any(len(o) != n for o in ordered):
+            raise ValueError("all jobs of one batch must supply the same number of shares")
+        idx = np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(jobs), n)
+        sh = np.zeros((len(jobs), n, 96), dtype=np.uint8)
+        for j, o in enumerate(ordered):
+            for k, (_, s) in enumerate(o):
+                sh[j, k] = np.frombuffer(bytes(s), dtype=np.uint8)
+        out, st = e.combine_signatures_wire(t, idx, sh)
+        return [bytes(out[j]) for j in range(len(jobs))], st
 
     def decrypt(self, shares, ct):
         """PublicKeySet::decrypt (src/lib.rs:618-626)."""
@@ -464,13 +526,13 @@ class PublicKeySet:
         n = len(ordered[0])
         if any(len(o) != n for o in ordered):
             raise ValueError("all jobs of one batch must supply the same number of shares")
-        idx = np.array([[int(i) for i, _ in o] for o in ordered], dtype=np.uint64).reshape(len(jobs), n)
+        idx, idx_fr = _index_arrays(ordered, n)
         sh = np.empty((len(jobs), n, 96), dtype=np.uint8)
         for j, o in enumerate(ordered):
             for k, (_, s) in enumerate(o):
                 sh[j, k] = np.frombuffer(s.raw, dtype=np.uint8)
         v, off = pack_messages([c.v for c in cts])
-        out, st = e.decrypt(t, idx, sh, v, off)
+        out, st = e.decrypt(t, idx, sh, v, off) if idx_fr is None else e.decrypt_fr(t, idx_fr, sh, v, off)
         res = [bytes(out[int(off[j]): int(off[j + 1])]) for j in range(len(jobs))]
         return res, st
 

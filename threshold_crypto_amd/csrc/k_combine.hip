@@ -23,6 +23,40 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange(const uint64_t
   if (st && status) status[j] = st;
 }
 
+// `T: IntoFr` abscissae as 32-byte Fr values (tc_combine_g{1,2}_fr_batch).  k_fr_idx_narrow: the value as a u64 where it fits
+// (so that a batch of ordinary indices that merely ARRIVED as Fr takes the u64 kernels, fast path included), a count of
+// the ones that do not, and valid[j] = 0 for a job that owns a non-canonical one (>= r) among the first t+1.
+__global__ void k_fr_idx_narrow(const uint32_t* __restrict__ idx_fr, size_t n_per_job, size_t take, size_t B, uint64_t* __restrict__ idx64,
+                                uint32_t* __restrict__ wide, uint8_t* __restrict__ valid) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < B * n_per_job;
+  bool is_wide = false;
+  if (live) {
+    const uint32_t* w = idx_fr + i * 8;
+    const bool used = (i % n_per_job) < take;                      // only the first t+1 samples matter (src/lib.rs:727-730)
+    is_wide = used && (w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) != 0;
+    idx64[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    if (used && !limbs_lt_p<FrParams>(w)) valid[i / n_per_job] = 0;
+  }
+  const uint64_t m = __builtin_amdgcn_ballot_w64(is_wide);
+  if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(wide, (uint32_t)__builtin_popcountll(m));
+}
+// one lane per (job, sample position), every job (no fast path: the abscissae are arbitrary field elements)
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_lagrange_fr(const uint32_t* __restrict__ idx_fr, size_t n_per_job, size_t t, size_t B,
+                                                                  uint32_t* __restrict__ lam, uint8_t* __restrict__ status) {
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t k = t + 1;
+  if (tid >= B * k) return;
+  const size_t j = tid / k, i = tid % k;
+  Fr l;
+  if (status[j] != TC_JOB_OK || !lagrange_coeff_at_zero_fr(idx_fr + j * n_per_job * 8, (int)t, (int)i, l)) {
+    for (int w = 0; w < 8; w++) lam[tid * 8 + w] = 0;
+    if (status[j] == TC_JOB_OK) status[j] = TC_JOB_DUPLICATE_ENTRY;
+    return;
+  }
+  l.to_canonical(lam + tid * 8);
+}
+
 // Large thresholds (no job takes the small-index fast path): all t+1 coefficients of a job with ONE inversion
 // (tc_threshold.h), in two kernels.
 //   k_lagrange_den     one lane per (job, i): the O(t^2) part.  A 256-lane workgroup takes floor(256 / (t+1)) jobs; the
@@ -173,7 +207,8 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   uint32_t tslot = 0;
   if (L > 1) tslot = table_slot_acquire(ta);
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
-  const bool mine = j < B && !(t >= 1 && t <= 3 && combine_small_applies(idx + j * n_per_job, (int)t));  // else: k_combine_fast's
+  // idx == nullptr: every job is this kernel's (coefficients from Fr abscissae: no fast path ran)
+  const bool mine = j < B && !(idx && t >= 1 && t <= 3 && combine_small_applies(idx + j * n_per_job, (int)t));  // else: k_combine_fast's
   if (mine) {
     if (status && status[j] != TC_JOB_OK) {  // lagrange stage flagged the job
       PointIO<F>::encode(Affine<F>::infinity(), out + j * PB);
@@ -216,6 +251,13 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
   const size_t n = B * (t + 1);
   if (n) hipLaunchKernelGGL(k_lagrange, dim3(grid_for(n)), dim3(kBlock), 0, st, idx, n_per_job, t, B, lam, status, need_general);
 }
+void launch_fr_idx_narrow(hipStream_t st, const uint32_t* idx_fr, size_t n_per_job, size_t take, size_t B, uint64_t* idx64, uint32_t* wide,
+                          uint8_t* valid) {
+  if (B * n_per_job) hipLaunchKernelGGL(k_fr_idx_narrow, dim3(grid_for(B * n_per_job)), dim3(kBlock), 0, st, idx_fr, n_per_job, take, B, idx64, wide, valid);
+}
+void launch_lagrange_fr(hipStream_t st, const uint32_t* idx_fr, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint8_t* status) {
+  if (B) hipLaunchKernelGGL(k_lagrange_fr, dim3(grid_for(B * (t + 1))), dim3(kBlock), 0, st, idx_fr, n_per_job, t, B, lam, status);
+}
 size_t lagrange_all_ws_words(size_t t, size_t B) { return B * 4 * (t + 1) * 8; }
 void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
                          uint8_t* status) {
@@ -238,7 +280,7 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general) {
   if (!B) return;
-  if (t >= 1 && t <= 3)
+  if (idx && t >= 1 && t <= 3)
     hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});
   hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, TableArena{nullptr, nullptr});
 }

@@ -80,6 +80,26 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
+// Wire ingest for the combiners (tc_combine_signatures_wire_batch / tc_decrypt_wire_batch): the FIRST `take` of the n_per_job
+// compressed samples of every job -- exactly the samples interpolate() uses (/root/reference/src/lib.rs:727-730) -- through the
+// CHECKED decode of from_bytes (:140-146, 246-252), written compactly (job-major, take per job); valid[i] = 1 iff sample i
+// decoded and is a member.  check = false leaves the membership test to the caller's batched test (k_check.hip).
+template <class F>
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_decompress_take(
+    const uint8_t* __restrict__ in, size_t n_per_job, size_t take, size_t n, uint8_t* __restrict__ out, uint8_t* __restrict__ valid) {
+  constexpr int L = JobLanes<F>::N;
+  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) / L;
+  if (i >= n) return;
+  const size_t rec = i / take, k = i % take;
+  const uint8_t st = job_decompress<F>(in + (rec * n_per_job + k) * PointIO<F>::CBYTES, out + i * PointIO<F>::BYTES);
+  if (L == 1 || pair_leader()) valid[i] = st == TC_JOB_OK ? 1 : 0;
+}
+// the matching prefix of the index array: out[j * take + k] = idx[j * n_per_job + k]
+__global__ void k_take_u64(const uint64_t* __restrict__ in, size_t n_per_job, size_t take, size_t n, uint64_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = in[(i / take) * n_per_job + i % take];
+}
+
 // scalars / G1 points folded with the hash's constant FR_COFACTOR_FIX (tc_jobs.h)
 __global__ void k_fr_scale_cofactor_fix(const uint8_t* __restrict__ fr, size_t S, uint8_t* __restrict__ out) {
   const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -130,6 +150,15 @@ void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* 
 }
 void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
+}
+void launch_decompress_take(hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid) {
+  const size_t n = B * take;
+  if (!n) return;
+  if (g2) hipLaunchKernelGGL(k_decompress_take<Fq2>, dim3(grid_for(n * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
+  else hipLaunchKernelGGL(k_decompress_take<Fq>, dim3(grid_for(n)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
+}
+void launch_take_u64(hipStream_t st, const uint64_t* in, size_t n_per_job, size_t take, size_t B, uint64_t* out) {
+  if (B * take) hipLaunchKernelGGL(k_take_u64, dim3(grid_for(B * take)), dim3(kBlock), 0, st, in, n_per_job, take, B * take, out);
 }
 void launch_fr_scale_cofactor_fix(hipStream_t st, const uint8_t* fr, size_t S, uint8_t* out) {
   if (S) hipLaunchKernelGGL(k_fr_scale_cofactor_fix, dim3(grid_for(S)), dim3(kBlock), 0, st, fr, S, out);

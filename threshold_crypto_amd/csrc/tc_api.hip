@@ -522,45 +522,93 @@ int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uin
 }
 
 // ---- combination -----------------------------------------------------------------------------
-static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx, const uint8_t* shares, size_t B,
-                   uint8_t* out, uint8_t* status, const uint8_t* v, const uint64_t* off, uint8_t* plain) {
+// The launches of one combination over device-resident operands: Lagrange stage + the group's kernels.  d_idx: B x n u64
+// abscissae (IntoFr for u64); d_idx_fr != nullptr: B x n Fr abscissae (8 canonical words each) instead -- every job takes
+// the general path then, coefficients from k_lagrange_fr.  d_st: B zeroed status bytes (or already flagged jobs).
+static void combine_launch(Call& k, bool g2, size_t t, size_t n, const uint64_t* d_idx, const uint32_t* d_idx_fr, const uint8_t* d_sh, size_t B,
+                           uint8_t* d_pt, uint8_t* d_st) {
+  tc_ctx* ctx = k.c;
+  const size_t PB = g2 ? 192 : 96;
+  uint32_t* d_lam = k.temp<uint32_t>(B * (t + 1) * 8);
+  // G2, t <= 3: jobs are grouped by the class of their Lagrange denominator so that whole waves take
+  // the cheap forms of the final division (tc_jobs.h combine_divide); not worth three launches for a
+  // batch that fills a fraction of the machine anyway
+  const bool group = g2 && !d_idx_fr && t >= 1 && t <= 3 && B >= 4096;
+  uint8_t* d_cls = group ? k.temp<uint8_t>(B) : nullptr;
+  uint32_t* d_counters = group ? k.temp<uint32_t>(8) : nullptr;
+  uint32_t* d_perm = group ? k.temp<uint32_t>(tc::combine_group_slots(B)) : nullptr;
+  uint32_t* d_need = (t > 0 && !d_idx_fr) ? k.temp<uint32_t>(1, /*zero=*/true) : nullptr;
+  if (k.failed) return;
+  if (d_idx_fr) {
+    // `T: IntoFr` abscissae beyond u64 (src/into_fr.rs:10-14, 28-56): no small-index fast path, no integer differences
+    if (t > 0) tc::launch_lagrange_fr(ctx->stream, d_idx_fr, n, t, B, d_lam, d_st);
+    if (g2 && t >= 1) msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);
+    else if (g2) tc::launch_combine_g2(ctx->stream, k.tables(), t, n, nullptr, d_sh, d_lam, B, d_pt, d_st, nullptr, nullptr, nullptr, nullptr);
+    else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);
+    else tc::launch_combine_g1(ctx->stream, t, n, nullptr, d_sh, d_lam, B, d_pt, d_st, nullptr);
+    return;
+  }
+  if (t + 1 >= tc::kMsmMinPoints) {
+    uint32_t* d_ws = k.temp<uint32_t>(tc::lagrange_all_ws_words(t, B));
+    if (!k.failed) tc::launch_lagrange_all(ctx->stream, d_idx, n, t, B, d_lam, d_ws, d_st);
+  } else if (t > 0) {
+    tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
+  }
+  if (g2 && t + 1 >= tc::kMsmMinPoints) {
+    msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds: every job, coefficients from the one-inversion kernels
+  } else if (g2) {
+    // t <= 3: small-index fast path first; then (t >= 1) the jobs it left, through the two-stage kernels
+    tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+    if (t >= 1) {
+      tc::MsmFilter f;
+      f.need = d_need;
+      f.idx = d_idx;
+      f.n_per_job = n;
+      f.t = t;
+      msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st, 64, f);
+    }
+  }
+  else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds in G1: the same two stages
+  else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need);
+}
+
+// samples.len() <= t  =>  Err(NotEnoughShares) for every job        (src/lib.rs:731-733)
+static int not_enough_shares(Call& k, size_t B, uint8_t* out, size_t out_bytes, uint8_t* status) {
+  if (k.c->device_io) {
+    k.check(hipMemsetAsync(status, TC_JOB_NOT_ENOUGH_SHARES, B, k.c->stream), "memset");
+    if (out && out_bytes) k.check(hipMemsetAsync(out, 0, B * out_bytes, k.c->stream), "memset");
+  } else {
+    memset(status, TC_JOB_NOT_ENOUGH_SHARES, B);
+    if (out && out_bytes) memset(out, 0, B * out_bytes);
+  }
+  return k.finish();
+}
+
+// idx_fr != nullptr: the abscissae as 32-byte Fr values (idx unused); wire: the shares arrive compressed (48 / 96 B, checked
+// decode) and a G2 result leaves compressed
+static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx, const uint8_t* idx_fr, const uint8_t* shares, size_t B,
+                   uint8_t* out, uint8_t* status, const uint8_t* v, const uint64_t* off, uint8_t* plain, bool wire = false) {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && out && status);
   TC_REQUIRE(t < (1u << 20));
-  const size_t PB = g2 ? 192 : 96;
+  const size_t PB = g2 ? 192 : 96, CB = PB / 2;
+  const size_t OB = plain ? 0 : (wire ? CB : PB);  // bytes of a point result
   Call k(ctx);
-  if (n <= t) {
-    // samples.len() <= t  =>  Err(NotEnoughShares) for every job        (src/lib.rs:731-733)
-    if (ctx->device_io) {
-      k.check(hipMemsetAsync(status, TC_JOB_NOT_ENOUGH_SHARES, B, ctx->stream), "memset");
-      k.check(hipMemsetAsync(out, 0, B * PB, ctx->stream), "memset");
-    } else {
-      memset(status, TC_JOB_NOT_ENOUGH_SHARES, B);
-      memset(out, 0, B * PB);
-    }
-    return k.finish();
-  }
-  TC_REQUIRE(idx && shares);
+  if (n <= t) return not_enough_shares(k, B, plain ? nullptr : out, OB, status);
+  TC_REQUIRE((idx || idx_fr) && shares);
   uint64_t total = 0;
   if (plain) {
     TC_REQUIRE(off);
     if (!total_bytes(k, off, B, &total)) return k.finish();
     TC_REQUIRE(total == 0 || v);
   }
-  const uint64_t* d_idx = k.in(idx, B * n);
-  const uint8_t* d_sh = k.in(shares, B * n * PB);
-  uint32_t* d_lam = k.temp<uint32_t>(B * (t + 1) * 8);
+  const uint64_t* d_idx = idx_fr ? nullptr : k.in(idx, B * n);
+  const uint32_t* d_idx_fr = idx_fr ? reinterpret_cast<const uint32_t*>(k.in(idx_fr, B * n * 32)) : nullptr;
+  const uint8_t* d_sh = k.in(shares, B * n * (wire ? CB : PB));
   uint8_t* d_st = k.out(status, B, /*zero=*/true);
-  uint8_t* d_pt = plain ? k.temp<uint8_t>(B * PB) : k.out(out, B * PB);
-  // G2, t <= 3: jobs are grouped by the class of their Lagrange denominator so that whole waves take
-  // the cheap forms of the final division (tc_jobs.h combine_divide); not worth three launches for a
-  // batch that fills a fraction of the machine anyway
-  const bool group = g2 && t >= 1 && t <= 3 && B >= 4096;
-  uint8_t* d_cls = group ? k.temp<uint8_t>(B) : nullptr;
-  uint32_t* d_counters = group ? k.temp<uint32_t>(8) : nullptr;
-  uint32_t* d_perm = group ? k.temp<uint32_t>(tc::combine_group_slots(B)) : nullptr;
-  uint32_t* d_need = t > 0 ? k.temp<uint32_t>(1, /*zero=*/true) : nullptr;
+  uint8_t* d_pt = (plain || wire) ? k.temp<uint8_t>(B * PB) : k.out(out, B * PB);
+  uint8_t* d_wire_out = (wire && !plain) ? k.out(out, B * CB) : nullptr;
   const uint8_t* d_v = nullptr;
   const uint64_t* d_off = nullptr;
   uint8_t* d_plain = nullptr;
@@ -570,32 +618,56 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
     d_plain = k.out(plain, (size_t)total, /*zero=*/true);  // failed jobs leave zeros, never stale staging bytes
   }
   k.begin_timing();
-  k.check_points(g2, d_sh, PB, n, t + 1, B, 1);  // exactly the first t+1 samples interpolate() takes
-  if (!k.failed) {
-    if (t + 1 >= tc::kMsmMinPoints) {
-      uint32_t* d_ws = k.temp<uint32_t>(tc::lagrange_all_ws_words(t, B));
-      if (!k.failed) tc::launch_lagrange_all(ctx->stream, d_idx, n, t, B, d_lam, d_ws, d_st);
-    } else if (t > 0) {
-      tc::launch_lagrange(ctx->stream, d_idx, n, t, B, d_lam, d_st, d_need);
-    }
-    if (g2 && t + 1 >= tc::kMsmMinPoints) {
-      msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds: every job, coefficients from the one-inversion kernels
-    } else if (g2) {
-      // t <= 3: small-index fast path first; then (t >= 1) the jobs it left, through the two-stage kernels
-      tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
-      if (t >= 1) {
-        tc::MsmFilter f;
-        f.need = d_need;
-        f.idx = d_idx;
-        f.n_per_job = n;
-        f.t = t;
-        msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st, 64, f);
+  size_t n_eff = n;
+  if (idx_fr && !k.failed) {
+    // abscissae that merely ARRIVED as Fr but fit 64 bits take the u64 kernels (fast path included); one word comes back
+    uint64_t* d_idx64 = k.temp<uint64_t>(B * n);
+    uint32_t* d_wide = k.temp<uint32_t>(1, /*zero=*/true);
+    uint8_t* d_canon = k.temp<uint8_t>(B);
+    if (!k.failed) {
+      k.check(hipMemsetAsync(d_canon, 1, B, ctx->stream), "memset");
+      tc::launch_fr_idx_narrow(ctx->stream, d_idx_fr, n, t + 1, B, d_idx64, d_wide, d_canon);
+      uint32_t wide = 0;
+      k.check(hipMemcpyAsync(&wide, d_wide, 4, hipMemcpyDeviceToHost, ctx->stream), "readback");
+      ctx->d2h_bytes += 4;
+      k.check(hipStreamSynchronize(ctx->stream), "stream sync");
+      k.checks.push_back({d_canon, 1, 1});  // a job that owns a non-canonical abscissa (>= r) fails like an undecodable operand
+      if (wide == 0) {
+        d_idx = d_idx64;
+        d_idx_fr = nullptr;
       }
     }
-    else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds in G1: the same two stages
-    else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need);
+  }
+  if (wire && !k.failed) {
+    // the first t+1 samples of every job through the checked decode of from_bytes (src/lib.rs:140-146, 246-252), compactly
+    uint8_t* d_dec = k.temp<uint8_t>(B * (t + 1) * PB);
+    uint8_t* d_valid = k.temp<uint8_t>(B * (t + 1));
+    if (!k.failed) {
+      tc::launch_decompress_take(ctx->stream, g2, d_sh, n, t + 1, B, d_dec, d_valid);
+      k.checks.push_back({d_valid, t + 1, 1});
+      if (d_idx_fr) {
+        uint32_t* d_fr2 = k.temp<uint32_t>(B * (t + 1) * 8);
+        if (d_fr2) tc::launch_take_u64(ctx->stream, reinterpret_cast<const uint64_t*>(d_idx_fr), n * 4, (t + 1) * 4, B, reinterpret_cast<uint64_t*>(d_fr2));
+        d_idx_fr = d_fr2;
+      } else {
+        uint64_t* d_idx2 = k.temp<uint64_t>(B * (t + 1));
+        if (d_idx2) tc::launch_take_u64(ctx->stream, d_idx, n, t + 1, B, d_idx2);
+        d_idx = d_idx2;
+      }
+      d_sh = d_dec;
+      n_eff = t + 1;
+    }
+  } else {
+    k.check_points(g2, d_sh, PB, n, t + 1, B, 1);  // exactly the first t+1 samples interpolate() takes
+  }
+  if (!k.failed) {
+    combine_launch(k, g2, t, n_eff, d_idx, d_idx_fr, d_sh, B, d_pt, d_st);
     k.apply_checks(B, d_st, d_pt, PB, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);
+    else if (wire) {
+      if (g2) tc::launch_g2_compress(ctx->stream, d_pt, B, d_wire_out, nullptr);   // Signature::to_bytes src/lib.rs:255-259
+      else tc::launch_g1_compress(ctx->stream, d_pt, B, d_wire_out, nullptr);
+    }
   }
   k.end_timing();
   return k.finish();
@@ -603,25 +675,45 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
 
 int tc_combine_g2_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                         size_t B, uint8_t* out, uint8_t* status) {
-  return combine(ctx, true, t, n_per_job, idx, shares, B, out, status, nullptr, nullptr, nullptr);
+  return combine(ctx, true, t, n_per_job, idx, nullptr, shares, B, out, status, nullptr, nullptr, nullptr);
 }
 
 int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                         size_t B, uint8_t* out, uint8_t* status) {
-  return combine(ctx, false, t, n_per_job, idx, shares, B, out, status, nullptr, nullptr, nullptr);
+  return combine(ctx, false, t, n_per_job, idx, nullptr, shares, B, out, status, nullptr, nullptr, nullptr);
 }
 
 int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
                      const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
   TC_REQUIRE(ctx && out && status && off);
-  if (n_per_job <= t) {
-    if (B == 0) return TC_OK;
-    Call k(ctx);
-    if (ctx->device_io) k.check(hipMemsetAsync(status, TC_JOB_NOT_ENOUGH_SHARES, B, ctx->stream), "memset");
-    else memset(status, TC_JOB_NOT_ENOUGH_SHARES, B);
-    return k.finish();
-  }
-  return combine(ctx, false, t, n_per_job, idx, shares_g1, B, out /*non-null marker*/, status, v, off, out);
+  return combine(ctx, false, t, n_per_job, idx, nullptr, shares_g1, B, out /*non-null marker*/, status, v, off, out);
+}
+
+// `T: IntoFr` beyond u64 (src/into_fr.rs:10-14, 28-56; combine_signatures / decrypt are generic over it, src/lib.rs:608-622)
+int tc_combine_g2_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares, size_t B, uint8_t* out,
+                           uint8_t* status) {
+  return combine(ctx, true, t, n_per_job, nullptr, idx_fr, shares, B, out, status, nullptr, nullptr, nullptr);
+}
+int tc_combine_g1_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares, size_t B, uint8_t* out,
+                           uint8_t* status) {
+  return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares, B, out, status, nullptr, nullptr, nullptr);
+}
+int tc_decrypt_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares_g1, const uint8_t* v,
+                        const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
+  TC_REQUIRE(ctx && out && status && off);
+  return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares_g1, B, out, status, v, off, out);
+}
+
+// wire-level forms: shares as they travel (Signature::to_bytes / DecryptionShare's compressed G1, checked decode of
+// from_bytes src/lib.rs:140-146, 246-252), the combined signature back as Signature::to_bytes (src/lib.rs:255-259)
+int tc_combine_signatures_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares96, size_t B,
+                                     uint8_t* out96, uint8_t* status) {
+  return combine(ctx, true, t, n_per_job, idx, nullptr, shares96, B, out96, status, nullptr, nullptr, nullptr, /*wire=*/true);
+}
+int tc_decrypt_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares48, const uint8_t* v,
+                          const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
+  TC_REQUIRE(ctx && out && status && off);
+  return combine(ctx, false, t, n_per_job, idx, nullptr, shares48, B, out, status, v, off, out, /*wire=*/true);
 }
 
 static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,

@@ -49,6 +49,10 @@ void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* ou
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
+// wire ingest of the combiners: the first `take` of n_per_job compressed samples per job, checked decode, compact output
+// (B x take points) + one validity byte per sample; and the matching prefix of the index array
+void launch_decompress_take(hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid);
+void launch_take_u64(hipStream_t st, const uint64_t* in, size_t n_per_job, size_t take, size_t B, uint64_t* out);
 
 // need_general: one zeroed device word; the Lagrange stage counts the jobs the small-index fast path
 // does not take, the general combine kernel leaves at once when it stays zero (k_combine.hip)
@@ -60,6 +64,13 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
                          uint8_t* status);
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general);
+// `T: IntoFr` abscissae beyond u64 (tc_combine_g{1,2}_fr_batch): idx_fr = B x n_per_job x 8 canonical LE words.
+//   launch_fr_idx_narrow   idx64[i] = the value when it fits 64 bits; *wide counts the ones that do not; valid[j] (preset
+//                          to 1) is cleared for a job that owns a non-canonical encoding (>= r) among its first `take`
+//   launch_lagrange_fr     lambda_i of every job from the Fr abscissae x = idx_fr + 1 (one lane per coefficient)
+void launch_fr_idx_narrow(hipStream_t st, const uint32_t* idx_fr, size_t n_per_job, size_t take, size_t B, uint64_t* idx64, uint32_t* wide,
+                          uint8_t* valid);
+void launch_lagrange_fr(hipStream_t st, const uint32_t* idx_fr, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint8_t* status);
 size_t combine_group_slots(size_t B);
 void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,

@@ -26,6 +26,24 @@ TC_HD bool lagrange_coeff_at_zero(const uint64_t* idx, int t, int i, Fr& out) {
   return true;
 }
 
+// The same coefficient for abscissae given as Fr values (`T: IntoFr` = Fr, negative i32 / i64: /root/reference/src/into_fr.rs:10-14,
+// 28-56): xs = (t+1) x 8 canonical LE words, x_j = xs_j + 1.  Identical construction -- numerator by POSITION, denominator
+// filtered by VALUE -- so repeated abscissae behave as in the reference.
+TC_HD bool lagrange_coeff_at_zero_fr(const uint32_t* xs, int t, int i, Fr& out) {
+  const Fr one = Fr::one();
+  const Fr xi = Fr::from_canonical(xs + 8 * i) + one;
+  Fr num = one;
+  Fr den = one;
+  TC_NOUNROLL for (int j = 0; j <= t; j++) {
+    const Fr xj = Fr::from_canonical(xs + 8 * j) + one;
+    if (j != i) num = num * xj;
+    if (xj != xi) den = den * (xj - xi);
+  }
+  if (den.is_zero()) return false;
+  out = num * den.inv();
+  return true;
+}
+
 // All t+1 coefficients of one job with ONE field inversion (Montgomery's trick) instead of one Fermat power
 // per coefficient -- what the reference does at src/lib.rs:763 costs ~320 Fr multiplications each, more than
 // the t multiplications of the denominator itself; at t = 67 the per-coefficient kernel was 15 % of the whole

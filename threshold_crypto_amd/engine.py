@@ -234,6 +234,35 @@ class Engine:
     def combine_g1(self, t, idx, shares):
         return self._combine("tc_combine_g1_batch", G1_BYTES, t, idx, shares)
 
+    def _combine_fr(self, name, pb, t, idx_fr, shares):
+        """`T: IntoFr` abscissae as (B, n, 32) little-endian Fr values (src/into_fr.rs)"""
+        dev = self._mode(idx_fr, shares)
+        self._arg(idx_fr, (None, None, FR_BYTES), "u8", "idx_fr")
+        B, n = idx_fr.shape[0], idx_fr.shape[1]
+        self._arg(shares, (B, n, pb), "u8", "shares")
+        out = self._empty(dev, (B, pb), ref=shares)
+        st = self._empty(dev, (B,), ref=shares)
+        self._call(name, int(t), int(n), _ptr(idx_fr), _ptr(shares), B, _ptr(out), _ptr(st))
+        return out, st
+
+    def combine_g2_fr(self, t, idx_fr, shares):
+        return self._combine_fr("tc_combine_g2_fr_batch", G2_BYTES, t, idx_fr, shares)
+
+    def combine_g1_fr(self, t, idx_fr, shares):
+        return self._combine_fr("tc_combine_g1_fr_batch", G1_BYTES, t, idx_fr, shares)
+
+    def combine_signatures_wire(self, t, idx, shares96):
+        """PublicKeySet::combine_signatures on the wire forms: (B, n, 96) compressed shares in (checked decode of from_bytes on
+        the device), (B, 96) Signature::to_bytes out"""
+        dev = self._mode(idx, shares96)
+        self._arg(idx, (None, None), "u64", "idx")
+        B, n = idx.shape
+        self._arg(shares96, (B, n, G2_BYTES // 2), "u8", "shares96")
+        out = self._empty(dev, (B, G2_BYTES // 2), ref=shares96)
+        st = self._empty(dev, (B,), ref=shares96)
+        self._call("tc_combine_signatures_wire_batch", int(t), int(n), _ptr(idx), _ptr(shares96), B, _ptr(out), _ptr(st))
+        return out, st
+
     def _lincomb(self, name, pb, scalars, points):
         dev = self._mode(scalars, points)
         self._arg(scalars, (None, None, FR_BYTES), "u8", "scalars")
@@ -261,6 +290,29 @@ class Engine:
         st = self._empty(dev, (B,), ref=v)
         self._call("tc_decrypt_batch", int(t), int(n), _ptr(idx), _ptr(shares_g1), _ptr(v), _ptr(off), B,
                    _ptr(out), _ptr(st))
+        return out, st
+
+    def decrypt_fr(self, t, idx_fr, shares_g1, v, off):
+        dev = self._mode(idx_fr, shares_g1, v, off)
+        self._arg(idx_fr, (None, None, FR_BYTES), "u8", "idx_fr")
+        B, n = idx_fr.shape[0], idx_fr.shape[1]
+        self._arg(shares_g1, (B, n, G1_BYTES), "u8", "shares")
+        self._msgs(v, off, B)
+        out = self._empty(dev, tuple(v.shape), ref=v)
+        st = self._empty(dev, (B,), ref=v)
+        self._call("tc_decrypt_fr_batch", int(t), int(n), _ptr(idx_fr), _ptr(shares_g1), _ptr(v), _ptr(off), B, _ptr(out), _ptr(st))
+        return out, st
+
+    def decrypt_wire(self, t, idx, shares48, v, off):
+        """PublicKeySet::decrypt with the decryption shares in their 48-byte compressed form (checked decode on the device)"""
+        dev = self._mode(idx, shares48, v, off)
+        self._arg(idx, (None, None), "u64", "idx")
+        B, n = idx.shape
+        self._arg(shares48, (B, n, G1_BYTES // 2), "u8", "shares48")
+        self._msgs(v, off, B)
+        out = self._empty(dev, tuple(v.shape), ref=v)
+        st = self._empty(dev, (B,), ref=v)
+        self._call("tc_decrypt_wire_batch", int(t), int(n), _ptr(idx), _ptr(shares48), _ptr(v), _ptr(off), B, _ptr(out), _ptr(st))
         return out, st
 
     def xor_with_hash(self, g1, data, off):
