@@ -78,6 +78,11 @@ TC_HD void sha3_256_words(const uint8_t* data, size_t len, uint32_t* out_words) 
   }
 }
 
+// The same as a REAL function over a generic pointer: hash_g1_g2 hashes a per-lane byte buffer (message or its digest, then the
+// compressed G1 point at a data-dependent offset); inlined into that kernel the 136 predicated byte loads of the private
+// array -- each with its own uniform address arithmetic -- cost 6 626 spilled SGPRs and 227 VGPRs (r03 code object).
+TC_HD_NOINLINE void sha3_256_words_call(const uint8_t* data, size_t len, uint32_t* out_words) { sha3_256_words(data, len, out_words); }
+
 // ---------------------------------------------------------------------------------------
 // ChaCha20 (djb layout: 64-bit block counter, 64-bit stream id = 0) as a u32 word stream
 // == rand_chacha 0.2.2 ChaChaRng::from_seed(key).next_u32()/next_u64()

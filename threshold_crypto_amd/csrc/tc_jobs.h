@@ -447,6 +447,12 @@ TC_HD G2Jac hash_g2_point(const uint8_t* msg, size_t len, bool fix = true) {
   sha3_256_words(msg, len, seed);
   return g2_random_from_seed(seed, fix);
 }
+// the same over a per-lane byte buffer (hash_g1_g2): SHA3 out of line (tc_hash.h sha3_256_words_call)
+TC_HD G2Jac hash_g2_point_of_buffer(const uint8_t* buf, size_t len, bool fix) {
+  uint32_t seed[8];
+  sha3_256_words_call(buf, len, seed);
+  return g2_random_from_seed(seed, fix);
+}
 TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix = true) {
   g2_encode_uncompressed(jac_to_affine(hash_g2_point(msg, len, fix)), out_g2);
 }
@@ -457,7 +463,7 @@ TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, 
   size_t n;
   if (len > 64) {
     uint32_t d[8];
-    sha3_256_words(msg, len, d);
+    sha3_256_words_call(msg, len, d);
     for (int i = 0; i < 8; i++) {
       buf[4 * i] = (uint8_t)d[i];
       buf[4 * i + 1] = (uint8_t)(d[i] >> 8);
@@ -471,7 +477,7 @@ TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, 
     n = len;
   }
   g1_encode_compressed(p, buf + n);
-  return hash_g2_point(buf, n + 48, fix);
+  return hash_g2_point_of_buffer(buf, n + 48, fix);
 }
 TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix = true) {
   G1Affine p;
