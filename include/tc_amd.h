@@ -75,6 +75,7 @@ typedef struct tc_ctx tc_ctx;
 int tc_ctx_create(tc_ctx** out, int device);
 void tc_ctx_destroy(tc_ctx* ctx);
 int tc_ctx_set_device_io(tc_ctx* ctx, int enabled);
+int tc_ctx_get_device_io(const tc_ctx* ctx);
 /* Use an externally owned HIP stream (hipStream_t passed as void*), e.g. torch's current
  * stream; NULL restores the context's own stream. */
 int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream);

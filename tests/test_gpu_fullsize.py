@@ -413,6 +413,17 @@ def test_rlc_decryption_share_validation_equals_per_share_path(engine):
     assert (ok == want).all() and nfb == 4
     ok, nfb = engine.verify_decryption_shares_rlc(pks, shares, we.u, we.v, we.off, we.w)
     assert ok.all() and nfb == 0
+    # a ciphertext whose u is ON the curve but outside G1 -- the per-share path rejects every share of it (u is
+    # one of its checked operands), and the RLC entry's share-by-share fallback must do the same instead of reporting the
+    # bare pairing result
+    u_bad = we.u.copy()
+    u_bad[123] = u8(o.g1_uncompressed((x, y)))
+    want_u = engine.verify_decryption_share(np.ascontiguousarray(np.tile(pks, (B, 1))), flat(shares), np.ascontiguousarray(np.repeat(u_bad, N, axis=0)),
+                                            np.ascontiguousarray(np.repeat(v32, N, axis=0).reshape(-1)), np.arange(B * N + 1, dtype=np.uint64) * 32,
+                                            np.ascontiguousarray(np.repeat(we.w, N, axis=0))).reshape(B, N)
+    assert not want_u[123].any() and want_u.sum() == (B - 1) * N
+    ok, nfb = engine.verify_decryption_shares_rlc(pks, shares, u_bad, we.v, we.off, we.w, seed=bytes(range(32)))
+    assert (ok == want_u).all() and nfb == 1
 
 
 def test_large_threshold_g1_and_g2_combination_vs_oracle(engine):

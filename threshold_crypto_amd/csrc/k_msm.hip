@@ -75,6 +75,8 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_msm_ladder_split(size_t
   if (g == 0) g2_encode_uncompressed(jac_to_affine(r), out + j * 192);
 }
 
+// ONE point set shared by every job with short scalars (the recoding never negates a base then): one table set for the launch
+__host__ __device__ inline bool msm_g1_shared_tables(size_t pts_stride, int nbits) { return pts_stride == 0 && nbits < 128; }
 // ---- G1 (tc_msm.h): stage T one lane per (job, chunk of 4 shares), stage L one lane per job -- or per PART of a job
 // when the batch alone does not fill the GPU (a job's `parts` lanes are adjacent; their partial sums meet in
 // log2(parts) rounds of one __shfl_xor exchange + one addition).  Two waves per SIMD (256 registers).
@@ -86,8 +88,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_msm_tables_g1(size_t n, size_t pt
   if (tid >= B * chunks) return;
   const size_t j = tid / chunks, c = tid % chunks;
   const size_t shares4 = chunks * kMsmChunk;
-  const bool ok = job_msm_tables_g1(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + j * shares4 * 8 * kMsmEntryWordsG1,
-                                    codes + j * kMsmColumns * shares4, nbits);
+  // ONE point set shared by every job, short scalars (the random linear combinations of the RLC checks): one table set, built
+  // by job 0; the other jobs only recode their scalars (B x N x 1 KiB of identical tables before)
+  const bool shared = msm_g1_shared_tables(pts_stride, nbits);
+  const bool ok = job_msm_tables_g1(n, c, points + j * pts_stride, scalars + j * n * 8, tbl + (shared ? 0 : j * shares4 * 8 * kMsmEntryWordsG1),
+                                    codes + j * kMsmColumns * shares4, nbits, !shared || j == 0);
   if (!ok && status[j] == TC_JOB_OK) status[j] = TC_JOB_INVALID_ENCODING;
 }
 __device__ __forceinline__ Fq msm_from_lane(const Fq& v, int lanes) {
@@ -97,7 +102,8 @@ __device__ __forceinline__ Fq msm_from_lane(const Fq& v, int lanes) {
 }
 template <bool SPLIT>
 __global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B, const int32_t* __restrict__ tbl, const uint8_t* __restrict__ codes,
-                                                           uint8_t* __restrict__ out, const uint8_t* __restrict__ status, size_t parts, int top) {
+                                                           uint8_t* __restrict__ out, const uint8_t* __restrict__ status, size_t parts, int top,
+                                                           int shared) {
   const size_t lp = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t j = lp / parts, g = lp % parts;
   if (j >= B) return;  // (parts divides 64: a job's lanes leave together)
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B,
     return;
   }
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
-  G1Jac r = job_msm_ladder_g1_part<SPLIT>(n, tbl + j * shares4 * 8 * kMsmEntryWordsG1, codes + j * kMsmColumns * shares4, msm_part(n, g, parts), top);
+  G1Jac r = job_msm_ladder_g1_part<SPLIT>(n, tbl + (shared ? 0 : j * shares4 * 8 * kMsmEntryWordsG1), codes + j * kMsmColumns * shares4,
+                                          msm_part(n, g, parts), top);
   if (SPLIT) {
     TC_NOUNROLL for (size_t d = 1; d < parts; d <<= 1) {
       const G1Jac o{msm_from_lane(r.x, (int)d), msm_from_lane(r.y, (int)d), msm_from_lane(r.z, (int)d)};
@@ -117,6 +124,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_msm_ladder_g1(size_t n, size_t B,
 }
 
 size_t msm_table_bytes_g1(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWordsG1 * sizeof(int32_t); }
+// jobs that own a table set in a launch_msm_g1 call: all of them, or one for a shared point set in short-scalar mode
+size_t msm_table_jobs_g1(size_t pts_stride, int nbits, size_t B) { return msm_g1_shared_tables(pts_stride, nbits) ? 1 : B; }
 // status: B bytes, TC_JOB_OK for the jobs to run (others get the identity and keep their status)
 // nbits = 128: any scalars below r.  nbits < 128 (even): odd scalars k1 + k2 x^2 with k1, k2 < 2^nbits (a job with another
 // scalar fails): nbits doublings instead of 128.
@@ -124,6 +133,7 @@ void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* p
                    uint8_t* codes, uint8_t* out, uint8_t* status, int nbits) {
   if (!B || !n) return;
   const int top = nbits / 2;
+  const int shared = msm_g1_shared_tables(pts_stride, nbits) ? 1 : 0;
   hipLaunchKernelGGL(k_msm_tables_g1, dim3(grid_for(B * msm_chunks(n))), dim3(kBlock), 0, st, n, pts_stride, points, scalars, B, tbl, codes, status, nbits);
   // lanes per job in stage L: 1 when the batch fills the 2048 wave slots by itself (131 072 lanes), else the power of two
   // that does, with at least four shares per part
@@ -131,10 +141,10 @@ void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* p
   while (parts < 64 && B * parts * 2 <= 131072 && parts * 2 * 4 <= n) parts *= 2;
   if (parts == 1)
     hipLaunchKernelGGL(k_msm_ladder_g1<false>, dim3(grid_for(B)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                       (const uint8_t*)status, parts, top);
+                       (const uint8_t*)status, parts, top, shared);
   else
     hipLaunchKernelGGL(k_msm_ladder_g1<true>, dim3(grid_for(B * parts)), dim3(kBlock), 0, st, n, B, (const int32_t*)tbl, (const uint8_t*)codes, out,
-                       (const uint8_t*)status, parts, top);
+                       (const uint8_t*)status, parts, top, shared);
 }
 
 size_t msm_table_bytes(size_t n, size_t B) { return B * msm_chunks(n) * kMsmChunk * 8 * kMsmEntryWords * sizeof(int32_t); }

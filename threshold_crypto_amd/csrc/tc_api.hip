@@ -237,13 +237,15 @@ size_t msm_table_budget(Call& k) {
   return b;
 }
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
-            uint8_t* d_st, int nbits = 64, tc::MsmFilter filter = tc::MsmFilter()) {
+            uint8_t* d_st, int nbits = 64, tc::MsmFilter filter = tc::MsmFilter(), bool secret_scalars = false) {
   const size_t per_job = tc::msm_table_bytes(n, 1);
   size_t tile = msm_table_budget(k) / (per_job ? per_job : 1);
   if (tile < 1) tile = 1;
   if (tile > B) tile = B;
   int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes(n, tile) / sizeof(int32_t));
   uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, tile));
+  // the digit codes are a lossless recoding of the scalars: wiped like them when they are secret
+  if (secret_scalars && d_codes) k.wipe.emplace_back(d_codes, tc::msm_code_bytes(n, tile));
   for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
     const size_t cnt = (B - lo < tile) ? B - lo : tile;
     tc::MsmFilter f = filter;
@@ -253,15 +255,18 @@ void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const ui
   }
 }
 
-// the same in G1 (k_msm.hip launch_msm_g1)
+// the same in G1 (k_msm.hip launch_msm_g1).  pts_stride 0 with short scalars: ONE table set for the whole call.
 void msm_g1(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out, uint8_t* d_st,
-            int nbits = 128) {
-  const size_t per_job = tc::msm_table_bytes_g1(n, 1);
+            int nbits = 128, bool secret_scalars = false) {
+  const bool shared = tc::msm_table_jobs_g1(pts_stride, nbits, B) == 1;
+  const size_t per_job = shared ? tc::msm_code_bytes(n, 1) : tc::msm_table_bytes_g1(n, 1);
   size_t tile = msm_table_budget(k) / (per_job ? per_job : 1);
   if (tile < 1) tile = 1;
   if (tile > B) tile = B;
-  int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes_g1(n, tile) / sizeof(int32_t));
+  int32_t* d_tbl = k.temp<int32_t>(tc::msm_table_bytes_g1(n, shared ? 1 : tile) / sizeof(int32_t));
   uint8_t* d_codes = k.temp<uint8_t>(tc::msm_code_bytes(n, tile));
+  // the digit codes are a lossless recoding of the scalars: wiped like them when they are secret
+  if (secret_scalars && d_codes) k.wipe.emplace_back(d_codes, tc::msm_code_bytes(n, tile));
   for (size_t lo = 0; lo < B && !k.failed; lo += tile) {
     const size_t cnt = (B - lo < tile) ? B - lo : tile;
     tc::launch_msm_g1(k.c->stream, n, pts_stride, d_pts + lo * pts_stride, d_scalars + lo * n * 8, cnt, d_tbl, d_codes, d_out + lo * 96, d_st + lo,
@@ -352,6 +357,11 @@ int tc_ctx_trim(tc_ctx* ctx) {
   if (!ctx) return TC_ERR_INVALID_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return TC_ERR_HIP;
   for (auto& s : ctx->slots) {
+    // staging slots may have held secret operands or their recodings: zeroed before they go back to the allocator
+    if (s.p) (void)hipMemsetAsync(s.p, 0, s.cap, ctx->stream);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& s : ctx->slots) {
     if (s.p) (void)hipFree(s.p);
     s.p = nullptr;
     s.cap = 0;
@@ -360,6 +370,7 @@ int tc_ctx_trim(tc_ctx* ctx) {
 }
 
 int tc_ctx_get_input_checks(const tc_ctx* ctx) { return (ctx && ctx->input_checks) ? 1 : 0; }
+int tc_ctx_get_device_io(const tc_ctx* ctx) { return (ctx && ctx->device_io) ? 1 : 0; }
 
 int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
   if (!ctx) return TC_ERR_INVALID_ARG;
@@ -738,11 +749,11 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
     } else if (g2) {
       uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
       if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
-      msm_g2(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
+      msm_g2(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf, 64, tc::MsmFilter(), /*secret_scalars=*/true);
     } else if (n >= tc::kMsmMinPoints) {
       uint8_t* st_buf = d_st ? d_st : k.temp<uint8_t>(B);
       if (st_buf) k.check(hipMemsetAsync(st_buf, 0, B, ctx->stream), "memset");
-      msm_g1(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf);
+      msm_g1(k, n, n * PB, d_pt, reinterpret_cast<const uint32_t*>(d_sc), B, d_out, st_buf, 128, /*secret_scalars=*/true);
     } else tc::launch_lincomb_g1(ctx->stream, n, d_sc, d_pt, B, d_out, d_st);
   }
   k.apply_checks(B, d_st, d_out, PB, nullptr);
@@ -904,7 +915,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
     tc::launch_rlc_scalars(ctx->stream, d_seed, B * N, d_r);
     // (the two-stage kernels' short-scalar mode: 16 doublings for the 64-bit random scalars)
     k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
-    msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16);
+    msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16, tc::MsmFilter(), /*secret_scalars=*/true);
     tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
     tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     // e(P, [c] Q') == e(g1, S)  <=>  e(P, Q') == e([1/c] g1, S)   (the folded hash constant of tc_verify_sig_batch)
@@ -1019,12 +1030,12 @@ static int verify_rlc(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const 
     k.check(hipMemsetAsync(d_st, 0, 2 * NG, ctx->stream), "memset");
     const uint32_t* rr = reinterpret_cast<const uint32_t*>(d_r);
     if (G) {
-      msm_g2(k, group, group * 192, d_sig, rr, G, d_S, d_st, /*nbits=*/16);
-      msm_g2(k, group, group * 192, d_hash, rr, G, d_H, d_st + NG, 16);
+      msm_g2(k, group, group * 192, d_sig, rr, G, d_S, d_st, /*nbits=*/16, tc::MsmFilter(), /*secret_scalars=*/true);
+      msm_g2(k, group, group * 192, d_hash, rr, G, d_H, d_st + NG, 16, tc::MsmFilter(), true);
     }
     if (tail) {
-      msm_g2(k, tail, tail * 192, d_sig + G * group * 192, rr + G * group * 8, 1, d_S + G * 192, d_st + G, 16);
-      msm_g2(k, tail, tail * 192, d_hash + G * group * 192, rr + G * group * 8, 1, d_H + G * 192, d_st + NG + G, 16);
+      msm_g2(k, tail, tail * 192, d_sig + G * group * 192, rr + G * group * 8, 1, d_S + G * 192, d_st + G, 16, tc::MsmFilter(), true);
+      msm_g2(k, tail, tail * 192, d_hash + G * group * 192, rr + G * group * 8, 1, d_H + G * 192, d_st + NG + G, 16, tc::MsmFilter(), true);
     }
     tc::launch_pairing_check(ctx->stream, d_pk, 0, d_H, 192, d_g1, 0, d_S, 192, NG, d_okg, k.pairing_ws(NG));
     k.check(hipMemsetAsync(d_ok, 1, B, ctx->stream), "memset");
@@ -1224,8 +1235,8 @@ int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares,
     tc::launch_rlc_scalars_g1(ctx->stream, d_seed, B * N, d_r);
     k.check(hipMemsetAsync(d_st, 0, 3 * B, ctx->stream), "memset");
     const uint32_t* rr = reinterpret_cast<const uint32_t*>(d_r);
-    msm_g1(k, N, N * 96, d_sh, rr, B, d_D, d_st, /*nbits=*/32);
-    msm_g1(k, N, 0, d_pk, rr, B, d_P, d_st + B, 32);
+    msm_g1(k, N, N * 96, d_sh, rr, B, d_D, d_st, /*nbits=*/32, /*secret_scalars=*/true);
+    msm_g1(k, N, 0, d_pk, rr, B, d_P, d_st + B, 32, true);   // the N key shares are the same for every ciphertext: one table set
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st + 2 * B, /*fix=*/false);
     tc::launch_g1_scale_cofactor_fix(ctx->stream, d_D, 96, B, d_Dc);
     // e(D, [c] Q') = e([c] D, Q') == e(P, w)      (the folded hash constant of tc_verify_decryption_share_batch)
@@ -1276,6 +1287,14 @@ int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares,
           tc::launch_invalidate_jobs(ctx->stream, vv, 1, 1, R, nullptr, nullptr, 0, c_ok);
           tc::launch_subgroup_check_g2(ctx->stream, c_w, 192, 1, 1, R, vv);
           tc::launch_invalidate_jobs(ctx->stream, vv, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          // ... and u, which tc_verify_decryption_share_batch checks too (an on-curve u outside G1 used to
+          // reach the bare pairing result here)
+          uint8_t* c_u = k.temp<uint8_t>(R * 96);
+          if (c_u) {
+            tc::launch_gather_rows(ctx->stream, d_u, 96, d_maps + R, R, c_u);
+            tc::launch_subgroup_check_g1(ctx->stream, c_u, 96, 1, 1, R, vv);
+            tc::launch_invalidate_jobs(ctx->stream, vv, 1, 1, R, nullptr, nullptr, 0, c_ok);
+          }
         }
         tc::launch_scatter_bytes(ctx->stream, c_ok, d_maps, R, d_ok);
         k.check(hipStreamSynchronize(ctx->stream), "stream sync");  // the host maps go out of scope

@@ -345,9 +345,12 @@ int tc_group_combine_signatures(tc_group* g, size_t n_per_job, const uint64_t* i
   return run_ranks(g, [&](int r) {
     size_t s, c;
     shard(B, (int)g->ctx.size(), r, &s, &c);
-    return c ? tc_combine_g2_batch(g->ctx[r], g->t, n_per_job, idx + s * n_per_job, shares + s * n_per_job * 192, c, out + s * 192,
-                                   status + s)
-             : TC_OK;
+    if (!c) return (int)TC_OK;
+    const int dio = tc_ctx_get_device_io(g->ctx[r]);  // host buffers here, whatever mode the user left the rank's context in
+    (void)tc_ctx_set_device_io(g->ctx[r], 0);
+    const int e = tc_combine_g2_batch(g->ctx[r], g->t, n_per_job, idx + s * n_per_job, shares + s * n_per_job * 192, c, out + s * 192, status + s);
+    (void)tc_ctx_set_device_io(g->ctx[r], dio);
+    return e;
   });
 }
 
@@ -367,9 +370,10 @@ int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, siz
     uint8_t* d_ok = (uint8_t*)dev_buf(g, r, kBufOk, c);
     if (!d_sig || !d_hash || !d_ok) return (int)TC_ERR_HIP;
     if (!h2d(g, r, d_sig, sig + s * 192, c * 192) || !h2d(g, r, d_hash, hash + s * 192, c * 192)) return (int)TC_ERR_HIP;
+    const int dio = tc_ctx_get_device_io(g->ctx[r]);  // the rank's context is also handed to the user (tc_group_ctx): leave its mode as found
     (void)tc_ctx_set_device_io(g->ctx[r], 1);
     int e = tc_verify_g2_batch(g->ctx[r], g->d_keyset[r], 0, d_sig, d_hash, c, d_ok);
-    (void)tc_ctx_set_device_io(g->ctx[r], 0);
+    (void)tc_ctx_set_device_io(g->ctx[r], dio);
     if (e == TC_OK && !d2h(g, r, ok + s, d_ok, c)) e = TC_ERR_HIP;
     if (e == TC_OK && hipStreamSynchronize(g->streams[r]) != hipSuccess) e = TC_ERR_HIP;
     for (size_t j = 0; j < c && e == TC_OK; j++) local[r] += ok[s + j] ? 1 : 0;
@@ -415,7 +419,12 @@ int tc_group_sign_combine_verify(tc_group* g, const uint8_t* sk_table, size_t N,
     if (!d_msgs || !d_off || !d_idx || !d_sk || !d_hash || !d_shares || !d_st || !d_sig || !d_stc || !d_ok) return (int)TC_ERR_HIP;
     bool up = h2d(g, r, d_msgs, msgs ? msgs + off[s] : nullptr, mbytes) && h2d(g, r, d_off, o.data(), (c + 1) * 8) &&
               h2d(g, r, d_idx, idx + s * n, c * n * 8) && h2d(g, r, d_sk, sk_table, N * 32);
-    if (!up) return (int)TC_ERR_HIP;
+    if (!up) {
+      (void)hipMemsetAsync(d_sk, 0, N * 32, g->streams[r]);  // (part of) the secret share table may have gone up: wiped on this path too
+      (void)hipStreamSynchronize(g->streams[r]);
+      return (int)TC_ERR_HIP;
+    }
+    const int dio = tc_ctx_get_device_io(ctx);
     (void)tc_ctx_set_device_io(ctx, 1);
     // hash points and shares are made right here by the library's own kernels: known group members (tc_amd.h "Decoding")
     const int checks = tc_ctx_get_input_checks(ctx);
@@ -426,7 +435,7 @@ int tc_group_sign_combine_verify(tc_group* g, const uint8_t* sk_table, size_t N,
     if (e == TC_OK) e = tc_verify_g2_batch(ctx, g->d_keyset[r], 0, d_sig, d_hash, c, d_ok);
     (void)hipMemsetAsync(d_sk, 0, N * 32, g->streams[r]);  // the secret key shares do not outlive the call
     (void)tc_ctx_set_input_checks(ctx, checks);
-    (void)tc_ctx_set_device_io(ctx, 0);
+    (void)tc_ctx_set_device_io(ctx, dio);
     std::vector<uint8_t> stc(c);
     if (e == TC_OK && !(d2h(g, r, sig + s * 192, d_sig, c * 192) && d2h(g, r, ok + s, d_ok, c) && d2h(g, r, stc.data(), d_stc, c))) e = TC_ERR_HIP;
     if (hipStreamSynchronize(g->streams[r]) != hipSuccess && e == TC_OK) e = TC_ERR_HIP;

@@ -103,6 +103,7 @@ void launch_msm_g2(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* p
 // the same two stages in G1 (threshold decryption and G1 linear combinations from kMsmMinPoints points on): codes as for G2
 // (msm_code_bytes), tables of msm_table_bytes_g1
 size_t msm_table_bytes_g1(size_t n, size_t B);
+size_t msm_table_jobs_g1(size_t pts_stride, int nbits, size_t B);  // 1 when every job shares ONE point set and the scalars are short
 void launch_msm_g1(hipStream_t st, size_t n, size_t pts_stride, const uint8_t* points, const uint32_t* scalars, size_t B, int32_t* tbl,
                    uint8_t* codes, uint8_t* out, uint8_t* status, int nbits = 128);
 // random scalars for the batch validation of G1 values: a + b x^2 with a (odd), b from 32-bit draws of ChaCha20(seed, i)

@@ -262,7 +262,10 @@ TC_HD bool msm_g1_recode(const uint32_t* k, uint8_t* codes, size_t stride, int n
 
 // Stage T in G1 for the chunk `c` of one job: tbl = (4 * chunks) shares x 8 entries x 32 words; codes: 65 columns x
 // (4 * chunks) shares, one byte each.
-TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes, int nbits = 128) {
+// build = false: codes and operand validity only -- the tables of a point set SHARED by every job (short-scalar mode: the
+// recoding never negates a base, so the entries depend on the points alone) are written by one job for all.
+TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const uint32_t* scalars, int32_t* tbl, uint8_t* codes, int nbits = 128,
+                             bool build = true) {
   const size_t shares4 = msm_chunks(n) * kMsmChunk;
   G1Affine b0[kMsmChunk];
   G1Jac mult[2 * kMsmChunk];  // 2P, 3P
@@ -286,6 +289,7 @@ TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const ui
     mult[2 * k] = jac_dbl(G1Jac::from_affine(p));
     mult[2 * k + 1] = jac_add_mixed(mult[2 * k], p);
   }
+  if (!wave_any(build)) return ok;
   // 2P and 3P of the four shares to affine with one inversion
   G1Affine ma[2 * kMsmChunk];
   jac_batch_to_affine<Fq, 2 * kMsmChunk>(mult, ma, 2 * kMsmChunk);
@@ -307,6 +311,7 @@ TC_HD bool job_msm_tables_g1(size_t n, size_t c, const uint8_t* points, const ui
   G1Affine aff[6 * kMsmChunk];
   jac_batch_to_affine<Fq, 6 * kMsmChunk>(sums, aff, 6 * kMsmChunk);
   TC_NOUNROLL for (int k = 0; k < kMsmChunk; k++) {
+    if (!build) break;
     const size_t s = c * kMsmChunk + k;
     int32_t* t = tbl + s * 8 * kMsmEntryWordsG1;
     msm_store_entry_g1(t, b0[k]);
