@@ -86,6 +86,8 @@ int hs_fq2_sqrt(const uint8_t* a /*c0||c1 be48*/, uint8_t* out) {
 }
 int hs_g1_mul(const uint8_t* fr, const uint8_t* pt, uint8_t* out) { return job_point_mul<Fq>(fr, pt, out); }
 int hs_g2_mul(const uint8_t* fr, const uint8_t* pt, uint8_t* out) { return job_point_mul<Fq2>(fr, pt, out); }
+// the body of k_g1_mul_arena: the ladder's table in the lane's arena entries (tc_gls.h g1_mul_glv_arena)
+int hs_g1_mul_arena(const uint8_t* fr, const uint8_t* pt, uint8_t* out) { return job_g1_mul_arena(fr, pt, out); }
 int hs_combine_job_class(const uint64_t* idx, int t) { return combine_job_class(idx, t); }
 // base-|x| digits of a scalar (8 LE u32 words)
 void hs_gls_decompose(const uint32_t* k, uint64_t* d) { gls_decompose(k, d); }

@@ -464,6 +464,7 @@ buf = ctypes.create_string_buffer
 P = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R)); Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
 k = rnd.randrange(o.R)
 out = buf(96); assert L.hs_g1_mul(o.fr_to_bytes(k), o.g1_uncompressed(P), out) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(P, k))
+out = buf(96); assert L.hs_g1_mul_arena(o.fr_to_bytes(k), o.g1_uncompressed(P), out) == 0 and out.raw == o.g1_uncompressed(o.E1.mul(P, k))
 out = buf(192); assert L.hs_g2_mul(o.fr_to_bytes(k), o.g2_uncompressed(Q2), out) == 0 and out.raw == o.g2_uncompressed(o.E2.mul(Q2, k))
 for t, ids in [(3, [1, 4, 6, 9]), (5, [0, 2, 3, 6, 9, 11]), (3, [2**40, 1, 2, 3]), (21, list(range(0, 66, 3)))]:
     poly = [rnd.randrange(o.R) for _ in range(t + 1)]
@@ -548,8 +549,13 @@ def test_g1_base4_sign_aligned_ladder_edges(L, rnd):
         out = buf(96)
         assert L.hs_g1_mul(o.fr_to_bytes(k), pb, out) == 0
         assert out.raw == c.g1_mul(o.fr_to_bytes(k), pb)[1], hex(k)
+        out2 = buf(96)          # the two-waves-per-SIMD form: table entries in the arena (k_g1_mul_arena)
+        assert L.hs_g1_mul_arena(o.fr_to_bytes(k), pb, out2) == 0 and out2.raw == out.raw, hex(k)
     out = buf(96)
     assert L.hs_g1_mul(o.fr_to_bytes(5), o.g1_uncompressed(None), out) == 0 and out.raw == o.g1_uncompressed(None)
+    assert L.hs_g1_mul_arena(o.fr_to_bytes(5), o.g1_uncompressed(None), out) == 0 and out.raw == o.g1_uncompressed(None)
+    bad = bytearray(pb); bad[50] ^= 1
+    assert L.hs_g1_mul_arena(o.fr_to_bytes(5), bytes(bad), out) == 3 and out.raw == o.g1_uncompressed(None)
 
 
 def test_g1_glv_and_phi_subgroup_test(L, rnd):

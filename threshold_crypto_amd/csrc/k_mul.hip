@@ -2,6 +2,8 @@
 #include "tc_jobs.h"
 #include "tc_launch.h"
 
+#include <stdlib.h>
+
 namespace tc {
 
 // One curve op per lane.  Lane order is signer-major (tid = s*B + j) so that the 64 lanes of
@@ -22,6 +24,23 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
     if (status && (L == 1 || pair_leader())) status[o] = st;
   }
   if (L > 1) table_slot_release(ta, tslot);
+}
+
+// G1, batches above one wave per SIMD (more than 65 536 multiplications): built for 256 registers so that TWO waves share a SIMD
+// -- a lone wave issues a v_mad_i64_i32 only every 8.75 cycles, two saturate the pipe (tools/ubench_issue) --, the 8-entry table
+// of the base-4 GLV ladder in the wave's arena slot (1 KB per lane, full-line entries) instead of 224 registers.
+__global__ __launch_bounds__(kBlock, 2) void k_g1_mul_arena(const uint8_t* __restrict__ fr, const uint8_t* __restrict__ pts, size_t S, size_t B,
+                                                          uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
+  const uint32_t tslot = table_slot_acquire(ta);
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = tid < S * B;
+  const size_t s = live ? tid / B : 0, j = live ? tid % B : 0;
+  const size_t o = j * S + s;
+  // (a lane past the end multiplies job 0 again and drops the result: the ladder's loads and stores are the whole wave's)
+  uint8_t sink[96];
+  const uint8_t st = job_g1_mul_arena(fr + s * 32, pts + j * 96, live ? out + o * 96 : sink);
+  if (live && status) status[o] = st;
+  table_slot_release(ta, tslot);
 }
 
 // S > 1 scalars over the same G2 points: a lane pair takes one point and a chunk of up to
@@ -118,9 +137,14 @@ __global__ void k_fill_g1_generator(uint8_t* out96, uint8_t* out96_unfix) {
   }
 }
 
-void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+// ta: the context's table arena, or {nullptr, nullptr} to force the register-table kernel
+void launch_g1_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {
-  if (S * B) hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, TableArena{nullptr, nullptr});
+  if (!(S * B)) return;
+  static const char* force = getenv("TC_G1_MUL_FORM");  // experiments: "arena" / "regs"
+  const bool arena = ta.mem && ta.flags && (force ? force[0] == 'a' : S * B > kG1ArenaMinJobs);
+  if (arena) hipLaunchKernelGGL(k_g1_mul_arena, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, ta);
+  else hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, TableArena{nullptr, nullptr});
 }
 void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {

@@ -451,7 +451,7 @@ static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts
   k.check_points(g2, d_pts, PB, 1, 1, B, S);
   if (!k.failed) {
     if (g2) tc::launch_g2_mul(ctx->stream, k.tables(), d_fr, d_pts, S, B, d_out, d_st);
-    else tc::launch_g1_mul(ctx->stream, d_fr, d_pts, S, B, d_out, d_st);
+    else tc::launch_g1_mul(ctx->stream, S * B > tc::kG1ArenaMinJobs ? k.tables() : tc::TableArena{nullptr, nullptr}, d_fr, d_pts, S, B, d_out, d_st);
   }
   k.apply_checks(S * B, d_st, d_out, PB, nullptr);
   k.end_timing();

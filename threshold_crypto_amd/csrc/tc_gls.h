@@ -328,8 +328,12 @@ TC_HD bool glv_recode_sign_aligned(const uint32_t* k, tc_u128* neg_out, tc_u128*
 // does).  The table is brought to one common Z without an inversion (tc_curve.h jac_batch_to_common_z: its entries are
 // affine points of an isomorphic curve, the result gets the common Z back).  Same recoding as the two-stage G1 kernels
 // (tc_msm.h msm_g1_recode), which keep their tables in HBM.
-TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
-  if (p.inf) return G1Jac::infinity();
+// ARENA: the table goes to this lane's 1 KB of the wave's arena slot (tc_table.h lane_table: full-line entries) instead of staying in
+// 224 registers -- the form of the kernels built for TWO waves per SIMD (256 registers), which batches above one wave per SIMD
+// take; the caller's kernel must hold a slot (table_slot_acquire).
+template <bool ARENA>
+TC_HD G1Jac g1_mul_glv_impl(const G1Affine& p, const uint32_t* k) {
+  if (!ARENA && p.inf) return G1Jac::infinity();
   tc_u128 neg, u;
   bool top;
   const bool flip = glv_recode_sign_aligned(k, &neg, &u, &top);
@@ -354,7 +358,12 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
   const Fq zc = jac_batch_to_common_z<Fq, 8>(e, tbl + 1, 7);
   const Fq zc2 = zc.sqr();
   tbl[0] = affine_scale_z(b, zc2, zc2 * zc);
-  G1Jac acc = G1Jac::from_affine(tbl[top ? 3 : 0]);
+  tbl_word* mem = nullptr;
+  if (ARENA) {
+    mem = lane_table();
+    TC_UNROLL for (int m = 0; m < 8; m++) tbl_store_g1(mem + m * kG1EntryWords, tbl[m]);
+  }
+  G1Jac acc = G1Jac::from_affine(ARENA ? tbl_load_g1(mem + (top ? 3 : 0) * kG1EntryWords) : tbl[top ? 3 : 0]);
   TC_NOUNROLL for (int c = 63; c >= 0; c--) {
     tc_fair();
     acc = jac_dbl(jac_dbl(acc));
@@ -362,13 +371,17 @@ TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) {
     neg <<= 2;
     u <<= 2;
     const bool sub = (n >> 1) != 0;
-    G1Affine t = tbl[w | ((((n >> 1) ^ n) & 1u) ? 0u : 4u)];
+    const uint32_t m = w | ((((n >> 1) ^ n) & 1u) ? 0u : 4u);
+    G1Affine t = ARENA ? tbl_load_g1(mem + m * kG1EntryWords) : tbl[m];
     t.y = Fq::select(sub, -t.y, t.y);
     acc = jac_add_mixed(acc, t);
   }
   acc.z = coord_norm(acc.z * zc);
+  if (ARENA && p.inf) acc = G1Jac::infinity();  // (uniform control flow up to here: the slot's stores and loads are the wave's)
   return acc;
 }
+TC_HD_NOINLINE G1Jac g1_mul_glv(const G1Affine& p, const uint32_t* k) { return g1_mul_glv_impl<false>(p, k); }
+TC_HD_NOINLINE G1Jac g1_mul_glv_arena(const G1Affine& p, const uint32_t* k) { return g1_mul_glv_impl<true>(p, k); }
 // the same for a Jacobian P (the share combiner's final [D^-1] step)
 // (no inversion: (X, Y) is an affine point of the isomorphic curve y^2 = x^3 + b Z^6, phi acts on
 // it the same way, and the a = 0 group law never reads b; the result's Z is multiplied by Z)

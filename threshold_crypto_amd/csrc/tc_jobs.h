@@ -69,6 +69,22 @@ TC_HD uint8_t job_point_mul(const uint8_t* fr_le32, const uint8_t* pt, uint8_t* 
   return TC_JOB_OK;
 }
 
+// the G1 multiplication with its ladder table in the wave's arena slot (tc_gls.h g1_mul_glv_arena): the body of the kernel built
+// for two waves per SIMD.  Every lane of the wave runs the ladder (a failed decode multiplies the identity's stand-in).
+TC_HD uint8_t job_g1_mul_arena(const uint8_t* fr_le32, const uint8_t* pt, uint8_t* out) {
+  uint32_t k[8];
+  G1Affine p;
+  bool ok = fr_from_le32(fr_le32, k);
+  ok &= g1_decode_uncompressed(pt, p);
+  if (!ok) {
+    p = G1Affine{g1_generator().x, g1_generator().y, true};
+    TC_UNROLL for (int i = 0; i < 8; i++) k[i] = (i == 0) ? 1u : 0u;
+  }
+  const G1Affine r = jac_to_affine(g1_mul_glv_arena(p, k));
+  g1_encode_uncompressed(ok ? r : G1Affine::infinity(), out);
+  return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+}
+
 // out[s] = fr[s] * pt for n <= C scalars and ONE G2 point (the S signers of tc_g2_mul_batch over the
 // same hash point): one decode, one table of psi-images (tc_gls.h g2_sac_table) and one inversion
 // for the n results.  A bad point fails all n outputs, a bad scalar only its own.

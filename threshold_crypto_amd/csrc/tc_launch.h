@@ -21,7 +21,10 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: the jobs are registe
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-void launch_g1_mul(hipStream_t st, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
+// G1 kernels take the two-waves-per-SIMD form (table in the arena) from here on: one lane per job fills one wave per SIMD at
+// 65 536 jobs, and only a second wave can use the other half of the multiplier's issue slots
+constexpr size_t kG1ArenaMinJobs = 65536;
+void launch_g1_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status);
 void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status);

@@ -36,6 +36,10 @@ __shared__ tbl_word* tc_wave_tables;
 // this lane pair's table (kBlock = 64: one wave per workgroup)
 __device__ __forceinline__ tbl_word* pair_table() { return tc_wave_tables + (threadIdx.x >> 1) * kPairTableWords; }
 
+// G1 kernels (one lane per job): the slot holds one 8-entry table per LANE -- 8 x 128 bytes (x, y: 14 limbs each + 4 words of
+// padding: a full-line entry, read with seven global_load_dwordx4) = 1 KB per lane, 64 KB per wave, the same slot size.
+__device__ __forceinline__ tbl_word* lane_table() { return tc_wave_tables + threadIdx.x * kLaneTableWords; }
+
 // Call once per wave, in convergent code, before the first table is built; returns the slot for table_slot_release.
 __device__ __forceinline__ uint32_t table_slot_acquire(const TableArena& ta) {
   const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (kTableXccs - 1);  // HW_REG_XCC_ID [3:0]
@@ -63,6 +67,10 @@ __device__ __forceinline__ void table_slot_release(const TableArena& ta, uint32_
 typedef int32_t tbl_word;
 TC_HD tbl_word* pair_table() {
   static thread_local tbl_word buf[kPairTableWords];
+  return buf;
+}
+TC_HD tbl_word* lane_table() {
+  static thread_local tbl_word buf[kLaneTableWords];
   return buf;
 }
 TC_HD uint32_t table_slot_acquire(const TableArena&) { return 0; }
@@ -111,6 +119,18 @@ TC_HD Fq tbl_load_fq(const tbl_word* w) {
   r.set_val(2.1f);
   return r;
 }
+// an affine G1 point (of the common-Z curve of a ladder table) <-> its 128-byte entry
+TC_HD void tbl_store_g1(tbl_word* e, const G1Affine& p) {
+  const Fq x = p.x.norm(), y = p.y.norm();
+#if defined(TC_BOUND_CHECK)
+  if (x.val() > 2.1f || y.val() > 2.1f) tc_bound_fail(x.val(), y.val());
+#endif
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    e[i] = x.l[i];
+    e[FQ_LIMBS + i] = y.l[i];
+  }
+}
+TC_HD G1Affine tbl_load_g1(const tbl_word* e) { return G1Affine{tbl_load_fq(e), tbl_load_fq(e + FQ_LIMBS), false}; }
 TC_HD G2Affine tbl_load_g2(const tbl_word* e) {
   G2Affine p;
 #if TC_PAIR
