@@ -209,3 +209,44 @@ def test_api_mirror_takes_into_fr_keys(engine, rnd):
     for keys in ([-3, 4, 9], [api.Fr(12345), api.Fr(o.R - 7), api.Fr(6)]):
         dshares = {k: sk_set.secret_key_share(k).decrypt_share_no_verify(ct) for k in keys}
         assert pk_set.decrypt(dshares, ct) == b"secret"
+
+
+def test_g1_two_wave_kernels_equal_the_one_wave_kernels(engine, rnd):
+    """Above 65 536 jobs the single G1 multiplication and the G1 combine fast path run their TWO-waves-per-SIMD builds
+    (k_g1_mul_arena, k_combine_fast_g1_arena: 256 registers, the base-4 GLV ladder's table in the lane's arena entries).  A
+    70 000-job call must return exactly what two calls of 35 000 jobs (the register-table kernels) return -- DecryptionShare
+    generation (src/lib.rs:460-462) and PublicKeySet::decrypt's combination (src/lib.rs:618-626) with the D = 1, 2^a and generic
+    denominators all present, an identity operand, an undecodable one -- and Oracle B recomputes a sample."""
+    B, t = 70000, 3
+    e = engine
+    e.set_input_checks(False)
+    try:
+        r = np.random.default_rng(11)
+        fr = r.integers(0, 256, size=(B, 32), dtype=np.uint8)
+        fr[:, 31] &= 0x3F
+        base, st = e.g1_mul(fr[:1].copy(), np.tile(u8(o.g1_uncompressed(o.G1_GEN))[None], (B, 1)))     # one point ...
+        pts = np.ascontiguousarray(base[:, 0])
+        scal = fr[1:5].copy()
+        sh, st = e.g1_mul(scal, pts)                                                                   # (B, 4, 96): four multiples each
+        assert not st.any()
+        pts[7] = u8(o.g1_uncompressed(None))
+        pts[9, 3] ^= 0x40
+        one, st1 = e.g1_mul(fr[5:6].copy(), pts)
+        halves = [e.g1_mul(fr[5:6].copy(), np.ascontiguousarray(pts[lo:lo + 35000])) for lo in (0, 35000)]
+        assert (one == np.concatenate([h[0] for h in halves])).all() and (st1 == np.concatenate([h[1] for h in halves])).all()
+        assert int(st1[9, 0]) == 3 and bytes(one[7, 0]) == o.g1_uncompressed(None)
+        for j in (0, 1, 35000, B - 1):
+            assert bytes(one[j, 0]) == c.g1_mul(bytes(fr[5]), bytes(pts[j]))[1]
+        subsets = [[0, 1, 2, 3], [0, 1, 2, 4], [1, 3, 5, 7], [0, 2, 5, 9], [2, 3, 4, 8]]                # D = 12, 24? ... mixed classes
+        idx = np.array([subsets[j % len(subsets)] for j in range(B)], dtype=np.uint64)
+        sh[11, 1] = u8(o.g1_uncompressed(None))
+        sh[13, 2, 5] ^= 0x01
+        comb, stc = e.combine_g1(t, idx, sh)
+        parts = [e.combine_g1(t, np.ascontiguousarray(idx[lo:lo + 35000]), np.ascontiguousarray(sh[lo:lo + 35000])) for lo in (0, 35000)]
+        assert (comb == np.concatenate([p[0] for p in parts])).all() and (stc == np.concatenate([p[1] for p in parts])).all()
+        assert int(stc[13]) == 3 and stc.sum() == 3
+        for j in (0, 1, 2, 3, 4, 11, 35001, B - 1):
+            rc, want = c.combine_g1(t, [int(i) for i in idx[j]], [bytes(x) for x in sh[j]])
+            assert rc == 0 and want == bytes(comb[j]), j
+    finally:
+        e.set_input_checks(True)

@@ -155,11 +155,11 @@ __global__ __launch_bounds__(kGroupBlock) void k_combine_scatter(const uint8_t* 
   }
 }
 
-template <class F, class IO>
+template <class F, class IO, bool ARENA = false>
 TC_D bool combine_fast(size_t t, const uint64_t* idx, bool live, IO& io, uint8_t* st) {
-  if (t == 1) return job_combine_small_io<F, 2>(idx, live, io, st);
-  if (t == 2) return job_combine_small_io<F, 3>(idx, live, io, st);
-  return job_combine_small_io<F, 4>(idx, live, io, st);
+  if (t == 1) return job_combine_small_io<F, 2, IO, ARENA>(idx, live, io, st);
+  if (t == 2) return job_combine_small_io<F, 3, IO, ARENA>(idx, live, io, st);
+  return job_combine_small_io<F, 4, IO, ARENA>(idx, live, io, st);
 }
 
 // The combination runs as TWO kernels so that each carries only its own private segment (the general
@@ -193,6 +193,24 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   const bool done = combine_fast<F>(t, idx + jj * n_per_job, live, io, &st);
   if (done && status && (L == 1 || pair_leader())) status[j] = st;
   if (L > 1) table_slot_release(ta, tslot);
+}
+
+// G1 above one wave per SIMD (more than 65 536 jobs): 256 registers so that two waves share a SIMD, the [1 / D] ladder's table in
+// the lane's arena entries (k_mul.hip k_g1_mul_arena explains)
+__global__ __launch_bounds__(kBlock, 2) void k_combine_fast_g1_arena(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
+                                                                  const uint8_t* __restrict__ shares, size_t B, uint8_t* __restrict__ out,
+                                                                  uint8_t* __restrict__ status, TableArena ta) {
+  using IO = WaveRowIO<96, 1>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[IO::BYTES];
+  const uint32_t tslot = table_slot_acquire(ta);
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = j < B;
+  const size_t jj = live ? j : 0;
+  IO io{lds, live ? shares + jj * n_per_job * 96 : nullptr, (size_t)96, live ? out + jj * 96 : nullptr};
+  uint8_t st = TC_JOB_OK;
+  const bool done = combine_fast<Fq, IO, true>(t, idx + jj * n_per_job, live, io, &st);
+  if (done && status) status[j] = st;
+  table_slot_release(ta, tslot);
 }
 
 template <class F>
@@ -278,10 +296,14 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
 // need_general: one zeroed word the Lagrange stage counts non-fast jobs in (nullptr when t == 0: no
 // Lagrange stage, the general kernel takes every job)
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general) {
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general, TableArena ta) {
   if (!B) return;
-  if (idx && t >= 1 && t <= 3)
-    hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});
+  if (idx && t >= 1 && t <= 3) {
+    if (ta.mem && ta.flags && B > kG1ArenaMinJobs)
+      hipLaunchKernelGGL(k_combine_fast_g1_arena, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, ta);
+    else
+      hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});
+  }
   hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, TableArena{nullptr, nullptr});
 }
 size_t combine_group_slots(size_t B) { return B + (size_t)kCombineClasses * kCombinePad; }

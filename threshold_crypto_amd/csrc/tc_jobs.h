@@ -244,6 +244,15 @@ TC_HD G1Jac combine_divide(const G1Jac& q, uint64_t d_abs, bool d_neg) {
   fr_inverse_of_small(d_abs, d_neg, dinv);
   return point_mul_scalar(q, dinv);
 }
+// the same with the ladder's table in the lane's arena entries (the two-waves-per-SIMD build of k_combine_fast<Fq>)
+TC_HD G1Jac combine_divide_arena(const G1Jac& q, uint64_t d_abs, bool d_neg) {
+  uint32_t dinv[8];
+  fr_inverse_of_small(d_abs, d_neg, dinv);
+  G1Jac r = g1_mul_glv_arena(G1Affine{q.x, q.y, q.is_inf()}, dinv);
+  r.z = coord_norm(r.z * q.z);
+  return r;
+}
+
 TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
   const int cls = combine_denominator_class(d_abs);
   G2Jac r = q;
@@ -267,6 +276,7 @@ TC_HD G2Jac combine_divide(const G2Jac& q, uint64_t d_abs, bool d_neg) {
   r.y = Fq2::select(d_neg, -r.y, r.y);
   return r;
 }
+TC_HD G2Jac combine_divide_arena(const G2Jac& q, uint64_t d_abs, bool d_neg) { return combine_divide(q, d_abs, d_neg); }  // (G2: always in the arena)
 
 // Where a job body finds the encodings of its operands and where its result goes.  DirectIO addresses global
 // memory as it is (one job per lane: 96/192-byte records `stride` apart); the kernels pass tc_stage.h's WaveRowIO
@@ -282,7 +292,7 @@ struct DirectIO {
 };
 
 // combination through the small-index fast path (tc_threshold.h); false => not applicable (or !live)
-template <class F, int K, class IO>
+template <class F, int K, class IO, bool ARENA = false>
 TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t* status) {
   uint64_t c_abs[K], d_abs = 1;
   bool c_neg[K], d_neg = false;
@@ -311,9 +321,9 @@ TC_HD bool job_combine_small_io(const uint64_t* idx, bool live, IO& io, uint8_t*
     } else {
       // (G2: out of line -- its own register allocation: the kernel's private segment drops from 8.0 to 5.6 KB at the
       // same speed; the one-lane G1 kernel measured 3 % slower that way)
-      Jac<F> a = (JobLanes<F>::N > 1) ? straus_small_call<F, K>(pts, c_abs) : straus_small<F, K>(pts, c_abs);
+      Jac<F> a = (JobLanes<F>::N > 1) ? straus_small_call<F, K>(pts, c_abs) : straus_small<F, K, ARENA>(pts, c_abs);
       TC_MARK(2);
-      const Jac<F> q = combine_divide(a, d_abs, d_neg);
+      const Jac<F> q = ARENA ? combine_divide_arena(a, d_abs, d_neg) : combine_divide(a, d_abs, d_neg);
       TC_MARK(4);
       const Affine<F> qa = jac_to_affine(q);
       TC_MARK(5);

@@ -65,8 +65,10 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
 size_t lagrange_all_ws_words(size_t t, size_t B);
 void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
                          uint8_t* status);
+// ta: the table arena when B > kG1ArenaMinJobs (the fast path then runs its two-waves-per-SIMD build), else {nullptr, nullptr}
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general);
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general,
+                       TableArena ta = TableArena{nullptr, nullptr});
 // `T: IntoFr` abscissae beyond u64 (tc_combine_g{1,2}_fr_batch): idx_fr = B x n_per_job x 8 canonical LE words.
 //   launch_fr_idx_narrow   idx64[i] = the value when it fits 64 bits; *wide counts the ones that do not; valid[j] (preset
 //                          to 1) is cleared for a job that owns a non-canonical encoding (>= r) among its first `take`

@@ -391,7 +391,7 @@ TC_HD uint32_t wave_max_u32(uint32_t v) {
 // sum_k c_k * P_k for K <= 4 points and 64-bit scalars: the joint ladder over the subset-sum table, with every special
 // case of the addition handled (the slow path of straus_small below)
 template <class F, int K>
-TC_HD_NOINLINE Jac<F> straus_small_safe(const Jac<F>* tbl, const uint64_t* c, uint32_t bits) {
+TC_HD Jac<F> straus_small_safe_body(const Jac<F>* tbl, const uint64_t* c, uint32_t bits) {
   Jac<F> acc = Jac<F>::infinity();
   TC_NOUNROLL for (int bit = (int)bits - 1; bit >= 0; bit--) {
     acc = jac_dbl(acc);
@@ -401,10 +401,14 @@ TC_HD_NOINLINE Jac<F> straus_small_safe(const Jac<F>* tbl, const uint64_t* c, ui
   }
   return acc;
 }
+template <class F, int K>
+TC_HD_NOINLINE Jac<F> straus_small_safe(const Jac<F>* tbl, const uint64_t* c, uint32_t bits) { return straus_small_safe_body<F, K>(tbl, c, bits); }
 // The fast form: a `started` flag instead of tests for the identity, the branch-free generic addition
 // (tc_curve.h jac_add_generic), and a second pass through straus_small_safe for the lanes that may have met a special
-// case (an input or a subset sum at infinity, P = +-Q).
-template <class F, int K>
+// case (an input or a subset sum at infinity, P = +-Q).  INLINE_SAFE: the fallback inlined too, so that the CALLING KERNEL's launch
+// bounds govern its registers -- an out-of-line device routine has none of its own, and the fallback's 38 accumulation registers
+// dropped the two-waves-per-SIMD build of the G1 combine kernel to one ("failed to meet occupancy target").
+template <class F, int K, bool INLINE_SAFE = false>
 TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
   Jac<F> tbl[1 << K];
   tbl[0] = Jac<F>::infinity();
@@ -437,7 +441,7 @@ TC_HD Jac<F> straus_small(const Affine<F>* pts, const uint64_t* c) {
       started = started || take;
     }
   }
-  if (wave_any(exc)) acc = Jac<F>::select(exc, straus_small_safe<F, K>(tbl, c, bits), acc);
+  if (wave_any(exc)) acc = Jac<F>::select(exc, INLINE_SAFE ? straus_small_safe_body<F, K>(tbl, c, bits) : straus_small_safe<F, K>(tbl, c, bits), acc);
   return acc;
 }
 
