@@ -160,6 +160,9 @@ def parse_args(argv=None):
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 captures (tools/capture_r03.sh): skip the legs that launch the headline kernels on OTHER work "
                          "(general-path and checked-input combines), so that a kernel's per-launch averages describe one kind of launch")
+    ap.add_argument("--latency-table", action="store_true",
+                    help="instead of the bench line: call latency (host buffers in, results back) of sign / combine / verify / decrypt at "
+                         "B = 1 ... 4096 next to ONE core of the CPU port -- the small-request table of INTEGRATION.md")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks, only with --test-engine")
     ap.add_argument("--test-engine", default=None, choices=[None, "hostsim"],
                     help="TEST HARNESS: tests/hostsim (g++ build of the device source) instead of the GPU; needs --backend gloo")
@@ -259,6 +262,9 @@ def main(argv=None):
         # from_bytes either.  `extras.combine_with_input_checks_per_s` is the same step with them on.
         eng.set_input_checks(False)
         peak = measure_peak() if rank == 0 else dict(PEAK_RECORDED)
+    if args.latency_table:
+        latency_table(eng)
+        return None
     if args.config == 5:
         from threshold_crypto_amd import config5
         result = config5.run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=cpu_baseline_config5)
@@ -620,6 +626,82 @@ def run_config2(args, eng, dev, rank, world, peak):
         "secondary_rooflines": legs,
         "cpu_baseline": cpu,
     }
+
+
+def latency_table(eng):
+    """Small requests.  The reference's API is single-item (SecretKeyShare::sign src/lib.rs:447, PublicKeySet::combine_signatures
+    :608, PublicKey::verify :115, PublicKeySet::decrypt :618); a GPU call costs the latency of ONE wave's job however few jobs it
+    carries.  Per entry and batch size B: wall time of one call with HOST buffers (staging copies included; median of 7 after a
+    warm-up), the kernel time inside it, the resulting jobs per second -- next to ONE host core of Oracle B on the same jobs (the
+    cpu_baseline leg: `kind: port`), and the smallest B from which the call beats that core.  One JSON line per entry."""
+    import numpy as np
+    from threshold_crypto_amd.engine import pack_messages
+    from threshold_crypto_amd.workload import ThresholdSigWorkload, ThresholdEncWorkload
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    c_oracle.load()
+    t, N, BMAX = 3, 10, 4096
+    sizes = [1, 8, 64, 1024, 4096]
+    eng.set_timing(True)
+    eng.set_input_checks(True)          # the context's default: what a caller that hands over received shares gets
+    wl = ThresholdSigWorkload(eng, t, N, BMAX)
+    we = ThresholdEncWorkload(eng, t, N, BMAX)
+    sig, st = eng.combine_g2(t, wl.idx, wl.shares)
+    sk = wl.shares_sk[0]._bytes()
+    fr = np.frombuffer(sk, dtype=np.uint8)[None].copy()
+
+    def med(fn, reps=7):
+        fn()
+        wall, kern = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            wall.append(time.perf_counter() - t0)
+            kern.append(eng.last_kernel_ms())
+        return sorted(wall)[reps // 2] * 1e3, sorted(kern)[reps // 2]
+
+    def cpu_time(fn, n):
+        t0 = time.perf_counter()
+        for j in range(n):
+            fn(j)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def msgs(B):
+        return pack_messages(wl.msgs[:B])
+
+    entries = {
+        "sign (SecretKeyShare::sign: hash_g2 + [sk] H)": (
+            lambda B: (lambda m=msgs(B): eng.sign(fr, m[0], m[1])),
+            lambda j: c_oracle.sign(sk, wl.msgs[j])),
+        "combine_signatures (t = 3, membership tests on the 4 shares: the context's default)": (
+            lambda B: (lambda: eng.combine_g2(t, wl.idx[:B].copy(), wl.shares[:B].copy())),
+            lambda j: c_oracle.combine_g2(t, [int(i) for i in wl.idx[j]], [bytes(x) for x in wl.shares[j]])),
+        "verify (PublicKey::verify: hash_g2 + pairing check, membership test on the signature)": (
+            lambda B: (lambda m=msgs(B): eng.verify_sig(wl.master_pk, sig[:B].copy(), m[0], m[1])),
+            lambda j: c_oracle.verify(bytes(wl.master_pk), bytes(sig[j]), wl.msgs[j])),
+        "decrypt (Ciphertext::verify + PublicKeySet::decrypt, t = 3)": (
+            lambda B: (lambda: (eng.ciphertext_verify(we.u[:B].copy(), we.v[:32 * B].copy(), we.off[:B + 1].copy(), we.w[:B].copy()),
+                                eng.decrypt(t, we.idx[:B].copy(), we.shares[:B].copy(), we.v[:32 * B].copy(), we.off[:B + 1].copy()))),
+            lambda j: (c_oracle.ciphertext_verify(bytes(we.u[j]), bytes(we.v[32 * j:32 * j + 32]), bytes(we.w[j])),
+                       c_oracle.threshold_decrypt(t, [int(i) for i in we.idx[j]], [bytes(x) for x in we.shares[j]], bytes(we.v[32 * j:32 * j + 32])))),
+    }
+    for name, (gpu, cpu) in entries.items():
+        cpu_ms = cpu_time(cpu, 6)
+        rows, crossover = [], None
+        for B in sizes:
+            wall_ms, kern_ms = med(gpu(B))
+            rows.append({"B": B, "call_ms": round(wall_ms, 3), "kernel_ms": round(kern_ms, 3), "jobs_per_s": round(B / (wall_ms * 1e-3), 1)})
+            if crossover is None and wall_ms < B * cpu_ms:
+                crossover = B
+        # refine the crossover between the last losing and the first winning size
+        if crossover and crossover > 1:
+            lo = sizes[sizes.index(crossover) - 1]
+            for B in range(lo + 1, crossover + 1):
+                if med(gpu(B), 3)[0] < B * cpu_ms:
+                    crossover = B
+                    break
+        print(json.dumps({"entry": name, "one_cpu_core_ms_per_job": round(cpu_ms, 3), "cpu_is": "Oracle B (oracle/c/tc_oracle.c), one host core",
+                          "gpu_rows": rows, "gpu_call_beats_one_core_from_B": crossover}), flush=True)
 
 
 def cpu_baseline(wl, gpu_sigs, t, seconds):

@@ -499,6 +499,7 @@ def test_config5_one_gpu_slice_properties(engine):
     assert res["status_errors"] == 0 and res["valid_local"] == B == res["valid_total"]
     msk = res["secret_key_set"].poly[0]
     msig, st = engine.g2_mul(torch.from_numpy(u8(msk.to_bytes(32, "little"))[None].copy()).cuda(), res["hashes"])
+    engine.sync()   # device-I/O calls return before their kernels have run (the context's own stream): wait before torch reads
     assert not st.any() and bool((msig[:, 0].cpu() == torch.from_numpy(res["sig"])).all())
     km, hashes = res["key_material"], res["hashes"].cpu().numpy()
     for j in sorted({0, 1, 2, B // 2, B - 2, B - 1}):
@@ -529,6 +530,7 @@ def test_config5_full_batch_eight_slices_on_one_gpu(engine):
         assert res["status_errors"] == 0 and res["valid_local"] == B, (r, res["status_errors"], res["valid_local"])
         msk = res["secret_key_set"].poly[0]
         msig, st = engine.g2_mul(torch.from_numpy(u8(msk.to_bytes(32, "little"))[None].copy()).cuda(), res["hashes"])
+        sync()      # device-I/O calls return before their kernels have run (the context's own stream): wait before torch reads
         assert not st.any() and bool((msig[:, 0].cpu() == torch.from_numpy(res["sig"])).all()), r
         km = res["key_material"]
         for j in (0, B // 2, B - 1):

@@ -188,6 +188,7 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
         master_sk = res["secret_key_set"].poly[0]
         msk = torch.from_numpy(np.frombuffer(master_sk.to_bytes(32, "little"), dtype=np.uint8)[None].copy())
         msig, _ = eng.g2_mul(msk.to(dev) if cuda else msk.numpy(), res["hashes"])
+        eng.sync()      # device-I/O calls return before their kernels have run: wait before torch copies the result
         msig = msig.cpu() if hasattr(msig, "cpu") else torch.from_numpy(np.asarray(msig))
         assert bool((msig[:, 0] == torch.from_numpy(res["sig"])).all().item()), "combine != master-key signature"
 
