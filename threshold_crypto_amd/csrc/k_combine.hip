@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_combine_fast_g1_arena(size_t t, s
 }
 
 template <class F>
-__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_combine_general(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1_AUX)) void k_combine_general(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                     const uint8_t* __restrict__ shares,
                                                     const uint32_t* __restrict__ lam, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status,
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
 // one lane per job: sum_i scalar_i * point_i with caller-supplied scalars (32 B LE each); the points of job
 // j start at points + j * pts_stride (n * PB for per-job points, 0 for ONE point set shared by every job)
 template <class F>
-__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1)) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
+__global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVES_G1_AUX)) void k_lincomb(size_t n, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points, size_t pts_stride, size_t B,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status, TableArena ta) {
   constexpr int PB = PointIO<F>::BYTES;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kFbBlock, 2) void k_g1_fixed_base(const int32_t* __
 }
 
 // out[(m * (degree + 1) + i)] = BivarCommitment::row(xs[m])[i]
-__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_bivar_commitment_row(const uint8_t* __restrict__ commit, size_t degree,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1_AUX) void k_bivar_commitment_row(const uint8_t* __restrict__ commit, size_t degree,
                                                                             const uint64_t* __restrict__ xs, size_t M,
                                                                             uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_encrypt(const uint8_t* 
   table_slot_release(ta, tslot);
 }
 
-__global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_commitment_evaluate(const uint8_t* __restrict__ commit, size_t t,
+__global__ __launch_bounds__(kBlock, TC_WAVES_G1_AUX) void k_commitment_evaluate(const uint8_t* __restrict__ commit, size_t t,
                                                                 const uint64_t* __restrict__ idx, size_t M,
                                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
   const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;

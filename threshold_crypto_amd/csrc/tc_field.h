@@ -558,12 +558,23 @@ __device__ TC_MULCALL_ATTR FqRaw fq2p_mul_call(int32_t a0, int32_t a1, int32_t a
   const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13};
   int32_t y[FQ_LIMBS], z[FQ_LIMBS], w[FQ_LIMBS];
   const int32_t mneg = odd - 1;  // even lane: -1 (negate the partner's coefficient), odd lane: 0
+#if defined(TC_MUL_SWIZZLE)
+  // experiment (r04): the operand exchange through the LDS crossbar (ds_swizzle, no memory access) instead of DPP moves: a
+  // v_mov_b32_dpp occupies the VALU as long as a multiply-add (4.2 cycles, tools/ubench_issue), a swizzle issues on the LDS pipe
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int32_t ao = __builtin_amdgcn_ds_swizzle(a[i], 0x80B1);
+    y[i] = __builtin_amdgcn_ds_swizzle(b[i], 0x80A0);
+    w[i] = __builtin_amdgcn_ds_swizzle(b[i], 0x80F5);
+    z[i] = (ao ^ mneg) - mneg;
+  }
+#else
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
     const int32_t ao = pair_swap(a[i]);
     y[i] = __builtin_amdgcn_mov_dpp(b[i], 0xA0, 0xF, 0xF, true);  // b0 on both lanes
     w[i] = __builtin_amdgcn_mov_dpp(b[i], 0xF5, 0xF, 0xF, true);  // b1 on both lanes
     z[i] = (ao ^ mneg) - mneg;
   }
+#endif
   FqRaw r;
   fq_mul2_body(a, y, z, w, r.l);
   return r;
@@ -574,12 +585,21 @@ __device__ TC_MULCALL_ATTR FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a
   int32_t x[FQ_LIMBS], y[FQ_LIMBS];
   int32_t even = odd - 1;  // even lane: all ones
   asm("" : "+v"(even));   // opaque: keeps the AND (one v_and_b32_dpp) from becoming a compare and a select
+#if defined(TC_MUL_SWIZZLE)
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int32_t a1 = __builtin_amdgcn_ds_swizzle(a[i], 0x80F5);
+    const int32_t a0 = __builtin_amdgcn_ds_swizzle(a[i], 0x80A0);
+    x[i] = a[i] + a1;
+    y[i] = a0 - (a1 & even);                  // even lane: a0 - a1; odd lane: a0
+  }
+#else
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
     const int32_t a1 = __builtin_amdgcn_mov_dpp(a[i], 0xF5, 0xF, 0xF, true);  // the odd lane's coefficient, on both lanes
     const int32_t a0 = __builtin_amdgcn_mov_dpp(a[i], 0xA0, 0xF, 0xF, true);  // the even lane's
     x[i] = a[i] + a1;                         // a0 + a1 | 2 a1
     y[i] = a0 - (pair_swap(a[i]) & even);     // a0 - a1 | a0
   }
+#endif
   FqRaw r;
   fq_mul_body<false>(x, y, r.l);
   return r;

@@ -17,6 +17,12 @@ namespace tc {
 #ifndef TC_WAVES_G1
 #define TC_WAVES_G1 1
 #endif
+// the G1 kernels of the paths beside the headline (Commitment::evaluate, BivarCommitment::row, the general-path combination and
+// small linear combinations): built for 256 registers.  One lane per job gives a 65 536-job batch one wave per SIMD whatever the
+// build, and from 131 072 jobs on the second wave is worth 4-15 % although 100-250 registers spill (r04: profiles/r04_g1_aux_probe.txt)
+#ifndef TC_WAVES_G1_AUX
+#define TC_WAVES_G1_AUX 2
+#endif
 constexpr int kBlock = 64;  // one wavefront per workgroup: the jobs are register/scratch heavy
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
