@@ -59,7 +59,7 @@ MAC_PER_FQMUL = 300
 # work outside (inversions, root exponentiations) is done by both and counted twice.
 EXECUTED_MACS = json.load(open(os.path.join(ROOT, "profiles", "executed_macs.json")))
 # algorithmic bytes per unit (canonical uncompressed affine I/O)
-ALG_BYTES = {"combine_g2": lambda t: (t + 1) * (192 + 8) + 192, "verify_g2": lambda t: 385, "g2_mul": lambda t: 192,
+ALG_BYTES = {"combine_g2": lambda t: (t + 1) * (192 + 8) + 192, "combine_g2_wire": lambda t: (t + 1) * (96 + 8) + 96, "verify_g2": lambda t: 385, "g2_mul": lambda t: 192,
              "hash_g2": lambda t: 207, "combine_g1": lambda t: (t + 1) * (96 + 8) + 96 + 32,
              "ciphertext_verify": lambda t: 96 + 32 + 192 + 1}
 # Roofline peak: the issue rate of the multiplier's own instruction (v_mad_i64_i32) with every SIMD full,
@@ -532,13 +532,13 @@ def run_config2(args, eng, dev, rank, world, peak):
         legs["threshold_decrypt"] = roofline("k_combine_fast<Fq> + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
                                              "combine_g1", t, B, dec_kernel_ms, peak)
         cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS.get("hash_g1_g2", EXECUTED_MACS["hash_g2"])
-        legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_loop + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
+        legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
                                              cv_kernel_ms, peak, executed=cv_macs)
         config4 = {"value": round(B * world / (e2 - e0), 1), "unit": "threshold_decryptions/s", "ms_per_step": round((e2 - e0) * 1e3, 3),
                    "is": "BASELINE config 4: Ciphertext::verify (hash_g1_g2 + pairing check) then PublicKeySet::decrypt (G1 combine + "
                          "keystream) over the batch; every plaintext compared with the workload's",
                    "kernel_ms": {"ciphertext_verify": round(cv_kernel_ms, 3), "decrypt": round(dec_kernel_ms, 3)},
-                   "roofline": roofline("k_hash_g1_g2 + k_miller_loop + k_final_exp + k_combine_fast<Fq> + k_xor_with_hash", None, None,
+                   "roofline": roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast<Fq> + k_xor_with_hash", None, None,
                                         "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
                                         executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"])}
     if not args.no_extras and not harness and not args.profile_run:
@@ -552,6 +552,35 @@ def run_config2(args, eng, dev, rank, world, peak):
         extras["combine_with_input_checks_per_s"] = round(B * world / (time.perf_counter() - c0), 1)
         eng.set_input_checks(False)
         assert bool((csig == sig).all().item()) and int(cst.to(torch.int32).sum().item()) == 0
+    wire = None
+    if not args.no_extras and not harness and not args.profile_run and cuda and t >= 1:
+        # ---- the wire-level combine: 96-byte shares in, 96-byte signature out (checked decode + combine + to_bytes) ----------
+        comp, cst2 = eng.g2_compress(d_shares.reshape(B * (t + 1), 192))
+        d_wire = comp.reshape(B, t + 1, 96).contiguous()
+        eng.set_timing(True)
+        wsig, wst = eng.combine_signatures_wire(t, d_idx, d_wire)
+        wire_ms = []
+        w0 = None
+        for _ in range(3):
+            sync()
+            w0 = time.perf_counter()
+            wsig, wst = eng.combine_signatures_wire(t, d_idx, d_wire)
+            sync()
+            wire_ms.append((time.perf_counter() - w0, eng.last_kernel_ms()))
+        eng.set_timing(False)
+        want, _ = eng.g2_compress(sig)
+        sync()
+        assert int(wst.to(torch.int32).sum().item()) == 0 and bool((wsig == want).all().item()), "wire-level combine differs from compress(combine)"
+        wall, kern = min(wire_ms)
+        wire_macs = (t + 1) * EXECUTED_MACS["g2_decompress"] + EXECUTED_MACS["combine_g2_t3_fast"]
+        wire = {"value": round(B * world / wall, 1), "unit": "combine_signatures/s", "ms_per_step": round(wall * 1e3, 3),
+                "is": "tc_combine_signatures_wire_batch on the BASELINE batch: %d compressed shares per job through the checked decode of from_bytes "
+                      "(square root + membership test each), combined, returned as Signature::to_bytes; result compared with "
+                      "compress(combine) of the timed batch" % (t + 1),
+                "algorithmic_bytes_per_job": (t + 1) * (96 + 8) + 96,
+                "roofline": roofline("k_decompress_take<Fq2> + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak,
+                                     executed=wire_macs) if t == 3 else None}
+        extras["wire_combine_per_s"] = wire["value"]
     if not args.no_extras and not harness and not args.profile_run:
         # ---- the same combine with HOST buffers at the C ABI (pageable numpy memory): PCIe-inclusive ---------
         eng.combine_g2(t, wl.idx, wl.shares)
@@ -583,7 +612,7 @@ def run_config2(args, eng, dev, rank, world, peak):
                                           "of 2048 waves and lasts as long as its slowest denominator class, whose waves run "
                                           "at frac_slowest_class (DESIGN.md 5.2)"})
     if not harness:
-        legs["pairing_check"] = roofline("k_miller_loop + k_final_exp", "verify_g2", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
+        legs["pairing_check"] = roofline("k_miller_lines + k_miller_accumulate + k_final_exp (above 16 384 checks; k_pairing_quad below)", "verify_g2_prepared", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
                                          traffic_key="pairing_check")
         legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak)
     # the CPU leg runs on rank 0 of a one-GPU run only (N ranks would time N oracles against each other on one host)
@@ -614,6 +643,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         "general_path": general,
         "config3": config3,
         "config4": config4,
+        "wire": wire,
         "pairing_verifies_per_s": round(B * world / min(verify_dt, verify_if_dt or verify_dt), 1),
         "pairing_verifies_sequential_per_s": round(B * world / verify_dt, 1),
         "pairing_verify_kernel_ms": round(verify_kernel_ms, 3),

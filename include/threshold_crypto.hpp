@@ -34,6 +34,40 @@ using G1Bytes = std::array<std::uint8_t, 96>;
 using G2Bytes = std::array<std::uint8_t, 192>;
 using FrBytes = std::array<std::uint8_t, 32>;
 
+// An index type beyond u64 -- `T: IntoFr` of combine_signatures / decrypt (src/lib.rs:608-622) for T = Fr, i32, i64
+// (src/into_fr.rs:10-14, 28-56): the field element as 32 little-endian bytes, ordered by its canonical value like the derived
+// Ord of pairing's Fr, so a std::map keyed by it iterates as the reference's BTreeMap<Fr, _> does.
+struct FrIndex {
+  FrBytes le{};
+  static FrIndex from_u64(std::uint64_t x) {
+    FrIndex f;
+    for (int i = 0; i < 8; i++) f.le[i] = (std::uint8_t)(x >> (8 * i));
+    return f;
+  }
+  // IntoFr for i64: a negative value is -(|x|) mod r
+  static FrIndex from_i64(std::int64_t x) {
+    if (x >= 0) return from_u64((std::uint64_t)x);
+    static const std::uint8_t R[32] = {0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
+                                       0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73};
+    const std::uint64_t m = (std::uint64_t)0 - (std::uint64_t)x;  // |x|
+    FrIndex f;
+    int borrow = 0;
+    for (int i = 0; i < 32; i++) {
+      const int sub = (i < 8 ? (int)((m >> (8 * i)) & 0xff) : 0) + borrow;
+      const int d = (int)R[i] - sub;
+      f.le[i] = (std::uint8_t)(d & 0xff);
+      borrow = d < 0 ? 1 : 0;
+    }
+    return f;
+  }
+  bool operator<(const FrIndex& o) const {
+    for (int i = 31; i >= 0; i--)
+      if (le[i] != o.le[i]) return le[i] < o.le[i];
+    return false;
+  }
+  bool operator==(const FrIndex& o) const { return le == o.le; }
+};
+
 // threshold_crypto::error::Error (src/error.rs:7-17)
 enum class Error { NotEnoughShares = 1, DuplicateEntry = 2 };
 struct ErrorException : std::runtime_error {
@@ -391,6 +425,46 @@ class PublicKeySet {
     if (B) e.check(tc_combine_g2_batch(e.ctx(), threshold(), n, idx.data(), sh.data(), B, flat.data(), status.data()));
     std::vector<Signature> out(B);
     for (std::size_t j = 0; j < B; j++) std::memcpy(out[j].g2.data(), &flat[j * 192], 192);
+    return out;
+  }
+
+  // the same with `T: IntoFr` keys beyond u64 (Fr values, negative i64: FrIndex above) -- tc_combine_g2_fr_batch
+  Signature combine_signatures(const std::map<FrIndex, SignatureShare>& shares, Engine& e = Engine::instance()) const {
+    const std::size_t n = shares.size();
+    std::vector<std::uint8_t> idx(n * 32 + 1), sh(n * 192 + 1);
+    std::size_t k = 0;
+    for (const auto& kv : shares) {
+      std::memcpy(&idx[k * 32], kv.first.le.data(), 32);
+      std::memcpy(&sh[k * 192], kv.second.sig.g2.data(), 192);
+      k++;
+    }
+    Signature out;
+    std::uint8_t st = 0;
+    e.check(tc_combine_g2_fr_batch(e.ctx(), threshold(), n, idx.data(), sh.data(), 1, out.g2.data(), &st));
+    raise_status(st);
+    return out;
+  }
+  // Wire-level combine_signatures: (index, SignatureShare::to_bytes) pairs in the order the reference's map would iterate; the
+  // shares pass the checked decode of from_bytes (src/lib.rs:246-252) on the device, the result is Signature::to_bytes
+  // (src/lib.rs:255-259).  status: 0, 1 = NotEnoughShares, 3 = FromBytesError::Invalid for a job that owns a bad share.
+  std::vector<std::array<std::uint8_t, SIG_SIZE>> combine_signatures_wire_batch(
+      const std::vector<std::vector<std::pair<std::uint64_t, std::array<std::uint8_t, SIG_SIZE>>>>& jobs, std::vector<std::uint8_t>& status,
+      Engine& e = Engine::instance()) const {
+    const std::size_t B = jobs.size();
+    const std::size_t n = B ? jobs[0].size() : 0;
+    std::vector<std::uint64_t> idx(B * n + 1);
+    std::vector<std::uint8_t> sh(B * n * SIG_SIZE + 1), flat(B * SIG_SIZE + 1);
+    for (std::size_t j = 0; j < B; j++) {
+      if (jobs[j].size() != n) throw std::invalid_argument("all jobs of one batch must supply the same number of shares");
+      for (std::size_t k = 0; k < n; k++) {
+        idx[j * n + k] = jobs[j][k].first;
+        std::memcpy(&sh[(j * n + k) * SIG_SIZE], jobs[j][k].second.data(), SIG_SIZE);
+      }
+    }
+    status.assign(B, 0);
+    if (B) e.check(tc_combine_signatures_wire_batch(e.ctx(), threshold(), n, idx.data(), sh.data(), B, flat.data(), status.data()));
+    std::vector<std::array<std::uint8_t, SIG_SIZE>> out(B);
+    for (std::size_t j = 0; j < B; j++) std::memcpy(out[j].data(), &flat[j * SIG_SIZE], SIG_SIZE);
     return out;
   }
 

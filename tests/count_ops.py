@@ -173,6 +173,9 @@ res["hash_g1_g2"] = (cnt(), 2)
 a = rnd.randrange(o.R)
 L.hs_pairing_check(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
                    o.g2_uncompressed(o.E2.mul(P2, a))); res["verify_g2"] = (cnt(), 2)
+# the prepared form (k_miller_lines + k_miller_accumulate + k_final_exp: what batches above 16 384 checks run)
+L.hs_pairing_check_prepared(o.g1_uncompressed(o.E1.mul(o.G1_GEN, a)), o.g2_uncompressed(P2), o.g1_uncompressed(o.G1_GEN),
+                            o.g2_uncompressed(o.E2.mul(P2, a))); res["verify_g2_prepared"] = (cnt(), 2)
 tot = [0] * 5
 N = 64
 for j in range(N):

@@ -3,7 +3,8 @@
 // Built and run by tests/test_gpu_cpp_api.py on the GPU box; key material and expected values come
 // from a fixture file the Python test writes with the oracle.
 //   fixture: u32 t, u32 n | n x 32 B share scalars | (t+1) x 96 B commitment | u32 msg_len, msg |
-//            192 B expected combined signature | ciphertext: 96 B u, u32 vlen, v, 192 B w | u32 plen, plaintext
+//            192 B expected combined signature | ciphertext: 96 B u, u32 vlen, v, 192 B w | u32 plen, plaintext |
+//            (r04) 4 x (i64 index, 32 B share scalar of that index): negative / large `T: IntoFr` keys
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -40,6 +41,13 @@ int main(int argc, char** argv) {
   Ciphertext ct; rd(f, ct.u.data(), 96); rd(f, &len, 4); ct.v.resize(len); rd(f, ct.v.data(), len); rd(f, ct.w.data(), 192);
   rd(f, &len, 4); Bytes plain(len); rd(f, plain.data(), len);
 
+  std::vector<std::pair<std::int64_t, SecretKeyShare>> odd;   // shares at indices u64 cannot carry (IntoFr for i64)
+  for (int i = 0; i < 4; i++) {
+    std::int64_t ix; FrBytes fr;
+    rd(f, &ix, 8); rd(f, fr.data(), 32);
+    odd.emplace_back(ix, SecretKeyShare(fr));
+  }
+
   PublicKeySet pk_set(commit);
   CHECK(pk_set.threshold() == t);
 
@@ -75,6 +83,22 @@ int main(int argc, char** argv) {
   for (auto s : st) CHECK(s == 0);
   auto ok = pk_set.public_key().verify_batch(combined, m);
   for (bool b : ok) CHECK(b);
+
+  // -- `T: IntoFr` keys beyond u64 (src/into_fr.rs: i64 negatives) and the wire-level combine (round 4) -------------------
+  {
+    std::map<FrIndex, SignatureShare> fsigs;
+    for (auto& kv : odd) fsigs[FrIndex::from_i64(kv.first)] = kv.second.sign(msg);
+    CHECK(pk_set.combine_signatures(fsigs) == expected);
+    CHECK(FrIndex::from_i64(-1) < FrIndex::from_i64(-1) == false && FrIndex::from_u64(5) < FrIndex::from_i64(-7));
+    std::vector<std::vector<std::pair<std::uint64_t, std::array<std::uint8_t, SIG_SIZE>>>> wjobs(3);
+    for (std::size_t j = 0; j < 3; j++)
+      for (const auto& kv : jobs[j]) wjobs[j].emplace_back(kv.first, kv.second.sig.to_bytes());
+    wjobs[2][1].second[5] ^= 0x01;   // a share that no longer decodes to a group member
+    std::vector<std::uint8_t> wst;
+    auto wire = pk_set.combine_signatures_wire_batch(wjobs, wst);
+    CHECK(wst[0] == 0 && wst[1] == 0 && wst[2] == 3);
+    CHECK(wire[0] == combined[0].to_bytes() && wire[1] == combined[1].to_bytes() && wire[2][0] == 0xc0);
+  }
 
   // -- test_from_to_bytes -----------------------------------------------------------------------
   CHECK(Signature::from_bytes(sig.to_bytes()) == sig);

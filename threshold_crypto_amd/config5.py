@@ -230,7 +230,7 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
         "share_sign": roofline("k_comb_tables + k_comb_sign" if (t + 1 >= 24 and B >= 8192) else "k_g2_mul_gather",
                                "g2_sign_comb_68_signers" if (t + 1 >= 24 and B >= 8192) else "g2_mul_gather_68_signers", "g2_mul", "g2_mul", t,
                                (t + 1) * B, float(ms[0]), peak),
-        "pairing_check": roofline("k_miller_loop + k_final_exp", "verify_g2", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
+        "pairing_check": roofline("k_miller_lines + k_miller_accumulate + k_final_exp", "verify_g2_prepared", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
     }
     cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline and world == 1 and not harness) else None
     return {
