@@ -604,6 +604,23 @@ __device__ TC_MULCALL_ATTR FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a
   fq_mul_body<false>(x, y, r.l);
   return r;
 }
+// the squaring INLINED (r04): for the one loop that is short enough to stay in the instruction cache with six of them in its body
+// -- the compressed cyclotomic squaring chain of the final exponentiation (tc_tower.h CycloCompressed::sqr_t): no argument /
+// result moves, no call, and the six independent squarings of a step interleave
+__device__ __forceinline__ FqRaw fq2p_sqr_inl(const int32_t* a, int32_t odd) {
+  int32_t x[FQ_LIMBS], y[FQ_LIMBS];
+  int32_t even = odd - 1;
+  asm("" : "+v"(even));
+  TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {
+    const int32_t a1 = __builtin_amdgcn_mov_dpp(a[i], 0xF5, 0xF, 0xF, true);
+    const int32_t a0 = __builtin_amdgcn_mov_dpp(a[i], 0xA0, 0xF, 0xF, true);
+    x[i] = a[i] + a1;
+    y[i] = a0 - (pair_swap(a[i]) & even);
+  }
+  FqRaw r;
+  fq_mul_body<false>(x, y, r.l);
+  return r;
+}
 #endif  // TC_PAIR
 #endif
 
