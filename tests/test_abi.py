@@ -137,3 +137,26 @@ def test_rust_shim_calls_existing_entry_points_with_matching_arity():
                  "tc_public_key_share_batch", "tc_g1_compress_batch", "tc_g2_decompress_batch", "tc_encrypt_batch",
                  "tc_verify_shares_rlc_batch", "tc_g1_commitment_batch", "tc_group_sign_combine_verify"):
         assert need in used, need
+
+
+def test_design_quotes_the_shipped_kernel_resources():
+    """DESIGN.md printed 1 931 spilled registers for a kernel whose shipped code object had 2 238.  Register,
+    scratch, LDS and spill figures now appear in DESIGN.md ONLY inside the block tools/kernel_resources.py generates from the
+    code objects bundled in threshold_crypto_amd/libtc_amd.so (.hip_fatbin -> offload bundles -> llvm-readelf --notes), next
+    to profiles/kernel_resources.json; this test unbundles the library again and fails on any difference."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(kr.LIB):
+        pytest.skip("libtc_amd.so not built")
+    table = kr.kernel_table()
+    assert len(table) >= 50 and "k_miller_lines" in table and "k_combine_fast<Fq2>" in table
+    assert json.load(open(kr.JSON)) == table, "run python tools/kernel_resources.py --write"
+    assert kr.design_block() == kr.markdown(table), "DESIGN.md's kernel-resources block is stale: run python tools/kernel_resources.py --write"
+    # the figures VERDICT r03 asked for, as properties of the shipped binary
+    assert table["k_miller_lines"]["spilled_vgprs"] < 300 and table["k_miller_accumulate"]["spilled_vgprs"] < 300
+    assert table["k_hash_g1_g2"]["spilled_sgprs"] < 100 and table["k_encrypt"]["spilled_sgprs"] < 100
+    assert table["k_g1_mul_arena"]["registers"] <= 256 and table["k_g1_mul_arena"]["of_which_agpr"] == 0
+    assert table["k_combine_fast_g1_arena"]["registers"] <= 256 and table["k_combine_fast_g1_arena"]["of_which_agpr"] == 0

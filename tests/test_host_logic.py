@@ -134,6 +134,57 @@ def test_config5_two_rank_gloo_pipeline_sharding_broadcast_gather():
         assert eng.L.hs_g2_mul(msk, bytes(single["hashes"][j]), b) == 0 and b.raw == single["sig"][j].tobytes()
 
 
+def _check_round4_lines(root, macs):
+    """round 4: the pairing check is three kernels (prepared lines), the line has a `wire` leg, the profile constants bench.py
+    embeds come from the capture committed with the line, and config 5 has run at its full 1 048 576 jobs on one GPU"""
+    import json
+    d = json.loads([l for l in open(os.path.join(root, "profiles", "r04_a_bench.txt")) if l.startswith("{")][-1])
+    B = d["config"]["batch_per_gpu"]
+    assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 == d["ranks"]["world_size"] and d["vs_baseline"] is None
+    assert d["config"]["overlapped"] is False and abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+    assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001 and d["streaming"]["value"] > d["value"]
+    legs = [d["roofline"], d["general_path"]["roofline"], d["config3"]["roofline"], d["config4"]["roofline"], d["wire"]["roofline"]]
+    legs += list(d["secondary_rooflines"].values())
+    for r in legs:
+        assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and r["hbm_frac"] < 0.01
+        want = r["executed_macs_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12
+        assert abs(r["achieved"] - want) / want < 2e-3
+        assert 36.0 < r["peak"] < 38.5                        # ONE denominator: the saturated v_mad_i64_i32 wall rate (DESIGN 5.1)
+    assert d["roofline"]["executed_macs_per_unit"] == macs["combine_g2_t3_fast"]
+    assert d["config3"]["roofline"]["executed_macs_per_unit"] == macs["verify_g2_prepared"] == macs["verify_g2"]
+    assert "k_miller_lines + k_miller_accumulate + k_final_exp" in d["config3"]["roofline"]["kernel"]
+    t = d["config"]["t"]
+    assert d["wire"]["roofline"]["executed_macs_per_unit"] == (t + 1) * macs["g2_decompress"] + macs["combine_g2_t3_fast"]
+    assert abs(d["wire"]["value"] - B / (d["wire"]["ms_per_step"] * 1e-3)) / d["wire"]["value"] < 2e-3
+    assert d["wire"]["value"] < d["value"]                    # the checked decode of t + 1 shares is most of the wire call
+    prof = json.load(open(os.path.join(root, "profiles", "profile_constants.json")))
+    assert prof["combine_g2_t3"]["source"] == "profiles/r04_a_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
+    assert prof["pairing_check"]["kernel"] == "k_miller_lines + k_miller_accumulate + k_final_exp"
+    assert d["config3"]["roofline"]["traffic"] == prof["pairing_check"]["traffic_bytes"] < 30e9        # was 41.7 GB in round 3
+    summary = open(os.path.join(root, "profiles", "r04_a_rocprofv3_summary.csv")).read()
+    avg = {}
+    for line in summary.splitlines():
+        f = line.split(",")
+        name = f[0].replace("void ", "")
+        if len(f) >= 12 and name in ("tc::k_combine_fast<tc::Fq2>", "tc::k_miller_lines", "tc::k_miller_accumulate", "tc::k_final_exp") and name not in avg:
+            avg[name] = float(f[3])
+    pair_ms = avg["tc::k_miller_lines"] + avg["tc::k_miller_accumulate"] + avg["tc::k_final_exp"]
+    assert abs(pair_ms - d["config3"]["kernel_ms"]) / pair_ms < 0.05
+    assert abs(avg["tc::k_combine_fast<tc::Fq2>"] - d["roofline"]["kernel_ms"]) / d["roofline"]["kernel_ms"] < 0.08
+    for k in ("k_g1_mul_arena", "k_hash_g1_g2", "k_msm_ladder", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+        assert k in summary, k
+    full = json.loads([l for l in open(os.path.join(root, "profiles", "r04_config5_full.txt")) if l.startswith("{")][-1])
+    assert full["config"]["emulated_world"] == 8 and full["n_gpus"] == 1 and full["config"]["batch_per_gpu"] == 1048576
+    assert full["valid_total_all_ranks"] == 1048576 and full["verified_all"] is True
+    recs = full["rank_records_start_jobs_valid_digest"]
+    assert [r[:3] for r in recs] == [[131072 * i, 131072, 131072] for i in range(8)] and len({r[3] for r in recs}) == 8
+    assert abs(full["value"] - 1048576 / (full["ms_per_step"] * 1e-3)) / full["value"] < 2e-3
+    one = json.loads([l for l in open(os.path.join(root, "profiles", "r04_config5_1gpu_bench.txt")) if l.startswith("{")][-1])
+    assert one["config"]["t"] == 67 and one["config"]["N"] == 200 and one["verified_all"] is True and one["config"]["batch_per_gpu"] == 131072
+    assert recs[0][3] == one["rank_records_start_jobs_valid_digest"][0][3]       # slice 0 of the emulation IS the 1-GPU run's slice
+    assert abs(full["value"] - one["value"]) / one["value"] < 0.03               # eight slices one after the other cost eight slices
+
+
 def test_committed_bench_lines_are_self_consistent():
     """The bench lines kept under profiles/ (what DESIGN.md quotes) obey the arithmetic of the contract: value =
     units / step time, frac = achieved / peak, achieved = executed multiply-adds x units / kernel time, every fraction a
@@ -183,9 +234,6 @@ def test_committed_bench_lines_are_self_consistent():
     assert d["config3"]["roofline"]["executed_macs_per_unit"] == macs["verify_g2"] and d["config3"]["kernel_ms"] == d["config3"]["roofline"]["kernel_ms"]
     assert d["config4"]["roofline"]["executed_macs_per_unit"] == macs["verify_g2"] + macs["hash_g1_g2"] + macs["combine_g1_t3_fast"]
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] / d["cpu_baseline"]["value"] > 100
-    prof = json.load(open(os.path.join(root, "profiles", "profile_constants.json")))
-    assert prof["combine_g2_t3"]["source"] == "profiles/r03_c_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
-    # (the line embeds the constants of the capture BEFORE it -- the capture that goes with it produces the next ones)
     assert d["roofline"]["traffic"] > 50 * d["roofline"]["algorithmic_bytes_per_launch"] and "profiles/" in d["roofline"]["traffic_is"]
     summary = open(os.path.join(root, "profiles", "r03_c_rocprofv3_summary.csv")).read()
     for k in ("k_combine_fast<tc::Fq2>", "k_miller_loop", "k_final_exp", "k_hash_g2", "k_hash_g1_g2", "k_g2_mul_shared", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
@@ -199,6 +247,7 @@ def test_committed_bench_lines_are_self_consistent():
     pair_ms = avg["tc::k_miller_loop"] + avg["tc::k_final_exp"]
     assert abs(pair_ms - d["config3"]["kernel_ms"]) / pair_ms < 0.05
     assert abs(avg["tc::k_combine_fast<tc::Fq2>"] - d["roofline"]["kernel_ms"]) / d["roofline"]["kernel_ms"] < 0.08   # (+ the small grouping kernels)
+    _check_round4_lines(root, macs)
     c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r03_config5_1gpu_bench.txt")) if l.startswith("{")][-1])
     assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True and c5["ranks"]["world_size"] == 1
     c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r02_config5_1gpu_bench.txt")) if l.startswith("{")][-1])

@@ -11,7 +11,9 @@ src = sys.argv[1]
 units = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 # per key: alternatives in order of preference; an alternative is one kernel or a tuple of kernels whose counters are summed
 # (the pairing check runs as k_miller_loop + k_final_exp since round 3)
-KERNELS = {"combine_g2_t3": ("k_combine_fast<tc::Fq2>", "k_combine<tc::Fq2>"), "pairing_check": (("k_miller_loop", "k_final_exp"), "k_pairing_check")}
+# (r04: k_miller_lines + k_miller_accumulate + k_final_exp above 16 384 checks)
+KERNELS = {"combine_g2_t3": ("k_combine_fast<tc::Fq2>", "k_combine<tc::Fq2>"),
+           "pairing_check": (("k_miller_lines", "k_miller_accumulate", "k_final_exp"), ("k_miller_loop", "k_final_exp"), "k_pairing_check")}
 vals = {}
 for line in open(src):
     f = line.rstrip("\n").split(",")
