@@ -1547,6 +1547,71 @@ EXPORT void or_threshold_decrypt_batch(size_t t, size_t n, const u64 *idx, const
   run_batch(p, B, nthreads);
 }
 
+/* ---- threaded drivers for the large-threshold tests (round 4): more jobs per test than a Python loop over the single-job
+ * functions can afford.  Each job is the composition of the single-job functions above, nothing else. ---- */
+typedef struct {
+  int kind; /* 0 = sign the n shares of a job and combine them, 1 = combine_g1, 2 = the n signature shares of a message */
+  size_t t, n, N, lo, hi;
+  const u64 *idx;
+  const uint8_t *a, *b;
+  uint8_t *out;
+  int *rc;
+} big_job;
+static void *big_worker(void *arg) {
+  big_job *j = (big_job *)arg;
+  uint8_t *sh = (uint8_t *)malloc(j->n * 192);
+  for (size_t k = j->lo; k < j->hi; k++) {
+    if (j->kind == 1) {
+      j->rc[k] = or_combine_g1(j->t, j->n, j->idx + k * j->n, j->a + k * j->n * 96, j->out + k * 96);
+      continue;
+    }
+    /* SecretKeyShare::sign_g2 (src/lib.rs:442-444) for the signers idx[k][0..n) of message k: a = the N x 32 B table of
+     * secret key shares, b = the hash point of every message */
+    int rc = 0;
+    uint8_t *dst = j->kind == 2 ? j->out + k * j->n * 192 : sh;
+    for (size_t s = 0; s < j->n && !rc; s++) {
+      const u64 who = j->idx[k * j->n + s];
+      rc = who < j->N ? or_g2_mul(j->a + who * 32, j->b + k * 192, dst + s * 192) : 3;
+    }
+    if (!rc && j->kind == 0) rc = or_combine_g2(j->t, j->n, j->idx + k * j->n, sh, j->out + k * 192);   /* src/lib.rs:608-615 */
+    j->rc[k] = rc;
+  }
+  free(sh);
+  return NULL;
+}
+static void run_big(big_job proto, size_t B, int nthreads) {
+  tc_init();
+  if (nthreads < 1) nthreads = 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  big_job *jobs = (big_job *)malloc(sizeof(big_job) * (size_t)nthreads);
+  for (int i = 0; i < nthreads; i++) {
+    jobs[i] = proto;
+    jobs[i].lo = B * (size_t)i / (size_t)nthreads;
+    jobs[i].hi = B * (size_t)(i + 1) / (size_t)nthreads;
+    pthread_create(&th[i], NULL, big_worker, &jobs[i]);
+  }
+  for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  free(th);
+  free(jobs);
+}
+/* B threshold signatures from scratch: job k signs hash[k] with the key shares sk_table[idx[k][*]] and combines the n shares */
+EXPORT void or_sign_combine_batch(size_t t, size_t n, size_t N, const uint8_t *sk_table, const u64 *idx, const uint8_t *hashes, size_t B,
+                                  uint8_t *out, int *rc, int nthreads) {
+  big_job p = {0, t, n, N, 0, 0, idx, sk_table, hashes, out, rc};
+  run_big(p, B, nthreads);
+}
+/* B combinations in G1 (PublicKeySet::decrypt's interpolate, src/lib.rs:618-626) */
+EXPORT void or_combine_g1_batch(size_t t, size_t n, const u64 *idx, const uint8_t *shares, size_t B, uint8_t *out, int *rc, int nthreads) {
+  big_job p = {1, t, n, 0, 0, 0, idx, shares, NULL, out, rc};
+  run_big(p, B, nthreads);
+}
+/* the n signature shares of each of B messages: out[k][s] = [sk_table[idx[k][s]]] hash[k]; an index >= N fails the message */
+EXPORT void or_sign_shares_batch(size_t n, size_t N, const uint8_t *sk_table, const u64 *idx, const uint8_t *hashes, size_t B, uint8_t *out,
+                                 int *rc, int nthreads) {
+  big_job p = {2, 0, n, N, 0, 0, idx, sk_table, hashes, out, rc};
+  run_big(p, B, nthreads);
+}
+
 /* checked decode of the compressed forms: EncodedPoint::into_affine (on-curve + [r]P == 0), the
  * check behind PublicKey::from_bytes (src/lib.rs:140-146) / Signature::from_bytes (:246-252) */
 static const u64 Q_P1_D4[6] = {0xee7fbfffffffeaabull, 0x07aaffffac54ffffull, 0xd9cc34a83dac3d89ull,

@@ -63,6 +63,12 @@ def load():
         _lib.or_decrypt_wire.argtypes = [sz, sz, vp, cp, cp, sz, cp]
         _lib.or_combine_signatures_wire_batch.argtypes = [sz, sz, vp, vp, sz, vp, vp, ctypes.c_int]
         _lib.or_combine_signatures_wire_batch.restype = None
+        _lib.or_sign_combine_batch.argtypes = [sz, sz, sz, vp, vp, vp, sz, vp, vp, ctypes.c_int]
+        _lib.or_sign_combine_batch.restype = None
+        _lib.or_combine_g1_batch.argtypes = [sz, sz, vp, vp, sz, vp, vp, ctypes.c_int]
+        _lib.or_combine_g1_batch.restype = None
+        _lib.or_sign_shares_batch.argtypes = [sz, sz, vp, vp, vp, sz, vp, vp, ctypes.c_int]
+        _lib.or_sign_shares_batch.restype = None
     return _lib
 
 
@@ -248,6 +254,46 @@ def combine_signatures_wire_batch(t, idx, shares96, nthreads):
     rc = np.zeros(B, dtype=np.int32)
     idx, shares96 = np.ascontiguousarray(idx), np.ascontiguousarray(shares96)
     load().or_combine_signatures_wire_batch(t, n, idx.ctypes.data, shares96.ctypes.data, B, out.ctypes.data, rc.ctypes.data, nthreads)
+    return out, rc
+
+
+def sign_combine_batch(t, sk_table, idx, hashes, nthreads):
+    """B threshold signatures from scratch on `nthreads` host threads: job k signs hashes[k] with the key shares
+    sk_table[idx[k][*]] (SecretKeyShare::sign_g2) and combines them (combine_signatures)."""
+    import numpy as np
+    sk_table = np.ascontiguousarray(sk_table, dtype=np.uint8)
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint8)
+    B, n = idx.shape
+    out = np.zeros((B, 192), dtype=np.uint8)
+    rc = np.zeros(B, dtype=np.int32)
+    load().or_sign_combine_batch(t, n, sk_table.shape[0], sk_table.ctypes.data, idx.ctypes.data, hashes.ctypes.data, B, out.ctypes.data,
+                                 rc.ctypes.data, nthreads)
+    return out, rc
+
+
+def combine_g1_batch(t, idx, shares, nthreads):
+    import numpy as np
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    shares = np.ascontiguousarray(shares, dtype=np.uint8)
+    B, n = idx.shape
+    out = np.zeros((B, 96), dtype=np.uint8)
+    rc = np.zeros(B, dtype=np.int32)
+    load().or_combine_g1_batch(t, n, idx.ctypes.data, shares.ctypes.data, B, out.ctypes.data, rc.ctypes.data, nthreads)
+    return out, rc
+
+
+def sign_shares_batch(sk_table, idx, hashes, nthreads):
+    """out[k][s] = [sk_table[idx[k][s]]] hashes[k] for B messages x n signers"""
+    import numpy as np
+    sk_table = np.ascontiguousarray(sk_table, dtype=np.uint8)
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint8)
+    B, n = idx.shape
+    out = np.zeros((B, n, 192), dtype=np.uint8)
+    rc = np.zeros(B, dtype=np.int32)
+    load().or_sign_shares_batch(n, sk_table.shape[0], sk_table.ctypes.data, idx.ctypes.data, hashes.ctypes.data, B, out.ctypes.data,
+                                rc.ctypes.data, nthreads)
     return out, rc
 
 

@@ -157,7 +157,7 @@ def test_ladder_special_cases_take_the_safe_path(engine, wl):
 
 def test_comb_signing_many_signers_vs_oracle(engine, wl):
     """tc_sign_shares_g2_batch with n >= 24 signers per message runs through the per-message comb (csrc/tc_comb.h):
-    every share of a few messages against Oracle B, plus a bad signer index, an identity point and an undecodable point."""
+    every share of 265 messages against Oracle B, plus a bad signer index, an identity point and an undecodable point."""
     c.load()
     rng = random.Random(31)
     N, n, B = 40, 30, 8192       # the comb runs from 24 signers and 8192 messages on (csrc/tc_launch.h)
@@ -175,13 +175,17 @@ def test_comb_signing_many_signers_vs_oracle(engine, wl):
     pts[6, 100] ^= 1                                 # not on the curve any more
     out, st = engine.sign_shares_g2(sk, idx, pts)
     assert st.shape == (B, n) and out.shape == (B, n, 192)
-    for j in (0, 1, 2, 3, 4, 5, 95, 96, 97, 511, 512, 4095, 4096, 4097, B - 2, B - 1):
+    for j in (0, 1, 2, 3, 4, 5, 95, 96, 97):
         for s in range(n):
             if j == 4 and s == 7:
                 assert st[j, s] == 3 and bytes(out[j, s]) == bytes(inf)
                 continue
             assert st[j, s] == 0, (j, s)
             assert bytes(out[j, s]) == oracle_mul(sk[int(idx[j, s])], pts[j]), (j, s)
+    # every share of 256 messages spread over the batch (wave and tile boundaries included), on all host threads
+    pick = np.unique(np.concatenate([np.array([511, 512, 4095, 4096, 4097, B - 2, B - 1]), np.linspace(8, B - 1, 249).astype(np.int64)]))
+    want, rc = c.sign_shares_batch(sk, idx[pick], pts[pick], c.host_threads())
+    assert not rc.any() and not st[pick].any() and (want == out[pick]).all()
     assert (st[6] == 3).all() and all(bytes(out[6, s]) == bytes(inf) for s in range(n))
     assert not st[7:].any()
     # the comb and the per-chunk ladders agree on a whole batch: n = 23 (ladders) and n = 24 (comb) share 23 signers

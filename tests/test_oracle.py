@@ -198,6 +198,35 @@ def test_checked_decompress_both_oracles(rnd):
     assert c.g1_decompress(bytes(bad))[0] == 3
 
 
+def test_threaded_oracle_drivers_equal_the_single_job_functions(rnd):
+    """The threaded drivers the large-threshold GPU tests use (or_sign_combine_batch, or_combine_g1_batch,
+    or_sign_shares_batch) against Oracle A: sign t + 1 shares and combine = the master key's signature; a signer index outside
+    the key table fails its message only."""
+    import numpy as np
+    u8 = lambda b: np.frombuffer(bytes(b), dtype=np.uint8)
+    t, N, B = 3, 7, 6
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    sk = np.stack([u8(o.secret_key_share(poly, i).to_bytes(32, "little")) for i in range(N)])
+    H = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(B)]
+    hs = np.stack([u8(o.g2_uncompressed(h)) for h in H])
+    idx = np.array([sorted(rnd.sample(range(N), t + 1)) for _ in range(B)], dtype=np.uint64)
+    out, rc = c.sign_combine_batch(t, sk, idx, hs, 3)
+    assert not rc.any() and all(bytes(out[j]) == o.g2_uncompressed(o.E2.mul(H[j], poly[0])) for j in range(B))
+    sh, rc = c.sign_shares_batch(sk, idx, hs, 2)
+    assert not rc.any()
+    for j in range(B):
+        for k in range(t + 1):
+            assert bytes(sh[j, k]) == o.g2_uncompressed(o.E2.mul(H[j], o.secret_key_share(poly, int(idx[j, k]))))
+    bad = idx.copy()
+    bad[1, 2] = N + 3
+    _, rc = c.sign_shares_batch(sk, bad, hs, 2)
+    assert list(rc) == [0, 3, 0, 0, 0, 0]
+    h1 = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    s1 = np.stack([np.stack([u8(o.g1_uncompressed(o.E1.mul(h1, o.secret_key_share(poly, int(i))))) for i in row]) for row in idx])
+    out1, rc = c.combine_g1_batch(t, idx, s1, 4)
+    assert not rc.any() and all(bytes(out1[j]) == o.g1_uncompressed(o.E1.mul(h1, poly[0])) for j in range(B))
+
+
 def test_reference_fixtures_if_present():
     """Pins BOTH oracles to vectors printed by the real threshold_crypto 0.4.0 crate (tools/ref_fixtures)
     when tests/golden/ref_v0.4.0/vectors.hex exists.  It does not in this repository (no Rust toolchain in
