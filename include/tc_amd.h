@@ -224,6 +224,16 @@ int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares,
 /* ok[j] = Ciphertext(u[j], v[j], w[j]).verify() = e(g1, w) == e(u, hash_g1_g2(u, v))   src/lib.rs:508-512 */
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
                                const uint8_t* w_g2, size_t B, uint8_t* ok);
+/* SecretKeyShare::decrypt_share src/lib.rs:452-457 for ONE key share and B ciphertexts: Ciphertext::verify, then [sk] u.
+ * ok[j] = 1 and out_g1[j] = the DecryptionShare when ciphertext j is valid; ok[j] = 0 and the identity's encoding when it is
+ * not (the reference returns None: an invalid ciphertext never yields a share).  sk_fr: 32 B LE, wiped from the staging
+ * buffers after the call.  One call = hash_g1_g2 + pairing check + G1 multiplication, nothing crosses PCIe in between. */
+int tc_decrypt_share_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
+                           const uint8_t* w_g2, size_t B, uint8_t* out_g1, uint8_t* ok);
+/* SecretKey::decrypt src/lib.rs:384-391: Ciphertext::verify, g = [sk] u, xor_with_hash(g, v).  out bytes[off[j]..off[j+1]] =
+ * the plaintext when ok[j] = 1, zeros when the ciphertext is invalid (None). */
+int tc_secret_key_decrypt_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
+                                const uint8_t* w_g2, size_t B, uint8_t* out, uint8_t* ok);
 /* ok[j] = pk_share[j].verify_decryption_share(share[j], ct[j])
  *       = e(share, hash_g1_g2(u, v)) == e(pk_share, w)                                  src/lib.rs:182-186 */
 int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share_g1, size_t pk_stride,

@@ -300,14 +300,13 @@ class SecretKey {
   }
   // SecretKey::decrypt (src/lib.rs:384-391)
   std::optional<Bytes> decrypt(const Ciphertext& ct, Engine& e = Engine::instance()) const {
-    if (!ct.verify(e)) return std::nullopt;
-    G1Bytes g{};
-    std::uint8_t st = 0;
-    e.check(tc_g1_mul_batch(e.ctx(), fr_.data(), ct.u.data(), 1, 1, g.data(), &st));
-    raise_status(st);
+    // one call: Ciphertext::verify, [sk] u and xor_with_hash on the device
     Bytes out(ct.v.size());
     std::uint64_t off[2] = {0, ct.v.size()};
-    if (!ct.v.empty()) e.check(tc_xor_with_hash_batch(e.ctx(), g.data(), ct.v.data(), off, 1, out.data(), &st));
+    std::uint8_t ok = 0, dummy = 0;
+    e.check(tc_secret_key_decrypt_batch(e.ctx(), fr_.data(), ct.u.data(), ct.v.empty() ? &dummy : ct.v.data(), off, ct.w.data(), 1,
+                                        out.empty() ? &dummy : out.data(), &ok));
+    if (!ok) return std::nullopt;
     return out;
   }
 
@@ -333,8 +332,13 @@ class SecretKeyShare {
   }
   // SecretKeyShare::decrypt_share (src/lib.rs:452-457)
   std::optional<DecryptionShare> decrypt_share(const Ciphertext& ct, Engine& e = Engine::instance()) const {
-    if (!ct.verify(e)) return std::nullopt;
-    return decrypt_share_no_verify(ct, e);
+    // one call: Ciphertext::verify and the multiplication on the device; an invalid ciphertext never yields [sk] u
+    DecryptionShare d;
+    std::uint64_t off[2] = {0, ct.v.size()};
+    std::uint8_t ok = 0, dummy = 0;
+    e.check(tc_decrypt_share_batch(e.ctx(), sk_.fr().data(), ct.u.data(), ct.v.empty() ? &dummy : ct.v.data(), off, ct.w.data(), 1, d.g1.data(), &ok));
+    if (!ok) return std::nullopt;
+    return d;
   }
 
  private:

@@ -13,7 +13,7 @@
 //! Rows of SURVEY.md section 8(a) and where they are:
 //!   A2  hash_g2                         hash_g2_batch
 //!   A4  SecretKey(Share)::sign / sign_g2  SecretKey::sign_batch, sign_g2_batch, SecretKeySet::sign_shares_batch
-//!   A5  SecretKeyShare::decrypt_share   SecretKeyShare::decrypt_share_no_verify_batch, decrypt_share_batch
+//!   A5  SecretKeyShare::decrypt_share   SecretKeyShare::decrypt_share_no_verify_batch, decrypt_share_batch; SecretKey::decrypt_batch
 //!   A6/A7 PublicKeySet::combine_signatures  PublicKeySet::combine_signatures_batch
 //!   A8  PublicKeySet::decrypt           PublicKeySet::decrypt_batch
 //!   A9  PublicKey::verify / verify_g2   PublicKey::verify_batch, verify_g2_batch, verify_rlc_batch (opt-in)
@@ -241,12 +241,45 @@ impl SecretKeyShare {
         gpu.check(rc);
         out.chunks(G1_BYTES).map(|c| DecryptionShare(g1_from(c))).collect()
     }
-    /// `decrypt_share`: `None` where the ciphertext does not verify (src/lib.rs:452-457).
+    /// `decrypt_share`: `None` where the ciphertext does not verify (src/lib.rs:452-457).  ONE call: Ciphertext::verify and the
+    /// multiplication both on the device (tc_decrypt_share_batch); a ciphertext that fails the check never yields [sk] u.
     pub fn decrypt_share_batch(&self, gpu: &Gpu, cts: &[Ciphertext]) -> Vec<Option<DecryptionShare>> {
-        let ok = Ciphertext::verify_batch(gpu, cts);
-        let shares = self.decrypt_share_no_verify_batch(gpu, cts);
-        shares.into_iter().zip(ok).map(|(s, good)| if good { Some(s) } else { None }).collect()
+        let mut fr = fr_bytes(&(self.0).0);
+        let (u, flat, off, w) = ciphertext_columns(cts);
+        let (mut out, mut ok) = (vec![0u8; cts.len() * G1_BYTES], vec![0u8; cts.len()]);
+        let rc = unsafe {
+            tc_decrypt_share_batch(gpu.0, fr.as_ptr(), u.as_ptr(), flat.as_ptr(), off.as_ptr(), w.as_ptr(), cts.len(), out.as_mut_ptr(), ok.as_mut_ptr())
+        };
+        fr.iter_mut().for_each(|b| *b = 0);
+        gpu.check(rc);
+        out.chunks(G1_BYTES).zip(ok).map(|(c, good)| if good == 1 { Some(DecryptionShare(g1_from(c))) } else { None }).collect()
     }
+}
+impl SecretKey {
+    /// `decrypt` for B ciphertexts (src/lib.rs:384-391): `None` where the ciphertext does not verify; verify, [sk] u and
+    /// xor_with_hash in one call (tc_secret_key_decrypt_batch).
+    pub fn decrypt_batch(&self, gpu: &Gpu, cts: &[Ciphertext]) -> Vec<Option<Vec<u8>>> {
+        let mut fr = fr_bytes(&self.0);
+        let (u, flat, off, w) = ciphertext_columns(cts);
+        let (mut out, mut ok) = (vec![0u8; flat.len()], vec![0u8; cts.len()]);
+        let rc = unsafe {
+            tc_secret_key_decrypt_batch(gpu.0, fr.as_ptr(), u.as_ptr(), flat.as_ptr(), off.as_ptr(), w.as_ptr(), cts.len(), out.as_mut_ptr(), ok.as_mut_ptr())
+        };
+        fr.iter_mut().for_each(|b| *b = 0);
+        gpu.check(rc);
+        (0..cts.len()).map(|j| if ok[j] == 1 { Some(out[off[j] as usize..off[j + 1] as usize].to_vec()) } else { None }).collect()
+    }
+}
+/// the columns of a ciphertext batch as the C ABI takes them: u (96 B each), the v bytes + offsets, w (192 B each)
+fn ciphertext_columns(cts: &[Ciphertext]) -> (Vec<u8>, Vec<u8>, Vec<u64>, Vec<u8>) {
+    let (mut u, mut w) = (Vec::with_capacity(cts.len() * G1_BYTES), Vec::with_capacity(cts.len() * G2_BYTES));
+    for ct in cts {
+        u.extend_from_slice(&g1_bytes(&ct.0));
+        w.extend_from_slice(&g2_bytes(&ct.2));
+    }
+    let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
+    let (flat, off) = pack_messages(&vs);
+    (u, flat, off, w)
 }
 
 // ---- A6 / A7 / A8 / A12: the key set (src/lib.rs:565-626, 719-773) -----------------------------------------------------

@@ -134,6 +134,7 @@ def test_rust_shim_calls_existing_entry_points_with_matching_arity():
     for need in ("tc_hash_g2_batch", "tc_sign_batch", "tc_g2_mul_batch", "tc_g1_mul_batch", "tc_combine_g2_batch", "tc_combine_g2_fr_batch",
                  "tc_decrypt_fr_batch", "tc_combine_signatures_wire_batch", "tc_decrypt_wire_batch",
                  "tc_verify_sig_batch", "tc_verify_g2_batch", "tc_ciphertext_verify_batch", "tc_verify_decryption_share_batch",
+                 "tc_decrypt_share_batch", "tc_secret_key_decrypt_batch",
                  "tc_public_key_share_batch", "tc_g1_compress_batch", "tc_g2_decompress_batch", "tc_encrypt_batch",
                  "tc_verify_shares_rlc_batch", "tc_g1_commitment_batch", "tc_group_sign_combine_verify"):
         assert need in used, need

@@ -5,6 +5,7 @@
     (/root/reference/src/lib.rs:140-146, 246-252) on the device, the combined signature back as Signature::to_bytes
     (src/lib.rs:255-259).  Checker: Oracle B's g2_decompress -> combine -> g2_compress, job by job, at BASELINE config 2's
     full batch with planted undecodable and non-member shares;
+  * SecretKeyShare::decrypt_share and SecretKey::decrypt as ONE call each (tc_decrypt_share_batch, tc_secret_key_decrypt_batch);
   * `T: IntoFr` beyond u64 (tc_combine_g{1,2}_fr_batch, tc_decrypt_fr_batch): the reference's test_interpolate
     (src/lib.rs:793-808, whose indices are i32) replayed with negative integers, field elements and 2^64-range values.
 """
@@ -140,6 +141,59 @@ def test_wire_combine_full_baseline_batch_vs_oracle(engine):
     bad[5::4096] = True
     bad[9::4096] = True
     assert ((st == 3) == bad).all()
+
+
+# ---- SecretKeyShare::decrypt_share / SecretKey::decrypt as ONE call each ----------------------------------------------------
+def test_decrypt_share_and_secret_key_decrypt_in_one_call_vs_oracle(engine, rnd):
+    """SecretKeyShare::decrypt_share (src/lib.rs:452-457) and SecretKey::decrypt (src/lib.rs:384-391) for 70 ciphertexts of
+    ragged length under one key: Ciphertext::verify, [sk] u (and xor_with_hash) in one call.  Oracle B recomputes every job as
+    the composition the reference writes (ciphertext_verify, then g1_mul, then xor_with_hash); a corrupted v, a swapped w, a
+    non-member w and an undecodable u must give ok = 0, the identity as the share and zeros as the plaintext -- never [sk] u.
+    Host buffers and device-resident buffers agree."""
+    import torch
+    B = 70
+    sk = rnd.randrange(1, o.R)
+    pk = u8(o.g1_uncompressed(o.E1.mul(o.G1_GEN, sk)))
+    msgs = [bytes(rnd.randrange(256) for _ in range(j % 37)) for j in range(B)]          # job 0 and 37: empty plaintexts
+    flat, off = pack_messages(msgs)
+    r = np.stack([u8(rnd.randrange(1, o.R).to_bytes(32, "little")) for _ in range(B)])
+    u, v, w, st = engine.encrypt(pk, r, flat, off)
+    assert not st.any()
+    u, v, w = u.copy(), v.copy(), w.copy()
+    v[int(off[5])] ^= 1                                            # a flipped ciphertext byte
+    w[9] = w[10]                                                   # the neighbour's w
+    w[11] = u8(o.g2_uncompressed(non_member_g2(rnd)))              # on the curve, outside G2
+    u[13, 50] ^= 4                                                 # not on the curve any more
+    bad = {5, 9, 11, 13}
+    fr = u8(sk.to_bytes(32, "little"))
+    shares, ok = engine.decrypt_share(fr, u, v, off, w)
+    plain, ok2 = engine.secret_key_decrypt(fr, u, v, off, w)
+    identity = bytes([0x40]) + bytes(95)
+    for j in range(B):
+        vj = bytes(v[int(off[j]):int(off[j + 1])])
+        good = c.ciphertext_verify(bytes(u[j]), vj, bytes(w[j])) if j != 13 else False
+        assert good == (j not in bad) and bool(ok[j]) == good == bool(ok2[j]), j
+        got = bytes(plain[int(off[j]):int(off[j + 1])])
+        if not good:
+            assert bytes(shares[j]) == identity and got == bytes(len(vj)), j
+            continue
+        rc, g = c.g1_mul(bytes(fr), bytes(u[j]))
+        assert rc == 0 and bytes(shares[j]) == g, j
+        rc, pt = c.xor_with_hash(g, vj)
+        assert rc == 0 and got == pt == msgs[j], j
+    # device-resident operands: the same bytes
+    dev = [torch.from_numpy(x).cuda() for x in (fr, u, v, off, w)]
+    shares_d, ok_d = engine.decrypt_share(*dev)
+    plain_d, ok_d2 = engine.secret_key_decrypt(*dev)
+    engine.sync()
+    assert (shares_d.cpu().numpy() == shares).all() and (ok_d.cpu().numpy() == ok).all()
+    assert (plain_d.cpu().numpy() == plain).all() and (ok_d2.cpu().numpy() == ok2).all()
+    # the host-side mirror: Option<DecryptionShare> / Option<Vec<u8>>
+    cts = [api.Ciphertext(bytes(u[j]), bytes(v[int(off[j]):int(off[j + 1])]), bytes(w[j]), _trusted=True) for j in (0, 1, 5, 9)]
+    sks = api.SecretKeyShare(sk)
+    got = sks.decrypt_share_batch(cts, engine=engine)
+    assert got[2] is None and got[3] is None and got[1].to_bytes() == o.g1_compressed(o.E1.mul(o.g1_from_uncompressed(bytes(u[1])), sk))
+    assert api.SecretKey(sk).decrypt_batch(cts, engine=engine) == [msgs[0], msgs[1], None, None]
 
 
 # ---- `T: IntoFr` --------------------------------------------------------------------------------------------------------

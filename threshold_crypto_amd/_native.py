@@ -52,6 +52,8 @@ PROTOTYPES = {
     "tc_verify_decryption_shares_rlc_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, ctypes.c_char_p, _u8p,
                                               ctypes.POINTER(ctypes.c_uint64)],
     "tc_ciphertext_verify_batch": [_u8p, _u8p, _u64p, _u8p, _sz, _u8p],
+    "tc_decrypt_share_batch": [_u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p, _u8p],
+    "tc_secret_key_decrypt_batch": [_u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p, _u8p],
     "tc_verify_decryption_share_batch": [_u8p, _sz, _u8p, _u8p, _u8p, _u64p, _u8p, _sz, _u8p],
     "tc_encrypt_batch": [_u8p, _sz, _u8p, _u8p, _u64p, _sz, _u8p, _u8p, _u8p, _u8p],
     "tc_public_key_share_batch": [_u8p, _sz, _u64p, _sz, _u8p, _u8p],

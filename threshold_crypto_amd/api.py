@@ -366,14 +366,15 @@ class SecretKey:
 
     def decrypt(self, ct):
         """SecretKey::decrypt (src/lib.rs:384-391): None if the ciphertext is invalid."""
-        if not ct.verify():
-            return None
-        e = default_engine()
-        g, st = e.g1_mul(_u8(self._bytes())[None], _u8(ct.u)[None])
-        _raise_status(st[0, 0])
-        v, off = pack_messages([ct.v])
-        out, st = e.xor_with_hash(np.ascontiguousarray(g[:, 0]), v, off)
-        return bytes(out[: len(ct.v)])
+        return self.decrypt_batch([ct])[0]
+
+    def decrypt_batch(self, cts, engine=None):
+        """SecretKey::decrypt for B ciphertexts in ONE call (verify + [sk] u + xor_with_hash on the device): the plaintext,
+        or None where Ciphertext::verify fails."""
+        e = engine or default_engine()
+        v, off = pack_messages([ct.v for ct in cts])
+        out, ok = e.secret_key_decrypt(_u8(self._bytes()), _stack([ct.u for ct in cts], 96), v, off, _stack([ct.w for ct in cts], 192))
+        return [bytes(out[int(off[j]):int(off[j + 1])]) if ok[j] else None for j in range(len(cts))]
 
 
 class SecretKeyShare(SecretKey):
@@ -393,9 +394,14 @@ class SecretKeyShare(SecretKey):
 
     def decrypt_share(self, ct):
         """SecretKeyShare::decrypt_share (src/lib.rs:452-457)."""
-        if not ct.verify():
-            return None
-        return self.decrypt_share_no_verify(ct)
+        return self.decrypt_share_batch([ct])[0]
+
+    def decrypt_share_batch(self, cts, engine=None):
+        """decrypt_share for B ciphertexts in ONE call (verify + [sk] u on the device): None where Ciphertext::verify fails."""
+        e = engine or default_engine()
+        v, off = pack_messages([ct.v for ct in cts])
+        out, ok = e.decrypt_share(_u8(self._bytes()), _stack([ct.u for ct in cts], 96), v, off, _stack([ct.w for ct in cts], 192))
+        return [DecryptionShare(out[j], _trusted=True) if ok[j] else None for j in range(len(cts))]
 
     def decrypt_share_no_verify(self, ct):
         """SecretKeyShare::decrypt_share_no_verify (src/lib.rs:460-462)."""

@@ -1150,6 +1150,56 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
   return k.finish();
 }
 
+// Ciphertext::verify, then [sk] u for the ciphertexts that pass: SecretKeyShare::decrypt_share (src/lib.rs:452-457) when
+// plain == nullptr, SecretKey::decrypt (src/lib.rs:384-391: the same, then xor_with_hash) otherwise
+static int verified_decrypt(tc_ctx* ctx, const uint8_t* sk, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
+                            size_t B, uint8_t* out_g1, uint8_t* plain, uint8_t* ok) {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;
+  TC_REQUIRE(ctx && sk && u && off && w && ok && (out_g1 || plain));
+  Call k(ctx);
+  uint64_t total = 0;
+  if (!total_bytes(k, off, B, &total)) return k.finish();
+  TC_REQUIRE(total == 0 || v);
+  const uint8_t* d_sk = k.in(sk, 32, /*secret=*/true);
+  const uint8_t* d_u = k.in(u, B * 96);
+  const uint8_t* d_v = k.in(v, (size_t)total);
+  const uint64_t* d_off = k.in(off, B + 1);
+  const uint8_t* d_w = k.in(w, B * 192);
+  uint8_t* d_hash = k.temp<uint8_t>(B * 192);
+  uint8_t* d_ok = k.out(ok, B);
+  uint8_t* d_st = k.temp<uint8_t>(B, /*zero=*/true);
+  uint8_t* d_pt = plain ? k.temp<uint8_t>(B * 96) : k.out(out_g1, B * 96);
+  uint8_t* d_plain = plain ? k.out(plain, (size_t)total, /*zero=*/true) : nullptr;
+  if (plain && d_pt) k.wipe_after_copy.emplace_back(d_pt, B * 96);  // g = [sk] u opens the ciphertext: not left in a staging slot
+  k.begin_timing();
+  k.check_points(false, d_u, 96, 1, 1, B, 1);
+  k.check_points(true, d_w, 192, 1, 1, B, 1);
+  if (!k.failed) {
+    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
+    tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok, k.pairing_ws(B));  // src/lib.rs:511
+    k.apply_checks(B, nullptr, nullptr, 0, d_ok);
+    tc::launch_g1_mul(ctx->stream, B > tc::kG1ArenaMinJobs ? k.tables() : tc::TableArena{nullptr, nullptr}, d_sk, d_u, 1, B, d_pt, d_st);
+    // `if !ct.verify() { return None; }` (src/lib.rs:385, 453): a ciphertext that fails the check gets the identity, never [sk] u
+    tc::launch_invalidate_jobs(ctx->stream, d_ok, 1, 1, B, d_st, d_pt, 96, nullptr);
+    if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);  // skips flagged jobs: zeros
+  }
+  k.end_timing();
+  return k.finish();
+}
+
+int tc_decrypt_share_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
+                           size_t B, uint8_t* out_g1, uint8_t* ok) {
+  TC_REQUIRE(ctx && (B == 0 || out_g1));
+  return verified_decrypt(ctx, sk_fr, u, v, off, w, B, out_g1, nullptr, ok);
+}
+
+int tc_secret_key_decrypt_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
+                                size_t B, uint8_t* out, uint8_t* ok) {
+  TC_REQUIRE(ctx && (B == 0 || out));
+  return verified_decrypt(ctx, sk_fr, u, v, off, w, B, nullptr, out, ok);
+}
+
 int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_t pk_stride, const uint8_t* share,
                                      const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
                                      size_t B, uint8_t* ok) {

@@ -416,6 +416,34 @@ class Engine:
         self._call("tc_ciphertext_verify_batch", _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(ok))
         return ok
 
+    def decrypt_share(self, fr, u, v, off, w):
+        """SecretKeyShare::decrypt_share (src/lib.rs:452-457) for one key share and B ciphertexts -> (shares (B, 96), ok (B,)):
+        ok[j] = Ciphertext::verify, the share of a ciphertext that fails it is the identity (the reference returns None)."""
+        dev = self._mode(fr, u, v, off, w)
+        self._arg(fr, (FR_BYTES,), "u8", "fr")
+        self._arg(u, (None, G1_BYTES), "u8", "u")
+        B = u.shape[0]
+        self._msgs(v, off, B)
+        self._arg(w, (B, G2_BYTES), "u8", "w")
+        out = self._empty(dev, (B, G1_BYTES), ref=u)
+        ok = self._empty(dev, (B,), ref=u)
+        self._call("tc_decrypt_share_batch", _ptr(fr), _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(out), _ptr(ok))
+        return out, ok
+
+    def secret_key_decrypt(self, fr, u, v, off, w):
+        """SecretKey::decrypt (src/lib.rs:384-391) for B ciphertexts -> (plaintext bytes laid out like v, ok (B,)); the bytes
+        of a ciphertext that fails Ciphertext::verify are zeros (None)."""
+        dev = self._mode(fr, u, v, off, w)
+        self._arg(fr, (FR_BYTES,), "u8", "fr")
+        self._arg(u, (None, G1_BYTES), "u8", "u")
+        B = u.shape[0]
+        self._msgs(v, off, B)
+        self._arg(w, (B, G2_BYTES), "u8", "w")
+        out = self._empty(dev, tuple(v.shape), ref=v)
+        ok = self._empty(dev, (B,), ref=u)
+        self._call("tc_secret_key_decrypt_batch", _ptr(fr), _ptr(u), _ptr(v), _ptr(off), _ptr(w), B, _ptr(out), _ptr(ok))
+        return out, ok
+
     def verify_decryption_share(self, pk_share, share, u, v, off, w):
         dev = self._mode(pk_share, share, u, v, off, w)
         self._arg(share, (None, G1_BYTES), "u8", "share")
