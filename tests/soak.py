@@ -294,6 +294,57 @@ while time.time() < t_end:
         if (lst[j] != 0) != bad_ or (not bad_ and bytes(lout[j]) != o.g1_uncompressed(acc)):
             fail("lincomb_g1", rounds, j, "n=%d" % nl)
     checked += 2 * Bs + Bd * (Nd + 1)
+    # ---- round-4 entries: wire-level combiners, IntoFr abscissae, decrypt_share / SecretKey::decrypt in one call -----------------
+    Bw = min(B, 40)
+    tw = rnd.choice([1, 2, 3, 3, 7])
+    nw = tw + 1 + rnd.choice([0, 1])
+    widx = np.zeros((Bw, nw), np.uint64)
+    w96 = np.zeros((Bw, nw, 96), np.uint8)
+    w48 = np.zeros((Bw, nw, 48), np.uint8)
+    for j in range(Bw):
+        widx[j] = sorted(rnd.sample(range(max(12, nw)), nw))
+        for k_ in range(nw):
+            w96[j, k_] = u8(maybe_corrupt(c_oracle.g2_compress(rnd.choice(pool2))[1]))
+            w48[j, k_] = u8(maybe_corrupt(c_oracle.g1_compress(rnd.choice(pool1))[1]))
+    wout, wst = e.combine_signatures_wire(tw, widx, w96)
+    wm = msgs[:Bw]
+    wflat, woff = pack_messages(wm)
+    dout, dst = e.decrypt_wire(tw, widx, w48, wflat, woff)
+    for j in range(Bw):
+        ids = [int(i) for i in widx[j]]
+        rc, want = c_oracle.combine_signatures_wire(tw, ids, [bytes(x) for x in w96[j]])
+        if int(wst[j]) != rc or bytes(wout[j]) != want:
+            fail("combine_signatures_wire", rounds, j, "t=%d st=%d rc=%d" % (tw, wst[j], rc))
+        rc, want = c_oracle.decrypt_wire(tw, ids, [bytes(x) for x in w48[j]], wm[j])
+        if int(dst[j]) != rc or bytes(dout[int(woff[j]): int(woff[j + 1])]) != want:
+            fail("decrypt_wire", rounds, j, "t=%d st=%d rc=%d" % (tw, dst[j], rc))
+    # IntoFr abscissae: the same shares keyed by Fr values / negative integers must give what the u64 entry gives for the
+    # u64 image of small keys, and Oracle A's interpolate (any integer through into_fr_plus_1) for wide ones (G1: cheap in Python)
+    Bf, tf = min(B, 4), rnd.choice([1, 2, 3])
+    keys = [[rnd.choice([rnd.randrange(o.R), -rnd.randrange(1, 1 << 40), (1 << 64) + rnd.randrange(99), rnd.randrange(50)]) for _ in range(tf + 1)]
+            for _ in range(Bf)]
+    fpts = [[rnd.choice(pool1) for _ in range(tf + 1)] for _ in range(Bf)]
+    fidx = np.stack([np.stack([u8((k_ % o.R).to_bytes(32, "little")) for k_ in row]) for row in keys])
+    fout, fst = e.combine_g1_fr(tf, fidx, np.stack([np.stack([u8(p) for p in row]) for row in fpts]))
+    for j in range(Bf):
+        want = o.interpolate(o.E1, tf, [(k_, o.g1_from_uncompressed(p, check=False)) for k_, p in zip(keys[j], fpts[j])])
+        if fst[j] != 0 or bytes(fout[j]) != o.g1_uncompressed(want):
+            fail("combine_g1_fr", rounds, j, "keys=%s" % keys[j])
+    # decrypt_share / SecretKey::decrypt on the ciphertext set above (valid, wrong-w, corrupted operands) under one key
+    dsh_, dok_ = e.decrypt_share(u8(fr(sk0)), us, cflat, coff, ws)
+    dpl_, dok2_ = e.secret_key_decrypt(u8(fr(sk0)), us, cflat, coff, ws)
+    for j in range(Bc):
+        if int(dok_[j]) != int(okc[j]) or int(dok2_[j]) != int(okc[j]):
+            fail("decrypt_share ok", rounds, j)
+        got = bytes(dpl_[int(coff[j]): int(coff[j + 1])])
+        if not okc[j]:
+            if bytes(dsh_[j]) != o.g1_uncompressed(None) or got != bytes(len(cm[j])):
+                fail("decrypt_share of an invalid ciphertext", rounds, j)
+            continue
+        rc, g_ = c_oracle.g1_mul(fr(sk0), bytes(us[j]))
+        if rc != 0 or bytes(dsh_[j]) != g_ or got != c_oracle.xor_with_hash(g_, cm[j])[1]:
+            fail("decrypt_share / secret_key_decrypt", rounds, j)
+    checked += 2 * Bw + Bf + 2 * Bc
     # ---- compressed round trip ------------------------------------------------------------------------
     c2, stc = e.g2_compress(np.stack([u8(p) for p in pts2]))
     d2, std = e.g2_decompress(c2)
