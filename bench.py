@@ -72,6 +72,56 @@ HBM_PEAK_GBPS = 8000.0
 PROFILE = json.load(open(os.path.join(ROOT, "profiles", "profile_constants.json")))
 
 
+class ClockSampler:
+    """Shader clock and board power while a leg runs (`rocm-smi`, one sample per ~0.2 s on a side thread; rank 0 only).  The
+    roofline denominator is measured in a multiply-add-only loop at 2.36 GHz; the kernels themselves run at 2.1-2.25 GHz
+    and up to 1.25 kW (tools/clock_probe.py), so a leg's `frac` also charges it for the clock it ran at:
+    frac_at_kernel_clock = frac x peak clock / sampled clock says what is left once that is taken out."""
+
+    def __init__(self, enabled):
+        import shutil
+        import threading
+        self.rows, self.stop = [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True) if (enabled and shutil.which("rocm-smi")) else None
+
+    @staticmethod
+    def sample():
+        import re
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+            d = json.loads(out)
+            card = d[sorted(k for k in d if k.startswith("card"))[int(os.environ.get("LOCAL_RANK", "0"))]]
+            sclk = next((v for k, v in card.items() if "sclk clock speed" in k.lower()), None)
+            pw = next((v for k, v in card.items() if "power (w)" in k.lower()), None)
+            m = re.search(r"(\d+)\s*[Mm][Hh]z", str(sclk))
+            return (int(m.group(1)) if m else None, float(pw) if pw not in (None, "N/A") else None)
+        except Exception:
+            return (None, None)
+
+    def _run(self):
+        while not self.stop.is_set():
+            self.rows.append(self.sample())
+            self.stop.wait(0.15)
+
+    def __enter__(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.thread:
+            self.thread.join(timeout=10)
+
+    def result(self):
+        clk = sorted(c for c, _ in self.rows[2:] if c)           # the first samples may still see the idle clock
+        pw = sorted(p for _, p in self.rows[2:] if p)
+        if len(clk) < 3:
+            return None
+        return {"sclk_GHz": round(clk[len(clk) // 2] / 1e3, 3), "sclk_GHz_min_max": [round(clk[0] / 1e3, 3), round(clk[-1] / 1e3, 3)],
+                "power_W": pw[len(pw) // 2] if pw else None, "samples": len(clk), "source": "rocm-smi --showclocks --showpower, sampled while the leg ran"}
+
+
 def measure_peak():
     """The roofline denominator: the wall rate of v_mad_i64_i32 -- the multiplier's own instruction, issued the way the field
     multiplier issues it -- with every SIMD saturated, from ~40 ms launches (the clock the chip sustains).  Two loop shapes are
@@ -411,9 +461,11 @@ def run_config2(args, eng, dev, rank, world, peak):
     if not harness and args.sustain_seconds > 0:
         eng.set_timing(False)
         n = max(args.steps, int(args.sustain_seconds / (ms_per_step * 1e-3)) + 1)
-        sdt, _ = timed(lambda: eng.combine_g2(t, d_idx, d_shares), n)
+        with ClockSampler(cuda and rank == 0) as cs:
+            sdt, _ = timed(lambda: eng.combine_g2(t, d_idx, d_shares), n)
         sustained = {"value": round(B * world / (sdt / n), 1), "ms_per_step": round(sdt / n * 1e3, 3), "steps": n, "seconds": round(sdt, 3),
-                     "is": "the headline step queued %d times on the one context (>= %.1f s of GPU time)" % (n, args.sustain_seconds)}
+                     "is": "the headline step queued %d times on the one context (>= %.1f s of GPU time)" % (n, args.sustain_seconds),
+                     "clock": cs.result()}
     eng.set_timing(True)
 
     # ---- config 3: verify the combined signatures; every 16th one replaced by its neighbour's ------------
@@ -431,6 +483,15 @@ def run_config2(args, eng, dev, rank, world, peak):
     sync()
     verify_dt = time.perf_counter() - v0
     assert bool((ok == expect_ok).all().item()), "verify_g2 ok-vector differs from the planted corruption pattern"
+    # the same call repeated for ~1.5 s on the one context: the rate it sustains and the clock / power it runs at
+    verify_sustained = None
+    if not harness and args.sustain_seconds > 0:
+        eng.set_timing(False)
+        nv = max(4, int(min(args.sustain_seconds, 1.5) / max(verify_dt, 1e-4)) + 1)
+        with ClockSampler(cuda and rank == 0) as cs:
+            vdt, _ = timed(lambda: eng.verify_g2(master_pk, bad, d_hashes), nv)
+        verify_sustained = {"value": round(B * world / (vdt / nv), 1), "ms_per_step": round(vdt / nv * 1e3, 3), "steps": nv, "clock": cs.result()}
+        eng.set_timing(True)
     # the same check with calls in flight: 8 steps alternating between the contexts
     verify_if_dt = None
     if len(engines) > 1:
@@ -622,7 +683,13 @@ def run_config2(args, eng, dev, rank, world, peak):
                "is": "BASELINE config 3: PublicKey::verify_g2 over the batch, one call, host waits; every 16th signature replaced, ok-vector checked",
                "streaming": ({"value": round(B * world / verify_if_dt, 1), "ms_per_step": round(verify_if_dt * 1e3, 3), "overlapped": True}
                              if verify_if_dt else None),
+               "sustained": verify_sustained,
                "roofline": legs.get("pairing_check")}
+    # what is left of each leg's frac once the clock it ran at is taken out (the denominator's loop runs ~5-10 % faster)
+    for leg, clock in ((head, sustained and sustained.get("clock")), (config3["roofline"], verify_sustained and verify_sustained.get("clock"))):
+        if leg and clock and clock.get("sclk_GHz") and leg.get("peak_clock_GHz"):
+            leg["kernel_clock"] = clock
+            leg["frac_at_kernel_clock"] = round(leg["frac"] * leg["peak_clock_GHz"] / clock["sclk_GHz"], 4)
     return {
         "metric": "combine_signatures/sec", "value": round(value, 1), "unit": "combine_signatures/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

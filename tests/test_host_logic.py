@@ -173,6 +173,15 @@ def _check_round4_lines(root, macs):
     assert abs(avg["tc::k_combine_fast<tc::Fq2>"] - d["roofline"]["kernel_ms"]) / d["roofline"]["kernel_ms"] < 0.08
     for k in ("k_g1_mul_arena", "k_hash_g1_g2", "k_msm_ladder", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
         assert k in summary, k
+    # the line also says which clock its legs ran at (rocm-smi sampled during the sustained legs): the denominator's loop runs
+    # at ~2.36 GHz, the kernels at 2.1-2.25 GHz and up to 1.25 kW; frac_at_kernel_clock takes that out and nothing else
+    b = json.loads([l for l in open(os.path.join(root, "profiles", "r04_b_bench.txt")) if l.startswith("{")][-1])
+    for leg, sus in ((b["roofline"], b["sustained"]), (b["config3"]["roofline"], b["config3"]["sustained"])):
+        clk = sus["clock"]
+        assert 1.5 < clk["sclk_GHz"] < leg["peak_clock_GHz"] <= 2.45 and clk["samples"] >= 3 and 300 < clk["power_W"] < 1500
+        assert abs(leg["frac_at_kernel_clock"] - leg["frac"] * leg["peak_clock_GHz"] / clk["sclk_GHz"]) < 2e-3
+        assert leg["frac"] < leg["frac_at_kernel_clock"] <= 1
+    assert abs(b["config3"]["sustained"]["value"] - b["config3"]["value"]) / b["config3"]["value"] < 0.05
     full = json.loads([l for l in open(os.path.join(root, "profiles", "r04_config5_full.txt")) if l.startswith("{")][-1])
     assert full["config"]["emulated_world"] == 8 and full["n_gpus"] == 1 and full["config"]["batch_per_gpu"] == 1048576
     assert full["valid_total_all_ranks"] == 1048576 and full["verified_all"] is True
