@@ -548,16 +548,24 @@ __device__ __attribute__((noinline)) inline FqRaw fq_sqr_call(int32_t a0, int32_
 #if TC_PAIR
 // ---- Fq2 spread over a lane pair (tc_common.h) ---------------------------------------------
 // A product needs the partner's coefficients: they come over DPP inside the callee, so a call
-// still passes only its own 15 + 15 limbs (+ the lane parity) in VGPRs.
+// still passes only its own 14 + 14 limbs in VGPRs.
+// The lane parity is NOT an argument (it was until r04): a value every product of a kernel needs is live from the first
+// instruction to the last, the 256-register kernels kept it in SCRATCH, and the register allocator reloaded it straight into the
+// argument register before every call -- one exposed scratch round trip per product (36 of the 46 products of a Miller step in
+// k_miller_accumulate waited on exactly that load).  Four instructions in the callee instead: the lane id from two
+// v_mbcnt (a workgroup is a whole number of waves, so its parity is threadIdx.x's), its low bit, minus one.
+__device__ __forceinline__ int32_t pair_even_mask() {  // even lane of a pair: -1, odd lane: 0
+  return (int32_t)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 1u) - 1;
+}
 //   even lane: c0 = a0 b0 - a1 b1 = mine*b0 + (-other)*b1
 //   odd  lane: c1 = a1 b0 + a0 b1 = mine*b0 +   other *b1
 // with b0 / b1 broadcast to both lanes of the pair (two DPP moves per limb) and the partner's a negated on the even
 // lane by xor/subtract with a lane mask (the xor carries the DPP swap): 56 prologue instructions, no branch.
-__device__ TC_MULCALL_ATTR FqRaw fq2p_mul_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13, int32_t odd) {
+__device__ TC_MULCALL_ATTR FqRaw fq2p_mul_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6, int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13) {
   const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
   const int32_t b[FQ_LIMBS] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13};
   int32_t y[FQ_LIMBS], z[FQ_LIMBS], w[FQ_LIMBS];
-  const int32_t mneg = odd - 1;  // even lane: -1 (negate the partner's coefficient), odd lane: 0
+  const int32_t mneg = pair_even_mask();  // even lane: -1 (negate the partner's coefficient), odd lane: 0
 #if defined(TC_MUL_SWIZZLE)
   // experiment (r04): the operand exchange through the LDS crossbar (ds_swizzle, no memory access) instead of DPP moves: a
   // v_mov_b32_dpp occupies the VALU as long as a multiply-add (4.2 cycles, tools/ubench_issue), a swizzle issues on the LDS pipe
@@ -580,10 +588,10 @@ __device__ TC_MULCALL_ATTR FqRaw fq2p_mul_call(int32_t a0, int32_t a1, int32_t a
   return r;
 }
 //   even lane: c0 = (a0 + a1)(a0 - a1);   odd lane: c1 = (2 a1) a0
-__device__ TC_MULCALL_ATTR FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13, int32_t odd) {
+__device__ TC_MULCALL_ATTR FqRaw fq2p_sqr_call(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6, int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13) {
   const int32_t a[FQ_LIMBS] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13};
   int32_t x[FQ_LIMBS], y[FQ_LIMBS];
-  int32_t even = odd - 1;  // even lane: all ones
+  int32_t even = pair_even_mask();  // even lane: all ones
   asm("" : "+v"(even));   // opaque: keeps the AND (one v_and_b32_dpp) from becoming a compare and a select
 #if defined(TC_MUL_SWIZZLE)
   TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) {

@@ -37,7 +37,7 @@ struct Fq2 {
     Fq2 r;
 #if defined(__HIP_DEVICE_COMPILE__)
     const Fq& a = m;
-    FqRaw t = fq2p_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13], pair_odd());
+    FqRaw t = fq2p_mul_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13]);
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #else
     r = b;
@@ -48,7 +48,7 @@ struct Fq2 {
     Fq2 r;
 #if defined(__HIP_DEVICE_COMPILE__)
     const Fq& a = m;
-    FqRaw t = fq2p_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13], pair_odd());
+    FqRaw t = fq2p_sqr_call(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12], a.l[13]);
     TC_UNROLL for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #else
     r = *this;

@@ -52,7 +52,7 @@ struct P {
 __device__ __forceinline__ P pmul(const P& a, const P& b, int odd) {
   P r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq2p_mul_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13], odd);
+  FqRaw t = fq2p_mul_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13]);
   for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #endif
   return r;
@@ -60,7 +60,7 @@ __device__ __forceinline__ P pmul(const P& a, const P& b, int odd) {
 __device__ __forceinline__ P psqr(const P& a, int odd) {
   P r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq2p_sqr_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], odd);
+  FqRaw t = fq2p_sqr_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13]);
   for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #endif
   return r;

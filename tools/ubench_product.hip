@@ -19,7 +19,7 @@ struct P {
 __device__ __forceinline__ P pmul(const P& a, const P& b, int odd) {
   P r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq2p_mul_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13], odd);
+  FqRaw t = fq2p_mul_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], b.m.l[0], b.m.l[1], b.m.l[2], b.m.l[3], b.m.l[4], b.m.l[5], b.m.l[6], b.m.l[7], b.m.l[8], b.m.l[9], b.m.l[10], b.m.l[11], b.m.l[12], b.m.l[13]);
   for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #endif
   return r;
@@ -27,7 +27,7 @@ __device__ __forceinline__ P pmul(const P& a, const P& b, int odd) {
 __device__ __forceinline__ P psqr(const P& a, int odd) {
   P r;
 #if defined(__HIP_DEVICE_COMPILE__)
-  FqRaw t = fq2p_sqr_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13], odd);
+  FqRaw t = fq2p_sqr_call(a.m.l[0], a.m.l[1], a.m.l[2], a.m.l[3], a.m.l[4], a.m.l[5], a.m.l[6], a.m.l[7], a.m.l[8], a.m.l[9], a.m.l[10], a.m.l[11], a.m.l[12], a.m.l[13]);
   for (int i = 0; i < FQ_LIMBS; i++) r.m.l[i] = t.l[i];
 #endif
   return r;
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) void k_product(const int32_t* in, int32_t* out,
   const int t = blockIdx.x * 64 + threadIdx.x;
   const int odd = t & 1;
   P x, y, u, v;
+  volatile int32_t spill[FQ_LIMBS];
   for (int i = 0; i < FQ_LIMBS; i++) {
     x.m.l[i] = in[((t & 1023) * 4 + 0) * FQ_LIMBS + i];
     y.m.l[i] = in[((t & 1023) * 4 + 1) * FQ_LIMBS + i];
@@ -51,9 +52,27 @@ __global__ __launch_bounds__(64) void k_product(const int32_t* in, int32_t* out,
       x = pmul(x, y, odd);
       P s = psqr(y, odd);
       for (int i = 0; i < FQ_LIMBS; i++) y.m.l[i] = s.m.l[i] + x.m.l[i];
-    } else {
+    } else if (SHAPE == 2) {
       x = pmul(x, y, odd);
       u = pmul(u, v, odd);
+    } else if (SHAPE == 3) {
+      // what the towers put between two products: a sum, a difference and a carry normalisation of the operands (no memory)
+      x = pmul(x, y, odd);
+      for (int i = 0; i < FQ_LIMBS; i++) y.m.l[i] = x.m.l[i] + u.m.l[i] - v.m.l[i];
+      y.m = y.m.norm();
+    } else if (SHAPE == 4) {
+      // a spill: 14 registers stored to scratch after a product, reloaded straight into the next product's operands
+      x = pmul(x, y, odd);
+      for (int i = 0; i < FQ_LIMBS; i++) spill[i] = x.m.l[i];
+      asm volatile("" ::: "memory");
+      for (int i = 0; i < FQ_LIMBS; i++) y.m.l[i] = spill[i] + (it & 1);
+    } else {
+      // a table look-up: 14 words per lane from a 64 KB per-wave table in global memory, issued before a product, used after it
+      const int32_t* row = in + ((((unsigned)x.m.l[0] >> 3) & 7) * 64 + threadIdx.x) * FQ_LIMBS % (1024 * 4 * FQ_LIMBS - 64);
+      int32_t tbl[FQ_LIMBS];
+      for (int i = 0; i < FQ_LIMBS; i++) tbl[i] = __builtin_nontemporal_load(row + i);
+      x = pmul(x, y, odd);
+      for (int i = 0; i < FQ_LIMBS; i++) y.m.l[i] = (x.m.l[i] + tbl[i]) & FQ_MASK;
     }
   }
   for (int i = 0; i < FQ_LIMBS; i++) out[(size_t)t * FQ_LIMBS + i] = x.m.norm().l[i] + y.m.norm().l[i] + u.m.norm().l[i];
@@ -122,15 +141,21 @@ int main() {
   const double peak = (double)simds * 4 * 40000 * 64 * 64 / (peak_ms * 1e-3) / 1e12;
   printf("{\"device\": \"%s\", \"simds\": %d, \"peak_T_lane_mac_per_s\": %.2f, \"peak_is\": \"v_mad_i64_i32, two chained accumulators, 4 waves per SIMD, %.1f ms\"}\n",
          p.gcnArchName, simds, peak, peak_ms);
-  const char* names[3] = {"mul (x = x*y)", "mix (x = x*y; y = y^2 + x)", "two independent chains (x = x*y; u = u*v)"};
-  const double macs_per_iter[3] = {588.0, 588.0 + 392.0, 2 * 588.0};
-  for (int shape = 0; shape < 3; shape++)
+  const char* names[6] = {"mul (x = x*y)", "mix (x = x*y; y = y^2 + x)", "two independent chains (x = x*y; u = u*v)",
+                          "mul + sum, difference and carry normalisation of an operand (no memory)",
+                          "mul + 14 registers through scratch (store, reload into the next operands)",
+                          "mul + a 14-word table row from global memory (issued before the product, used after)"};
+  const double macs_per_iter[6] = {588.0, 588.0 + 392.0, 2 * 588.0, 588.0, 588.0, 588.0};
+  for (int shape = 0; shape < 6; shape++)
     for (int w : {1, 2, 3, 4}) {  // 104-131 registers: four resident waves at most (three for the two-chain shape)
       const int iters = (shape == 0 ? 24000 : 14000) / (w > 2 ? (w + 1) / 2 : 1);
       float ms = 0;
       if (shape == 0) ms = time_launch(launch_product<0>, simds * w, iters, d_in, d_out);
       if (shape == 1) ms = time_launch(launch_product<1>, simds * w, iters, d_in, d_out);
       if (shape == 2) ms = time_launch(launch_product<2>, simds * w, iters, d_in, d_out);
+      if (shape == 3) ms = time_launch(launch_product<3>, simds * w, iters, d_in, d_out);
+      if (shape == 4) ms = time_launch(launch_product<4>, simds * w, iters, d_in, d_out);
+      if (shape == 5) ms = time_launch(launch_product<5>, simds * w, iters, d_in, d_out);
       const double rate = (double)simds * w * 64 * iters * macs_per_iter[shape] / (ms * 1e-3) / 1e12;
       printf("{\"shape\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.2f, \"T_lane_mac_per_s\": %.2f, \"frac_of_peak\": %.3f}\n", names[shape], w, ms, rate, rate / peak);
       fflush(stdout);
