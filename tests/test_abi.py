@@ -161,3 +161,49 @@ def test_design_quotes_the_shipped_kernel_resources():
     assert table["k_hash_g1_g2"]["spilled_sgprs"] < 100 and table["k_encrypt"]["spilled_sgprs"] < 100
     assert table["k_g1_mul_arena"]["registers"] <= 256 and table["k_g1_mul_arena"]["of_which_agpr"] == 0
     assert table["k_combine_fast_g1_arena"]["registers"] <= 256 and table["k_combine_fast_g1_arena"]["of_which_agpr"] == 0
+
+
+def test_null_context_is_an_error_not_a_crash():
+    """The C ABI never aborts (SURVEY 8b "Errors": return codes, no exceptions across the boundary): every batch entry point and
+    every group call handed a NULL context / group and all-zero arguments answers TC_ERR_INVALID_ARG (the getters: 0 / an empty
+    string), in a child process so that a segmentation fault would be seen as one.  No device is needed: the argument checks
+    come before any HIP call."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from threshold_crypto_amd import _native
+lib = _native.load()
+bad = []
+zero = lambda t: 0 if t in (ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32) else None
+for name, args in sorted(_native.PROTOTYPES.items()):
+    rc = getattr(lib, name)(None, *[zero(t) for t in args])
+    # an empty batch is a valid no-op for some entries only AFTER the context check: NULL must always be refused
+    if rc != _native.TC_ERR_INVALID_ARG:
+        bad.append((name, rc))
+for name, (res, args) in sorted(_native.GROUP_PROTOTYPES.items()):
+    rc = getattr(lib, name)(*[zero(t) for t in args])      # the first argument is the (NULL) group / the (NULL) out pointer
+    if res is ctypes.c_int and name not in ("tc_group_size", "tc_group_uses_rccl") and rc != _native.TC_ERR_INVALID_ARG:
+        bad.append((name, rc))
+    if name in ("tc_group_size", "tc_group_uses_rccl") and rc != 0:
+        bad.append((name, rc))
+lib.tc_ctx_destroy(None)
+for name in ("tc_ctx_set_device_io", "tc_ctx_set_timing", "tc_ctx_set_input_checks"):
+    if getattr(lib, name)(None, 1) != _native.TC_ERR_INVALID_ARG:
+        bad.append((name, "rc"))
+for name in ("tc_ctx_trim", "tc_sync"):
+    if getattr(lib, name)(None) != _native.TC_ERR_INVALID_ARG:
+        bad.append((name, "rc"))
+if lib.tc_ctx_get_input_checks(None) != 0 or lib.tc_ctx_get_device_io(None) != 0:
+    bad.append(("getters", "nonzero"))
+if lib.tc_ctx_set_stream(None, None) != _native.TC_ERR_INVALID_ARG:
+    bad.append(("tc_ctx_set_stream", "rc"))
+if lib.tc_ctx_transfer_bytes(None, None, None) != _native.TC_ERR_INVALID_ARG:
+    bad.append(("tc_ctx_transfer_bytes", "rc"))
+lib.tc_last_error(None)
+print("BAD", bad)
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    assert "BAD []" in out.stdout, out.stdout[-2000:]

@@ -327,3 +327,35 @@ def test_bench_under_the_launcher_runs_its_collectives_over_rccl(config):
         assert d["valid_total_all_ranks"] == 2048 and d["rank_records_start_jobs_valid_digest"][0][:3] == [0, 2048, 2048]
     else:
         assert d["verified_all"] is True
+
+
+def test_null_operands_are_an_error_not_a_crash():
+    """With a LIVE context: every batch entry point called with all sizes = 1 and every data pointer NULL answers
+    TC_ERR_INVALID_ARG -- not a HIP error, not a segmentation fault (child process); with all sizes = 0 it is a no-op or an
+    argument error.  The context stays usable afterwards."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from threshold_crypto_amd import _native
+lib = _native.load()
+ctx = ctypes.c_void_p()
+assert lib.tc_ctx_create(ctypes.byref(ctx), 0) == 0
+bad = []
+for name, args in sorted(_native.PROTOTYPES.items()):
+    ones = [1 if t is ctypes.c_size_t else None for t in args]
+    rc = getattr(lib, name)(ctx, *ones)
+    if rc != _native.TC_ERR_INVALID_ARG:
+        bad.append((name, "sizes 1", rc))
+    zeros = [0 if t is ctypes.c_size_t else None for t in args]
+    rc = getattr(lib, name)(ctx, *zeros)
+    if rc not in (_native.TC_OK, _native.TC_ERR_INVALID_ARG):
+        bad.append((name, "sizes 0", rc))
+assert lib.tc_sync(ctx) == 0
+lib.tc_ctx_destroy(ctx)
+print("BAD", bad)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    assert "BAD []" in out.stdout, out.stdout[-2000:]
