@@ -32,7 +32,6 @@ VMEM = re.compile(r"^\s+(scratch_|global_|buffer_|tbuffer_)(load|store|atomic)")
 FLAT = re.compile(r"^\s+flat_(load|store|atomic)")
 LGKM = re.compile(r"^\s+(ds_|s_load|s_buffer_load|s_memtime|s_memrealtime|s_sendmsg)")
 LABEL = re.compile(r"^[.\w$]+:")
-VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
 def dest_range(line):
