@@ -151,7 +151,15 @@ def measure_peak():
                             **extra)
     except Exception:
         pass
-    return best or dict(PEAK_RECORDED)
+    best = best or dict(PEAK_RECORDED)
+    # what the SHIPPED lane-pair product reaches when a SIMD runs nothing else, at the occupancies the kernels run at: the
+    # practical ceiling of `frac` for an Fq2 kernel; reported beside every roofline, never used as its denominator
+    try:
+        out = subprocess.run([os.path.join(ROOT, "tools", "ubench_product"), "--ceiling"], capture_output=True, text=True, timeout=120).stdout
+        best["product_ceiling"] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    except Exception:
+        best["product_ceiling"] = None
+    return best
 
 
 def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traffic_key=None, extra=None, executed=None):
@@ -720,6 +728,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         "verified_all": True,
         "extras": extras,
         "roofline": head,
+        "product_ceiling": peak.get("product_ceiling"),
         "secondary_rooflines": legs,
         "cpu_baseline": cpu,
     }

@@ -182,6 +182,11 @@ def _check_round4_lines(root, macs):
         assert abs(leg["frac_at_kernel_clock"] - leg["frac"] * leg["peak_clock_GHz"] / clk["sclk_GHz"]) < 2e-3
         assert leg["frac"] < leg["frac_at_kernel_clock"] <= 1
       assert abs(b["config3"]["sustained"]["value"] - b["config3"]["value"]) / b["config3"]["value"] < 0.05
+    # ... and what the shipped product alone reaches at the kernels' occupancy: the practical ceiling of frac, measured live
+    e = json.loads([l for l in open(os.path.join(root, "profiles", "r04_d_bench.txt")) if l.startswith("{")][-1])
+    pc = e["product_ceiling"]
+    assert 0.6 < pc["product_frac_1_wave"] < pc["product_frac_2_waves"] < 0.9
+    assert e["roofline"]["frac"] < e["config3"]["roofline"]["frac"] < pc["product_frac_2_waves"]
     full = json.loads([l for l in open(os.path.join(root, "profiles", "r04_config5_full.txt")) if l.startswith("{")][-1])
     assert full["config"]["emulated_world"] == 8 and full["n_gpus"] == 1 and full["config"]["batch_per_gpu"] == 1048576
     assert full["valid_total_all_ranks"] == 1048576 and full["verified_all"] is True

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string>
 #include "../threshold_crypto_amd/csrc/tc_tower.h"
 
 using namespace tc;
@@ -116,7 +117,8 @@ static void launch_product(int blocks, int iters, void* in, void* out) {
 }
 static void launch_peak(int blocks, int iters, void* out, void*) { hipLaunchKernelGGL(k_peak, dim3(blocks), dim3(64), 0, 0, (uint64_t*)out, 777u, iters); }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool ceiling_only = argc > 1 && std::string(argv[1]) == "--ceiling";   // one line for bench.py: peak + the product at 1 / 2 waves
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
     fprintf(stderr, "no HIP device\n");
@@ -141,6 +143,18 @@ int main() {
   const double peak = (double)simds * 4 * 40000 * 64 * 64 / (peak_ms * 1e-3) / 1e12;
   printf("{\"device\": \"%s\", \"simds\": %d, \"peak_T_lane_mac_per_s\": %.2f, \"peak_is\": \"v_mad_i64_i32, two chained accumulators, 4 waves per SIMD, %.1f ms\"}\n",
          p.gcnArchName, simds, peak, peak_ms);
+  if (ceiling_only) {
+    double rate[2];
+    for (int w = 1; w <= 2; w++) {
+      const float ms = time_launch(launch_product<0>, simds * w, 8000, d_in, d_out);
+      rate[w - 1] = (double)simds * w * 64 * 8000 * 588.0 / (ms * 1e-3) / 1e12;
+    }
+    printf("{\"same_process_peak_T\": %.2f, \"product_T_1_wave\": %.2f, \"product_T_2_waves\": %.2f, \"product_frac_1_wave\": %.3f, \"product_frac_2_waves\": %.3f, "
+           "\"is\": \"fq2p_mul_call alone (tools/ubench_product): what the shipped lane-pair product reaches with one / two waves per SIMD, as a fraction of the "
+           "v_mad_i64_i32 rate measured in the same process\"}\n",
+           peak, rate[0], rate[1], rate[0] / peak, rate[1] / peak);
+    return 0;
+  }
   const char* names[6] = {"mul (x = x*y)", "mix (x = x*y; y = y^2 + x)", "two independent chains (x = x*y; u = u*v)",
                           "mul + sum, difference and carry normalisation of an operand (no memory)",
                           "mul + 14 registers through scratch (store, reload into the next operands)",
