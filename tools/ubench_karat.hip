@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64, 2) void k_mul(const int32_t* in, int32_t* out, 
 #if defined(__HIP_DEVICE_COMPILE__)
   TC_NOUNROLL for (int it = 0; it < ITERS; it++) {
     FqRaw r = K ? fq2p_mulk_call(x.l[0], x.l[1], x.l[2], x.l[3], x.l[4], x.l[5], x.l[6], x.l[7], x.l[8], x.l[9], x.l[10], x.l[11], x.l[12], x.l[13], y.l[0], y.l[1], y.l[2], y.l[3], y.l[4], y.l[5], y.l[6], y.l[7], y.l[8], y.l[9], y.l[10], y.l[11], y.l[12], y.l[13], odd)
-                  : fq2p_mul_call(x.l[0], x.l[1], x.l[2], x.l[3], x.l[4], x.l[5], x.l[6], x.l[7], x.l[8], x.l[9], x.l[10], x.l[11], x.l[12], x.l[13], y.l[0], y.l[1], y.l[2], y.l[3], y.l[4], y.l[5], y.l[6], y.l[7], y.l[8], y.l[9], y.l[10], y.l[11], y.l[12], y.l[13], odd);
+                  : fq2p_mul_call(x.l[0], x.l[1], x.l[2], x.l[3], x.l[4], x.l[5], x.l[6], x.l[7], x.l[8], x.l[9], x.l[10], x.l[11], x.l[12], x.l[13], y.l[0], y.l[1], y.l[2], y.l[3], y.l[4], y.l[5], y.l[6], y.l[7], y.l[8], y.l[9], y.l[10], y.l[11], y.l[12], y.l[13]);
     for (int i = 0; i < FQ_LIMBS; i++) {
       y.l[i] = x.l[i];
       x.l[i] = r.l[i];
