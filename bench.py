@@ -598,7 +598,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         extras["threshold_decryptions_incl_ciphertext_verify_per_s"] = round(B * world / (e2 - e0), 1)
         assert int(okc.to(torch.int32).sum().item()) == B and int(dst.to(torch.int32).sum().item()) == 0
         assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item()), "threshold decryption returned wrong plaintext"
-        legs["threshold_decrypt"] = roofline("k_combine_fast<Fq> + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
+        legs["threshold_decrypt"] = roofline("k_combine_fast_g1_arena + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
                                              "combine_g1", t, B, dec_kernel_ms, peak)
         cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS.get("hash_g1_g2", EXECUTED_MACS["hash_g2"])
         legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
@@ -607,7 +607,7 @@ def run_config2(args, eng, dev, rank, world, peak):
                    "is": "BASELINE config 4: Ciphertext::verify (hash_g1_g2 + pairing check) then PublicKeySet::decrypt (G1 combine + "
                          "keystream) over the batch; every plaintext compared with the workload's",
                    "kernel_ms": {"ciphertext_verify": round(cv_kernel_ms, 3), "decrypt": round(dec_kernel_ms, 3)},
-                   "roofline": roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast<Fq> + k_xor_with_hash", None, None,
+                   "roofline": roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast_g1_arena + k_xor_with_hash", None, None,
                                         "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
                                         executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"])}
     if not args.no_extras and not harness and not args.profile_run:

@@ -266,11 +266,12 @@ def test_api_mirror_takes_into_fr_keys(engine, rnd):
 
 
 def test_g1_two_wave_kernels_equal_the_one_wave_kernels(engine, rnd):
-    """Above 65 536 jobs the single G1 multiplication and the G1 combine fast path run their TWO-waves-per-SIMD builds
-    (k_g1_mul_arena, k_combine_fast_g1_arena: 256 registers, the base-4 GLV ladder's table in the lane's arena entries).  A
-    70 000-job call must return exactly what two calls of 35 000 jobs (the register-table kernels) return -- DecryptionShare
-    generation (src/lib.rs:460-462) and PublicKeySet::decrypt's combination (src/lib.rs:618-626) with the D = 1, 2^a and generic
-    denominators all present, an identity operand, an undecodable one -- and Oracle B recomputes a sample."""
+    """The single G1 multiplication and the G1 combine fast path run their TWO-waves-per-SIMD builds (k_g1_mul_arena,
+    k_combine_fast_g1_arena: 256 registers, the base-4 GLV ladder's table in the lane's arena entries) at every batch size.  A
+    70 000-job call -- more waves than SIMDs, so lanes share their SIMD and the arena slots turn over -- must return exactly what
+    two calls of 35 000 jobs return: DecryptionShare generation (src/lib.rs:460-462) and PublicKeySet::decrypt's combination
+    (src/lib.rs:618-626) with the D = 1, 2^a and generic denominators all present, an identity operand, an undecodable one --
+    and Oracle B recomputes a sample."""
     B, t = 70000, 3
     e = engine
     e.set_input_checks(False)

@@ -299,10 +299,13 @@ void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general, TableArena ta) {
   if (!B) return;
   if (idx && t >= 1 && t <= 3) {
-    if (ta.mem && ta.flags && B > kG1ArenaMinJobs)
-      hipLaunchKernelGGL(k_combine_fast_g1_arena, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, ta);
-    else
+    if (!ta.mem || !ta.flags) return;   // (the arena could not be allocated: the call has failed already)
+#if TC_G1_ARENA_MIN > 0
+    if (B <= kG1ArenaMinJobs)
       hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});
+    else
+#endif
+      hipLaunchKernelGGL(k_combine_fast_g1_arena, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, ta);
   }
   hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, TableArena{nullptr, nullptr});
 }

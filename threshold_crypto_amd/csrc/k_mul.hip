@@ -137,14 +137,18 @@ __global__ void k_fill_g1_generator(uint8_t* out96, uint8_t* out96_unfix) {
   }
 }
 
-// ta: the context's table arena, or {nullptr, nullptr} to force the register-table kernel
+// ta: the context's table arena (the per-lane ladder tables live there)
 void launch_g1_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {
-  if (!(S * B)) return;
+  if (!(S * B) || !ta.mem || !ta.flags) return;
+#if TC_G1_ARENA_MIN > 0
   static const char* force = getenv("TC_G1_MUL_FORM");  // experiments: "arena" / "regs"
-  const bool arena = ta.mem && ta.flags && (force ? force[0] == 'a' : S * B > kG1ArenaMinJobs);
-  if (arena) hipLaunchKernelGGL(k_g1_mul_arena, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, ta);
-  else hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, TableArena{nullptr, nullptr});
+  if (force ? force[0] != 'a' : S * B <= kG1ArenaMinJobs) {
+    hipLaunchKernelGGL(k_point_mul<Fq>, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, TableArena{nullptr, nullptr});
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(k_g1_mul_arena, dim3(grid_for(S * B)), dim3(kBlock), 0, st, fr, pts, S, B, out, status, ta);
 }
 void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status) {

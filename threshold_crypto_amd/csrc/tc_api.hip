@@ -451,7 +451,7 @@ static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts
   k.check_points(g2, d_pts, PB, 1, 1, B, S);
   if (!k.failed) {
     if (g2) tc::launch_g2_mul(ctx->stream, k.tables(), d_fr, d_pts, S, B, d_out, d_st);
-    else tc::launch_g1_mul(ctx->stream, S * B > tc::kG1ArenaMinJobs ? k.tables() : tc::TableArena{nullptr, nullptr}, d_fr, d_pts, S, B, d_out, d_st);
+    else tc::launch_g1_mul(ctx->stream, k.tables(), d_fr, d_pts, S, B, d_out, d_st);
   }
   k.apply_checks(S * B, d_st, d_out, PB, nullptr);
   k.end_timing();
@@ -581,7 +581,7 @@ static void combine_launch(Call& k, bool g2, size_t t, size_t n, const uint64_t*
   }
   else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds in G1: the same two stages
   else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need,
-                             B > tc::kG1ArenaMinJobs ? k.tables() : tc::TableArena{nullptr, nullptr});
+                             k.tables());
 }
 
 // samples.len() <= t  =>  Err(NotEnoughShares) for every job        (src/lib.rs:731-733)
@@ -1179,7 +1179,7 @@ static int verified_decrypt(tc_ctx* ctx, const uint8_t* sk, const uint8_t* u, co
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
     tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok, k.pairing_ws(B));  // src/lib.rs:511
     k.apply_checks(B, nullptr, nullptr, 0, d_ok);
-    tc::launch_g1_mul(ctx->stream, B > tc::kG1ArenaMinJobs ? k.tables() : tc::TableArena{nullptr, nullptr}, d_sk, d_u, 1, B, d_pt, d_st);
+    tc::launch_g1_mul(ctx->stream, k.tables(), d_sk, d_u, 1, B, d_pt, d_st);
     // `if !ct.verify() { return None; }` (src/lib.rs:385, 453): a ciphertext that fails the check gets the identity, never [sk] u
     tc::launch_invalidate_jobs(ctx->stream, d_ok, 1, 1, B, d_st, d_pt, 96, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);  // skips flagged jobs: zeros

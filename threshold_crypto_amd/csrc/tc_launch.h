@@ -27,9 +27,14 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: the jobs are registe
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// G1 kernels take the two-waves-per-SIMD form (table in the arena) from here on: one lane per job fills one wave per SIMD at
-// 65 536 jobs, and only a second wave can use the other half of the multiplier's issue slots
-constexpr size_t kG1ArenaMinJobs = 65536;
+// The G1 ladder kernels keep their per-lane table in the HBM arena and fit 256 registers (two waves per SIMD) at
+// EVERY batch size since the end of r04: the register-table builds they replaced (377 registers + 121 AGPRs, 7 KB of scratch per
+// lane) were no faster below 65 536 jobs (profiles/r04_g1_arena_all_sizes.txt: single multiplications 7-16 % SLOWER, the
+// combination 1 % faster) and are only compiled with -DTC_G1_ARENA_MIN=<jobs> (experiments).
+#ifndef TC_G1_ARENA_MIN
+#define TC_G1_ARENA_MIN 0
+#endif
+constexpr size_t kG1ArenaMinJobs = TC_G1_ARENA_MIN;
 void launch_g1_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
                    uint8_t* status);
 void launch_g2_mul(hipStream_t st, TableArena ta, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
@@ -71,7 +76,7 @@ void launch_lagrange(hipStream_t st, const uint64_t* idx, size_t n_per_job, size
 size_t lagrange_all_ws_words(size_t t, size_t B);
 void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
                          uint8_t* status);
-// ta: the table arena when B > kG1ArenaMinJobs (the fast path then runs its two-waves-per-SIMD build), else {nullptr, nullptr}
+// ta: the table arena (the fast path's per-lane ladder tables); may be empty when idx == nullptr (no fast path)
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general,
                        TableArena ta = TableArena{nullptr, nullptr});
