@@ -20,7 +20,12 @@ consecutive launches overlap at their ends, "overlapped": true), `sustained` the
 verified (config 3: PublicKey::verify_g2, src/lib.rs:108-110; every 16th signature replaced by its neighbour's, so
 the expected ok-vector is known), re-signed, verified with hashing on the device, and run through the
 threshold-decryption path (config 4: Ciphertext::verify + PublicKeySet::decrypt); each leg carries its own roofline
-object and ANY failing leg fails the run.
+object and ANY failing leg fails the run.  Beside `frac` (executed multiply-adds / the live-measured v_mad_i64_i32 peak) the line says
+what bounds it from above and what it was charged for: `product_ceiling` = what the shipped lane-pair product alone reaches at one /
+two waves per SIMD (tools/ubench_product --ceiling), `sustained.clock` / `config3.sustained.clock` = shader clock and board power
+sampled with rocm-smi while the leg loops, `roofline.frac_at_kernel_clock` = frac x peak clock / that clock, `wire` =
+the bytes-in / bytes-out combination (tc_combine_signatures_wire_batch), and with --latency-table one call's latency at B = 1 ... 4 096
+against one CPU core.
 
 --config 5 (BASELINE "t=67, N=200, batch=1 048 576 mixed sign+combine+verify sharded across 8 GPUs"): one step =
 sign the t+1 selected shares of every job ON the device, combine them, verify the result; 131 072 jobs per GPU (weak
