@@ -305,3 +305,32 @@ def test_g1_two_wave_kernels_equal_the_one_wave_kernels(engine, rnd):
             assert rc == 0 and want == bytes(comb[j]), j
     finally:
         e.set_input_checks(True)
+
+
+def test_g1_combination_grouped_by_class_equals_ungrouped(engine):
+    """From 524 288 jobs on the G1 fast path groups its jobs by the class of their common denominator (k_combine_classify /
+    k_combine_scatter, a wave of D = 1 jobs skips the [1 / D] ladder: csrc/tc_launch.h kG1GroupMinJobs).  PublicKeySet::decrypt's
+    combination (src/lib.rs:618-626) over 524 288 jobs with the bench's random 4-of-10 subsets -- every class present -- must
+    return exactly what eight ungrouped calls of 65 536 jobs return; Oracle B recomputes 64 jobs spread over the batch."""
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    e = engine
+    e.set_input_checks(False)
+    try:
+        wl = ThresholdSigWorkload(e, 3, 10, 65536)
+        B = 524288
+        r = np.random.default_rng(23)
+        fr = r.integers(0, 256, size=(4, 32), dtype=np.uint8)
+        fr[:, 31] &= 0x3F
+        pts, st = e.g1_mul(fr, np.tile(wl.master_pk[None], (B, 1)))      # (B, 4, 96): four "decryption shares" per job
+        assert not st.any()
+        idx = np.ascontiguousarray(np.tile(wl.idx, (B // 65536, 1)))
+        big, stb = e.combine_g1(3, idx, pts)
+        assert not stb.any()
+        for lo in range(0, B, 65536):
+            part, stp = e.combine_g1(3, np.ascontiguousarray(idx[lo:lo + 65536]), np.ascontiguousarray(pts[lo:lo + 65536]))
+            assert not stp.any() and (part == big[lo:lo + 65536]).all(), lo
+        pick = np.unique(np.linspace(0, B - 1, 64).astype(np.int64))
+        want, rc = c.combine_g1_batch(3, idx[pick], pts[pick], c.host_threads())
+        assert not rc.any() and (want == big[pick]).all()
+    finally:
+        e.set_input_checks(True)

@@ -197,13 +197,18 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
 
 // G1 above one wave per SIMD (more than 65 536 jobs): 256 registers so that two waves share a SIMD, the [1 / D] ladder's table in
 // the lane's arena entries (k_mul.hip k_g1_mul_arena explains)
+// perm / slots: the jobs grouped by the class of their denominator (k_combine_classify / k_combine_scatter, as in G2) so that a
+// wave of D = 1 jobs skips the [1 / D] ladder altogether (tc_jobs.h combine_divide_arena); perm = nullptr: the jobs' own order
 __global__ __launch_bounds__(kBlock, 2) void k_combine_fast_g1_arena(size_t t, size_t n_per_job, const uint64_t* __restrict__ idx,
                                                                   const uint8_t* __restrict__ shares, size_t B, uint8_t* __restrict__ out,
-                                                                  uint8_t* __restrict__ status, TableArena ta) {
+                                                                  uint8_t* __restrict__ status, const uint32_t* __restrict__ perm, size_t slots,
+                                                                  TableArena ta) {
   using IO = WaveRowIO<96, 1>;
   __shared__ __attribute__((aligned(16))) uint8_t lds[IO::BYTES];
   const uint32_t tslot = table_slot_acquire(ta);
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  size_t j = B;                                            // B = no job on this lane (past the end, or class padding)
+  if (slot < slots) j = perm ? (size_t)perm[slot] : slot;
   const bool live = j < B;
   const size_t jj = live ? j : 0;
   IO io{lds, live ? shares + jj * n_per_job * 96 : nullptr, (size_t)96, live ? out + jj * 96 : nullptr};
@@ -296,16 +301,28 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
 // need_general: one zeroed word the Lagrange stage counts non-fast jobs in (nullptr when t == 0: no
 // Lagrange stage, the general kernel takes every job)
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general, TableArena ta) {
+                       const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general, TableArena ta,
+                       uint8_t* cls, uint32_t* counters, uint32_t* perm) {
   if (!B) return;
   if (idx && t >= 1 && t <= 3) {
     if (!ta.mem || !ta.flags) return;   // (the arena could not be allocated: the call has failed already)
+    size_t slots = B;
+    if (perm && cls && counters) {
+      slots = combine_group_slots(B);
+      (void)hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st);
+      (void)hipMemsetAsync(perm, 0xff, slots * sizeof(uint32_t), st);
+      const unsigned gb = (unsigned)((B + kGroupBlock - 1) / kGroupBlock);
+      hipLaunchKernelGGL(k_combine_classify, dim3(gb), dim3(kGroupBlock), 0, st, idx, n_per_job, t, B, cls, counters);
+      hipLaunchKernelGGL(k_combine_scatter, dim3(gb), dim3(kGroupBlock), 0, st, cls, B, counters, perm);
+    } else {
+      perm = nullptr;
+    }
 #if TC_G1_ARENA_MIN > 0
     if (B <= kG1ArenaMinJobs)
       hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});
     else
 #endif
-      hipLaunchKernelGGL(k_combine_fast_g1_arena, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, ta);
+      hipLaunchKernelGGL(k_combine_fast_g1_arena, dim3(grid_for(slots)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots, ta);
   }
   hipLaunchKernelGGL(k_combine_general<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, lam, B, out, status, need_general, TableArena{nullptr, nullptr});
 }

@@ -544,7 +544,7 @@ static void combine_launch(Call& k, bool g2, size_t t, size_t n, const uint64_t*
   // G2, t <= 3: jobs are grouped by the class of their Lagrange denominator so that whole waves take
   // the cheap forms of the final division (tc_jobs.h combine_divide); not worth three launches for a
   // batch that fills a fraction of the machine anyway
-  const bool group = g2 && !d_idx_fr && t >= 1 && t <= 3 && B >= 4096;
+  const bool group = !d_idx_fr && t >= 1 && t <= 3 && (g2 ? B >= 4096 : B >= tc::kG1GroupMinJobs);
   uint8_t* d_cls = group ? k.temp<uint8_t>(B) : nullptr;
   uint32_t* d_counters = group ? k.temp<uint32_t>(8) : nullptr;
   uint32_t* d_perm = group ? k.temp<uint32_t>(tc::combine_group_slots(B)) : nullptr;
@@ -581,7 +581,7 @@ static void combine_launch(Call& k, bool g2, size_t t, size_t n, const uint64_t*
   }
   else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds in G1: the same two stages
   else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need,
-                             k.tables());
+                             k.tables(), d_cls, d_counters, d_perm);
 }
 
 // samples.len() <= t  =>  Err(NotEnoughShares) for every job        (src/lib.rs:731-733)

@@ -246,6 +246,13 @@ TC_HD G1Jac combine_divide(const G1Jac& q, uint64_t d_abs, bool d_neg) {
 }
 // the same with the ladder's table in the lane's arena entries (the two-waves-per-SIMD build of k_combine_fast<Fq>)
 TC_HD G1Jac combine_divide_arena(const G1Jac& q, uint64_t d_abs, bool d_neg) {
+  // a wave whose jobs all have D = 1 (the combine kernels group jobs by class from kG1GroupMinJobs on) has nothing to divide by;
+  // G1 has no cheap form for D = 2^a (the G2 shortcut rests on psi = [x])
+  if (!wave_any(d_abs != 1)) {
+    G1Jac r = q;
+    r.y = Fq::select(d_neg, -r.y, r.y);
+    return r;
+  }
   uint32_t dinv[8];
   fr_inverse_of_small(d_abs, d_neg, dinv);
   G1Jac r = g1_mul_glv_arena(G1Affine{q.x, q.y, q.is_inf()}, dinv);

@@ -77,9 +77,16 @@ size_t lagrange_all_ws_words(size_t t, size_t B);
 void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, size_t t, size_t B, uint32_t* lam, uint32_t* ws,
                          uint8_t* status);
 // ta: the table arena (the fast path's per-lane ladder tables); may be empty when idx == nullptr (no fast path)
+// cls / counters / perm (all three or none): scratch of the caller for grouping the fast path's jobs by denominator class, as in G2
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general,
-                       TableArena ta = TableArena{nullptr, nullptr});
+                       TableArena ta = TableArena{nullptr, nullptr}, uint8_t* cls = nullptr, uint32_t* counters = nullptr,
+                       uint32_t* perm = nullptr);
+// From this many jobs on the G1 fast path groups its jobs by denominator class (a wave of D = 1 jobs -- a fifth of the 4-of-10
+// subsets -- skips the [1 / D] ladder).  It only pays once a SIMD sees several rounds of waves: measured 3.5 % slower at 131 072
+// jobs (every wave resident at once: the launch lasts as long as two generic waves on one SIMD, grouped or not), equal at
+// 262 144, 8 % faster at 524 288 (profiles/r04_g1_group_ab.txt).
+constexpr size_t kG1GroupMinJobs = 524288;
 // `T: IntoFr` abscissae beyond u64 (tc_combine_g{1,2}_fr_batch): idx_fr = B x n_per_job x 8 canonical LE words.
 //   launch_fr_idx_narrow   idx64[i] = the value when it fits 64 bits; *wide counts the ones that do not; valid[j] (preset
 //                          to 1) is cleared for a job that owns a non-canonical encoding (>= r) among its first `take`
