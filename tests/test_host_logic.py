@@ -138,7 +138,7 @@ def _check_round4_lines(root, macs):
     """round 4: the pairing check is three kernels (prepared lines), the line has a `wire` leg, the profile constants bench.py
     embeds come from the capture committed with the line, and config 5 has run at its full 1 048 576 jobs on one GPU"""
     import json
-    d = json.loads([l for l in open(os.path.join(root, "profiles", "r04_e_bench.txt")) if l.startswith("{")][-1])   # the final build (r04_a: mid-round)
+    d = json.loads([l for l in open(os.path.join(root, "profiles", "r04_f_bench.txt")) if l.startswith("{")][-1])   # the final build (r04_a: mid-round)
     B = d["config"]["batch_per_gpu"]
     assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 == d["ranks"]["world_size"] and d["vs_baseline"] is None
     assert d["config"]["overlapped"] is False and abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
@@ -158,10 +158,10 @@ def _check_round4_lines(root, macs):
     assert abs(d["wire"]["value"] - B / (d["wire"]["ms_per_step"] * 1e-3)) / d["wire"]["value"] < 2e-3
     assert d["wire"]["value"] < d["value"]                    # the checked decode of t + 1 shares is most of the wire call
     prof = json.load(open(os.path.join(root, "profiles", "profile_constants.json")))
-    assert prof["combine_g2_t3"]["source"] == "profiles/r04_e_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
+    assert prof["combine_g2_t3"]["source"] == "profiles/r04_f_rocprofv3_summary.csv" == prof["pairing_check"]["source"]
     assert prof["pairing_check"]["kernel"] == "k_miller_lines + k_miller_accumulate + k_final_exp"
     assert d["config3"]["roofline"]["traffic"] == prof["pairing_check"]["traffic_bytes"] < 30e9        # was 41.7 GB in round 3
-    summary = open(os.path.join(root, "profiles", "r04_e_rocprofv3_summary.csv")).read()
+    summary = open(os.path.join(root, "profiles", "r04_f_rocprofv3_summary.csv")).read()
     avg = {}
     for line in summary.splitlines():
         f = line.split(",")
