@@ -161,6 +161,13 @@ def test_design_quotes_the_shipped_kernel_resources():
     assert table["k_hash_g1_g2"]["spilled_sgprs"] < 100 and table["k_encrypt"]["spilled_sgprs"] < 100
     assert table["k_g1_mul_arena"]["registers"] <= 256 and table["k_g1_mul_arena"]["of_which_agpr"] == 0
     assert table["k_combine_fast_g1_arena"]["registers"] <= 256 and table["k_combine_fast_g1_arena"]["of_which_agpr"] == 0
+    # the few spill figures the prose repeats outside the block must be the binary's too
+    text = open(kr.DESIGN).read()
+    triple = "%d / %d / %d" % (table["k_miller_lines"]["spilled_vgprs"], table["k_miller_accumulate"]["spilled_vgprs"], table["k_final_exp"]["spilled_vgprs"])
+    assert ("Spills 2 238 → **%s**" % triple) in text, triple
+    assert ("its %d spilled registers" % table["k_combine_fast_g1_arena"]["spilled_vgprs"]) in text
+    assert ("`k_hash_g1_g2` 6 626 → %d and `k_encrypt` 6 630 → %d spilled SGPRs" % (table["k_hash_g1_g2"]["spilled_sgprs"], table["k_encrypt"]["spilled_sgprs"])) in text
+    assert "k_point_mul<Fq>" not in table and "k_combine_fast<Fq>" not in table      # the 377-register G1 builds are gone
 
 
 def test_null_context_is_an_error_not_a_crash():
