@@ -63,6 +63,8 @@ MAC_PER_FQMUL = 300
 # (tests/count_ops.py).  Two lanes work on a G2 job; work inside Fq2 operations is split between them, Fq
 # work outside (inversions, root exponentiations) is done by both and counted twice.
 EXECUTED_MACS = json.load(open(os.path.join(ROOT, "profiles", "executed_macs.json")))
+# the same with the work both lanes of a pair repeat identically counted ONCE (tests/count_ops.py --json-useful): `frac_useful`
+USEFUL_MACS = json.load(open(os.path.join(ROOT, "profiles", "useful_macs.json")))
 # algorithmic bytes per unit (canonical uncompressed affine I/O)
 ALG_BYTES = {"combine_g2": lambda t: (t + 1) * (192 + 8) + 192, "combine_g2_wire": lambda t: (t + 1) * (96 + 8) + 96, "verify_g2": lambda t: 385, "g2_mul": lambda t: 192,
              "hash_g2": lambda t: 207, "combine_g1": lambda t: (t + 1) * (96 + 8) + 96 + 32,
@@ -167,13 +169,14 @@ def measure_peak():
     return best
 
 
-def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traffic_key=None, extra=None, executed=None):
+def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traffic_key=None, extra=None, executed=None, useful=None):
     """frac = the kernel's OWN multiply-add count / time / peak (utilisation of the integer multiplier);
     algorithmic_speedup = reference-algorithm work / executed work (what the smarter algorithm buys)."""
     if not kernel_ms or kernel_ms < 1e-6:
         return None     # (test harness: nothing was timed)
     sec = kernel_ms * 1e-3
     per_unit = executed if executed is not None else EXECUTED_MACS[unit_key]
+    useful_per_unit = useful if useful is not None else (USEFUL_MACS[unit_key] if executed is None else None)
     executed_total = per_unit * units
     ref = W_FQMUL[ref_key] * MAC_PER_FQMUL * units if ref_key else None
     ach = executed_total / sec / 1e12
@@ -184,6 +187,9 @@ def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traf
          "peak_clock_GHz": peak["clock_ghz"], "peak_source": peak["source"],
          "executed_macs_per_unit": per_unit,
          "achieved_is": "v_mad the kernel executes per unit (tests/count_ops.py) x units / HIP-event kernel time",
+         "useful_macs_per_unit": useful_per_unit,
+         "frac_useful": round(useful_per_unit * units / sec / 1e12 / peak["tmacs"], 4) if useful_per_unit else None,
+         "frac_useful_is": "frac with the Fq-only work both lanes of a pair execute identically counted once (tests/count_ops.py --json-useful)",
          "algorithmic_bytes_per_launch": alg_bytes,
          "hbm_achieved_GBps": round(alg_bytes / sec / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBPS,
          "hbm_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, 6),
@@ -579,7 +585,8 @@ def run_config2(args, eng, dev, rank, world, peak):
         sync()
         extras["hash_g2_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
         assert bool((hh == d_hashes).all().item())
-        legs["hash_g2"] = roofline("k_hash_g2", "hash_g2", "hash_g2", "hash_g2", t, B, hash_kernel_ms, peak)
+        legs["hash_g2"] = roofline("k_hash_g2_x2" if B >= 131072 else "k_hash_g2", "hash_g2_x2" if B >= 131072 else "hash_g2", "hash_g2", "hash_g2", t, B,
+                                   hash_kernel_ms, peak)
         # ---- config 4: threshold decryption = Ciphertext::verify + G1 combine + keystream -------------------
         we = ThresholdEncWorkload(eng, t, N, B, start=start)
         du, dv, dw = torch.from_numpy(we.u).to(dev), torch.from_numpy(we.v).to(dev), torch.from_numpy(we.w).to(dev)
@@ -605,16 +612,19 @@ def run_config2(args, eng, dev, rank, world, peak):
         assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item()), "threshold decryption returned wrong plaintext"
         legs["threshold_decrypt"] = roofline("k_combine_fast_g1_arena + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
                                              "combine_g1", t, B, dec_kernel_ms, peak)
-        cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS.get("hash_g1_g2", EXECUTED_MACS["hash_g2"])
+        # (the hashes take two messages per lane pair from 131 072 messages on: csrc/tc_launch.h kDuoMinHash)
+        hkey = "hash_g1_g2_x2" if B >= 131072 else "hash_g1_g2"
+        cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS[hkey]
+        cv_useful = USEFUL_MACS["verify_g2"] + USEFUL_MACS[hkey]
         legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
-                                             cv_kernel_ms, peak, executed=cv_macs)
+                                             cv_kernel_ms, peak, executed=cv_macs, useful=cv_useful)
         config4 = {"value": round(B * world / (e2 - e0), 1), "unit": "threshold_decryptions/s", "ms_per_step": round((e2 - e0) * 1e3, 3),
                    "is": "BASELINE config 4: Ciphertext::verify (hash_g1_g2 + pairing check) then PublicKeySet::decrypt (G1 combine + "
                          "keystream) over the batch; every plaintext compared with the workload's",
                    "kernel_ms": {"ciphertext_verify": round(cv_kernel_ms, 3), "decrypt": round(dec_kernel_ms, 3)},
                    "roofline": roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast_g1_arena + k_xor_with_hash", None, None,
                                         "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
-                                        executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"])}
+                                        executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"], useful=cv_useful + USEFUL_MACS["combine_g1_t3_fast"])}
     if not args.no_extras and not harness and not args.profile_run:
         # ---- the headline step with the context's default membership tests on every share -------------------------
         eng.set_input_checks(True)
@@ -646,14 +656,17 @@ def run_config2(args, eng, dev, rank, world, peak):
         sync()
         assert int(wst.to(torch.int32).sum().item()) == 0 and bool((wsig == want).all().item()), "wire-level combine differs from compress(combine)"
         wall, kern = min(wire_ms)
-        wire_macs = (t + 1) * EXECUTED_MACS["g2_decompress"] + EXECUTED_MACS["combine_g2_t3_fast"]
+        # (more than 32 768 decodes per call run two points per lane pair: csrc/tc_launch.h kDuoMinDecode, tc_duo.h)
+        dkey = "g2_decompress_x2" if B * (t + 1) > 32768 else "g2_decompress"
+        wire_macs = (t + 1) * EXECUTED_MACS[dkey] + EXECUTED_MACS["combine_g2_t3_fast"]
+        wire_useful = (t + 1) * USEFUL_MACS[dkey] + USEFUL_MACS["combine_g2_t3_fast"]
         wire = {"value": round(B * world / wall, 1), "unit": "combine_signatures/s", "ms_per_step": round(wall * 1e3, 3),
                 "is": "tc_combine_signatures_wire_batch on the BASELINE batch: %d compressed shares per job through the checked decode of from_bytes "
                       "(square root + membership test each), combined, returned as Signature::to_bytes; result compared with "
                       "compress(combine) of the timed batch" % (t + 1),
                 "algorithmic_bytes_per_job": (t + 1) * (96 + 8) + 96,
-                "roofline": roofline("k_decompress_take<Fq2> + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak,
-                                     executed=wire_macs) if t == 3 else None}
+                "roofline": roofline("k_decompress_take_g2_x2 + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak,
+                                     executed=wire_macs, useful=wire_useful) if t == 3 else None}
         extras["wire_combine_per_s"] = wire["value"]
     if not args.no_extras and not harness and not args.profile_run:
         # ---- the same combine with HOST buffers at the C ABI (pageable numpy memory): PCIe-inclusive ---------

@@ -187,10 +187,26 @@ L.hs_g1_fixed_base_mul(o.fr_to_bytes(1), buf(96)); cnt()   # (builds the host co
 L.hs_g1_fixed_base_mul(o.fr_to_bytes(rnd.randrange(o.R)), buf(96)); res["g1_fixed_base_mul"] = (cnt(), 1)
 L.hs_decompress_g2(o.g2_compressed(P2), buf(192)); res["g2_decompress"] = (cnt(), 2)
 L.hs_decompress_g1(o.g1_compressed(P1), buf(96)); res["g1_decompress"] = (cnt(), 1)
-if "--json" in sys.argv:
+# ---- two jobs per lane pair (tc_duo.h): per JOB = half of what the pair's call executes ----
+_half = lambda c: tuple(x // 2 for x in c)
+Q2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+cnt()
+L.hs_decompress_g2_x2(o.g2_compressed(P2), o.g2_compressed(Q2), buf(192), buf(192)); res["g2_decompress_x2"] = (_half(cnt()), 2)
+L.hs_hash_g2_x2.restype = None
+tot = [0] * 5
+for j in range(0, N, 2):
+    ma, mb = b"tc/msg" + j.to_bytes(8, "little"), b"tc/msg" + (j + 1).to_bytes(8, "little")
+    L.hs_hash_g2_x2(ma, ctypes.c_size_t(len(ma)), mb, ctypes.c_size_t(len(mb)), buf(192), buf(192), 1)
+    tot = [x + y for x, y in zip(tot, cnt())]
+res["hash_g2_x2"] = (tuple(x // N for x in tot), 2)
+L.hs_hash_g1_g2_x2(o.g1_uncompressed(P1), _m, ctypes.c_size_t(len(_m)), o.g1_uncompressed(P1), _m, ctypes.c_size_t(len(_m)), buf(192), buf(192), 1)
+res["hash_g1_g2_x2"] = (_half(cnt()), 2)
+if "--json" in sys.argv or "--json-useful" in sys.argv:
     import json
-    print(json.dumps({k: macs(c, lanes) for k, (c, lanes) in res.items()}, indent=1))
+    useful = "--json-useful" in sys.argv
+    print(json.dumps({k: macs(c, 1 if useful else lanes) for k, (c, lanes) in res.items()}, indent=1))
     sys.exit(0)
-print("%-26s %8s %8s %8s %8s %8s %12s" % ("job", "mul2", "split_m", "split_s", "all_mul", "all_sqr", "device v_mad"))
+print("%-40s %8s %8s %8s %8s %8s %12s %12s %6s" % ("job", "mul2", "split_m", "split_s", "all_mul", "all_sqr", "device v_mad", "useful", "dup %"))
 for k, (c, lanes) in res.items():
-    print("%-26s %8d %8d %8d %8d %8d %12d" % ((k,) + tuple(c) + (macs(c, lanes),)))
+    ex, us = macs(c, lanes), macs(c, 1)
+    print("%-40s %8d %8d %8d %8d %8d %12d %12d %6.1f" % ((k,) + tuple(c) + (ex, us, 100.0 * (ex - us) / ex)))

@@ -310,6 +310,35 @@ int hs_commitment_evaluate(const uint8_t* commit, int t, uint64_t idx, uint8_t* 
 }
 int hs_decompress_g1(const uint8_t* in, uint8_t* out) { return job_decompress<Fq>(in, out); }
 int hs_decompress_g2(const uint8_t* in, uint8_t* out) { return job_decompress<Fq2>(in, out); }
+// two jobs per lane pair (tc_duo.h): on the host one thread runs both slots of every lane-split phase
+int hs_decompress_g2_x2(const uint8_t* in_a, const uint8_t* in_b, uint8_t* out_a, uint8_t* out_b) {
+  uint8_t sa, sb;
+  job_decompress_g2_x2(in_a, in_b, out_a, out_b, sa, sb);
+  return sa | (sb << 8);
+}
+void hs_hash_g2_x2(const uint8_t* msg_a, size_t len_a, const uint8_t* msg_b, size_t len_b, uint8_t* out_a, uint8_t* out_b, int fix) {
+  job_hash_g2_x2(msg_a, len_a, msg_b, len_b, out_a, out_b, fix != 0);
+}
+int hs_hash_g1_g2_x2(const uint8_t* g1_a, const uint8_t* msg_a, size_t len_a, const uint8_t* g1_b, const uint8_t* msg_b, size_t len_b,
+                     uint8_t* out_a, uint8_t* out_b, int fix) {
+  uint8_t sa, sb;
+  job_hash_g1_g2_x2(g1_a, msg_a, len_a, g1_b, msg_b, len_b, out_a, out_b, fix != 0, sa, sb);
+  return sa | (sb << 8);
+}
+int hs_fq2_sqrt_x2(const uint8_t* a, const uint8_t* b, uint8_t* out_a, uint8_t* out_b) {
+  Fq2 x, z, y, w;
+  fq_from_be48(a, false, x.c0);
+  fq_from_be48(a + 48, false, x.c1);
+  fq_from_be48(b, false, z.c0);
+  fq_from_be48(b + 48, false, z.c1);
+  bool oka, okb;
+  fq2_sqrt_x2(x, z, y, w, oka, okb);
+  fq_to_be48(y.c0, out_a);
+  fq_to_be48(y.c1, out_a + 48);
+  fq_to_be48(w.c0, out_b);
+  fq_to_be48(w.c1, out_b + 48);
+  return (oka ? 1 : 0) | (okb ? 2 : 0);
+}
 int hs_compress_g1(const uint8_t* in, uint8_t* out) { return job_compress<Fq>(in, out); }
 int hs_compress_g2(const uint8_t* in, uint8_t* out) { return job_compress<Fq2>(in, out); }
 

@@ -334,3 +334,87 @@ def test_g1_combination_grouped_by_class_equals_ungrouped(engine):
         assert not rc.any() and (want == big[pick]).all()
     finally:
         e.set_input_checks(True)
+
+
+def test_two_jobs_per_lane_pair_forms_equal_the_one_job_forms(engine, rnd):
+    """r05 (tc_duo.h): from 65 536 jobs on the checked G2 decode (from_bytes, /root/reference/src/lib.rs:246-252), hash_g2
+    (:691-694) and hash_g1_g2 (:697-707) give a lane pair TWO jobs and run each job's Fq-only phases on one lane.  Forced on
+    and off (TC_DUO_MIN, read at every launch) over the SAME odd-sized batches -- members, the identity, points outside G2, x
+    without a point, x >= q, flag errors in either slot of a pair; ragged messages on both sides of the SHA3 rate and of the
+    64-byte switch; undecodable G1 operands -- both forms must return identical bytes and statuses, and a sample of them is
+    recomputed by Oracle A here.  (The full-size tests run the two-job form against Oracle B on every job.)"""
+    n = 1023
+    enc, want_st = [], []
+    members = [o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R)) for _ in range(6)]
+    outside = [non_member_g2(rnd) for _ in range(3)]
+    nopoint = []
+    while len(nopoint) < 3:
+        x = (rnd.randrange(o.Q), rnd.randrange(o.Q))
+        if o.g2_get_point_from_x(x, False) is None:
+            e = bytearray(x[1].to_bytes(48, "big") + x[0].to_bytes(48, "big")); e[0] |= 0x80 | (0x20 * (len(nopoint) & 1))
+            nopoint.append(bytes(e))
+    for i in range(n):
+        k = rnd.randrange(12)
+        if k < 6:
+            P = members[rnd.randrange(6)]
+            if rnd.randrange(2):
+                P = (P[0], ((-P[1][0]) % o.Q, (-P[1][1]) % o.Q))  # the other root of the same x
+            enc.append(o.g2_compressed(P)); want_st.append(0)
+        elif k == 6:
+            enc.append(o.g2_compressed(None)); want_st.append(0)
+        elif k == 7:
+            enc.append(o.g2_compressed(outside[rnd.randrange(3)])); want_st.append(3)
+        elif k == 8:
+            enc.append(nopoint[rnd.randrange(3)]); want_st.append(3)
+        elif k == 9:
+            e = bytearray(o.g2_compressed(members[0])); e[0] &= 0x7f; enc.append(bytes(e)); want_st.append(3)
+        elif k == 10:
+            e = bytearray(o.Q.to_bytes(48, "big") + (5).to_bytes(48, "big")); e[0] |= 0x80; enc.append(bytes(e)); want_st.append(3)
+        else:
+            e = bytearray(o.g2_compressed(None)); e[rnd.randrange(1, 96)] |= 1 << rnd.randrange(8); enc.append(bytes(e)); want_st.append(3)
+    msgs = [bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 31, 32, 63, 64, 65, 88, 135, 136, 137, 200]))) for _ in range(n)]
+    g1 = [o.g1_uncompressed(o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))) for _ in range(8)] + [o.g1_uncompressed(None)]
+    g1rows = []
+    for i in range(n):
+        p = bytearray(g1[rnd.randrange(len(g1))])
+        if rnd.randrange(9) == 0:
+            p[95] ^= 1  # off the curve
+        g1rows.append(bytes(p))
+    enc_a = np.frombuffer(b"".join(enc), np.uint8).reshape(n, 96).copy()
+    g1_a = np.frombuffer(b"".join(g1rows), np.uint8).reshape(n, 96).copy()
+    blob, off = pack_messages(msgs)
+    res = {}
+    saved = os.environ.get("TC_DUO_MIN")
+    try:
+        for form, minimum in (("two", "1"), ("one", str(10 ** 12))):
+            os.environ["TC_DUO_MIN"] = minimum  # read by the library at every launch (tc_launch.h duo_form)
+            pts, st = engine.g2_decompress(enc_a)
+            h = engine.hash_g2(blob, off)
+            hg, hst = engine.hash_g1_g2(g1_a, blob, off)
+            res[form] = (pts, st, h, hg, hst)
+    finally:
+        if saved is None:
+            os.environ.pop("TC_DUO_MIN", None)
+        else:
+            os.environ["TC_DUO_MIN"] = saved
+    for x, y in zip(res["two"], res["one"]):
+        assert (x == y).all(), np.flatnonzero((x != y).reshape(n, -1).any(axis=1))[:16]
+    pts, st, h, hg, hst = res["two"]
+    assert st.tolist() == want_st
+    for i in list(range(0, n, 37)) + [n - 1]:
+        if want_st[i] == 0:
+            assert bytes(pts[i]) == o.g2_uncompressed(o.g2_from_compressed(enc[i]))
+        else:
+            assert bytes(pts[i]) == o.g2_uncompressed(None)
+        assert bytes(h[i]) == o.g2_uncompressed(o.hash_g2(msgs[i]))
+    for i in list(range(0, n, 101)) + [n - 1]:
+        try:
+            P = o.g1_from_uncompressed(g1rows[i])
+            ok = True
+        except Exception:
+            ok = False
+        assert int(hst[i]) == (0 if ok else 3)
+        if ok:
+            assert bytes(hg[i]) == o.g2_uncompressed(o.hash_g1_g2(P, msgs[i]))
+        else:
+            assert bytes(hg[i]) == o.g2_uncompressed(None)

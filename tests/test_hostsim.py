@@ -904,3 +904,133 @@ def test_quad_pairing_check_matches_oracle(L, rnd):
         assert L.hs_pairing_check_quad(*ops) == want == L.hs_pairing_check(*ops)
         # ... and the prepared form (stage P -> line products in memory -> stage M -> final exponentiation)
         assert L.hs_pairing_check_prepared(*ops) == want
+
+
+# ---- two jobs per lane pair (tc_duo.h, r05): the x2 forms against the oracle AND against the one-job forms ----------------------
+def _fq2_bytes(a):
+    return be(a[0]) + be(a[1])
+
+
+def test_fq2_sqrt_x2(L, rnd):
+    """tc_sqrt.h fq2_sqrt_x2: squares with a1 != 0, squares inside Fq (both kinds: a0 a square / a non-square of Fq), zero,
+    non-squares -- the result squares to the input exactly when the input is a square, in both slots independently."""
+    def fq2_sqr(a):
+        return ((a[0] * a[0] - a[1] * a[1]) % o.Q, 2 * a[0] * a[1] % o.Q)
+    cases = []
+    for _ in range(12):
+        r = (rnd.randrange(o.Q), rnd.randrange(o.Q))
+        cases.append((fq2_sqr(r), True))
+    cases += [((rnd.randrange(1, o.Q), 0), True) for _ in range(6)]      # every element of Fq is a square in Fq2
+    cases += [((0, 0), True), ((1, 0), True), ((o.Q - 1, 0), True), ((0, 1), True), ((0, o.Q - 1), True)]
+    while len(cases) < 36:
+        a = (rnd.randrange(o.Q), rnd.randrange(1, o.Q))
+        n = (a[0] * a[0] + a[1] * a[1]) % o.Q
+        sq = pow(n, (o.Q - 1) // 2, o.Q) == 1
+        cases.append((a, sq))
+    rnd.shuffle(cases)
+    for (a, sa), (b, sb) in zip(cases[::2], cases[1::2]):
+        oa, ob = buf(96), buf(96)
+        r = L.hs_fq2_sqrt_x2(_fq2_bytes(a), _fq2_bytes(b), oa, ob)
+        assert (bool(r & 1), bool(r & 2)) == (sa, sb), (a, b)
+        for inp, out, ok in ((a, oa, sa), (b, ob, sb)):
+            y = (int.from_bytes(out.raw[:48], "big"), int.from_bytes(out.raw[48:], "big"))
+            assert (fq2_sqr(y) == inp) == ok
+
+
+def test_checked_decompress_x2(L, rnd):
+    """job_decompress_g2_x2 = job_decompress<Fq2> on each slot: members, the identity, points of the twist outside G2,
+    x with no point, x >= q, missing / stray flags -- in every slot combination."""
+    enc = []
+    for _ in range(4):
+        enc.append(o.g2_compressed(o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))))
+    enc.append(o.g2_compressed(None))
+    n = 0
+    while n < 3:
+        P0 = o.g2_get_point_from_x((rnd.randrange(o.Q), rnd.randrange(o.Q)), bool(n & 1))
+        if P0 is None:
+            continue
+        enc.append(o.g2_compressed(P0))  # on the twist, not in G2
+        n += 1
+    while n < 5:
+        x = (rnd.randrange(o.Q), rnd.randrange(o.Q))
+        if o.g2_get_point_from_x(x, False) is not None:
+            continue
+        e = bytearray(be(x[1]) + be(x[0])); e[0] |= 0x80 | (0x20 if n & 1 else 0)
+        enc.append(bytes(e))  # x^3 + b is not a square
+        n += 1
+    g = bytearray(o.g2_compressed(o.G2_GEN)); g[0] &= 0x7f; enc.append(bytes(g))           # compression flag missing
+    inf = bytearray(o.g2_compressed(None)); inf[95] = 1; enc.append(bytes(inf))             # identity with a stray bit
+    inf = bytearray(o.g2_compressed(None)); inf[0] |= 0x20; enc.append(bytes(inf))          # identity with the sign flag
+    big = bytearray(be(o.Q) + be(5)); big[0] |= 0x80; enc.append(bytes(big))                # x.c1 = q: out of range
+    big = bytearray(be(5) + be(o.Q + 1)); big[0] |= 0x80; enc.append(bytes(big))            # x.c0 > q
+    one = {}
+    for e in enc:
+        out = buf(192)
+        one[e] = (L.hs_decompress_g2(e, out), out.raw)
+    assert sorted(set(st for st, _ in one.values())) == [0, 3]
+    for a in enc:
+        for b in enc:
+            oa, ob = buf(192), buf(192)
+            r = L.hs_decompress_g2_x2(a, b, oa, ob)
+            assert (r & 0xff, oa.raw) == one[a] and (r >> 8, ob.raw) == one[b]
+
+
+def test_hash_g2_x2(L, rnd):
+    """job_hash_g2_x2 / job_hash_g1_g2_x2 = the one-message forms (and Oracle A) on each slot: message lengths on both sides of the
+    SHA3 rate and of hash_g1_g2's 64-byte switch, both forms of the cofactor constant, an undecodable G1 operand in either slot."""
+    L.hs_hash_g2_x2.restype = None
+    msgs = [b"", b"a", b"tc/x2/%d" % 7, bytes(135), bytes(136), bytes(137), bytes(range(200)), b"m" * 64, b"m" * 65]
+    msgs += [bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 90))) for _ in range(7)]
+    single = {}
+    for m in msgs:
+        a, b = buf(192), buf(192)
+        L.hs_hash_g2(m, ctypes.c_size_t(len(m)), a)
+        L.hs_hash_g2_unfixed(m, ctypes.c_size_t(len(m)), b)
+        single[m] = (a.raw, b.raw)
+    for m in msgs[:4]:
+        assert single[m][0] == o.g2_uncompressed(o.hash_g2(m))
+    for i in range(0, len(msgs), 2):
+        ma, mb = msgs[i], msgs[(i + 5) % len(msgs)]
+        for fix in (1, 0):
+            oa, ob = buf(192), buf(192)
+            L.hs_hash_g2_x2(ma, ctypes.c_size_t(len(ma)), mb, ctypes.c_size_t(len(mb)), oa, ob, fix)
+            assert oa.raw == single[ma][1 - fix] and ob.raw == single[mb][1 - fix]
+    # the last pair of an odd batch: no second output
+    oa = buf(192)
+    L.hs_hash_g2_x2(msgs[2], ctypes.c_size_t(len(msgs[2])), msgs[2], ctypes.c_size_t(len(msgs[2])), oa, None, 1)
+    assert oa.raw == single[msgs[2]][0]
+    # hash_g1_g2
+    pts = [o.g1_uncompressed(o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))) for _ in range(3)] + [o.g1_uncompressed(None)]
+    bad = bytearray(pts[0]); bad[95] ^= 1
+    pts.append(bytes(bad))  # not on the curve
+    ref = {}
+    for p in pts:
+        for m in (b"", b"x" * 64, b"y" * 65, bytes(170)):
+            out = buf(192)
+            ref[(p, m)] = (L.hs_hash_g1_g2(p, m, ctypes.c_size_t(len(m)), out), out.raw)
+    keys = list(ref)
+    assert ref[(pts[1], b"x" * 64)] == (0, o.g2_uncompressed(o.hash_g1_g2(o.g1_from_uncompressed(pts[1]), b"x" * 64)))
+    for i, ka in enumerate(keys):
+        kb = keys[(7 * i + 3) % len(keys)]
+        oa, ob = buf(192), buf(192)
+        r = L.hs_hash_g1_g2_x2(ka[0], ka[1], ctypes.c_size_t(len(ka[1])), kb[0], kb[1], ctypes.c_size_t(len(kb[1])), oa, ob, 1)
+        assert (r & 0xff, oa.raw) == ref[ka] and (r >> 8, ob.raw) == ref[kb]
+
+
+def test_hash_g2_x2_second_round(L, rnd):
+    """the forced second round of G2::random's outer loop (a cofactor-cleared identity: never in practice) in the x2 form: both
+    slots go on from their own stream positions, like the one-message form"""
+    L.hs_hash_g2_x2.restype = None
+    ma, mb = b"retry/0", b"retry/3"
+    for extra in (1, 2):
+        want = []
+        for m in (ma, mb):
+            L.hs_force_extra_hash_rounds(extra)
+            out = buf(192)
+            L.hs_hash_g2(m, ctypes.c_size_t(len(m)), out)
+            want.append(out.raw)
+        L.hs_force_extra_hash_rounds(extra)
+        oa, ob = buf(192), buf(192)
+        L.hs_hash_g2_x2(ma, ctypes.c_size_t(len(ma)), mb, ctypes.c_size_t(len(mb)), oa, ob, 1)
+        L.hs_force_extra_hash_rounds(0)
+        assert [oa.raw, ob.raw] == want

@@ -20,6 +20,34 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g1_g2(const uint8_
   if (status && pair_leader()) status[j] = st;
 }
 
+// batches from 65 536 messages on: a lane pair takes TWO messages (tc_duo.h) -- pair p hashes messages 2p and 2p + 1
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g2_x2(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
+                                                                 size_t B, uint8_t* __restrict__ out, int fix) {
+  const size_t p = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const size_t ja = 2 * p;
+  if (ja >= B) return;
+  const bool has_b = ja + 1 < B;
+  const size_t jb = has_b ? ja + 1 : ja;
+  job_hash_g2_x2(msgs + off[ja], (size_t)(off[ja + 1] - off[ja]), msgs + off[jb], (size_t)(off[jb + 1] - off[jb]), out + ja * 192,
+                 has_b ? out + jb * 192 : nullptr, fix != 0);
+}
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g1_g2_x2(const uint8_t* __restrict__ g1, const uint8_t* __restrict__ msgs,
+                                                                    const uint64_t* __restrict__ off, size_t B,
+                                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status, int fix) {
+  const size_t p = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const size_t ja = 2 * p;
+  if (ja >= B) return;
+  const bool has_b = ja + 1 < B;
+  const size_t jb = has_b ? ja + 1 : ja;
+  uint8_t sa, sb;
+  job_hash_g1_g2_x2(g1 + ja * 96, msgs + off[ja], (size_t)(off[ja + 1] - off[ja]), g1 + jb * 96, msgs + off[jb],
+                    (size_t)(off[jb + 1] - off[jb]), out + ja * 192, has_b ? out + jb * 192 : nullptr, fix != 0, sa, sb);
+  if (status && pair_leader()) {
+    status[ja] = sa;
+    if (has_b) status[jb] = sb;
+  }
+}
+
 __global__ __launch_bounds__(kBlock, TC_WAVES_G1) void k_xor_with_hash(const uint8_t* __restrict__ g1,
                                                           const uint8_t* __restrict__ data,
                                                           const uint64_t* __restrict__ off, size_t B,
@@ -64,11 +92,15 @@ void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t,
   if (M) hipLaunchKernelGGL(k_commitment_evaluate, dim3(grid_for(M)), dim3(kBlock), 0, st, commit, t, idx, M, out, status);
 }
 void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix) {
-  if (B) hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
+  if (!B) return;
+  if (duo_form(B, kDuoMinHash)) hipLaunchKernelGGL(k_hash_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
+  else hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
 }
 void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
                        uint8_t* out, uint8_t* status, bool fix) {
-  if (B) hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
+  if (!B) return;
+  if (duo_form(B, kDuoMinHash)) hipLaunchKernelGGL(k_hash_g1_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
+  else hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
 }
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
                           uint8_t* out, uint8_t* status) {

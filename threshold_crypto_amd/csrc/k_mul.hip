@@ -99,6 +99,21 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   if (status && (L == 1 || pair_leader())) status[j] = st;
 }
 
+// G2: a lane pair takes TWO points (tc_duo.h) -- pair p decodes points 2p and 2p + 1
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_decompress_g2_x2(const uint8_t* __restrict__ in, size_t B, uint8_t* __restrict__ out,
+                                                                       uint8_t* __restrict__ status) {
+  const size_t p = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const size_t ja = 2 * p, jb = 2 * p + 1;
+  if (ja >= B) return;
+  const bool has_b = jb < B;
+  uint8_t sa, sb;
+  job_decompress_g2_x2(in + ja * 96, in + (has_b ? jb : ja) * 96, out + ja * 192, has_b ? out + jb * 192 : nullptr, sa, sb);
+  if (status && pair_leader()) {
+    status[ja] = sa;
+    if (has_b) status[jb] = sb;
+  }
+}
+
 // Wire ingest for the combiners (tc_combine_signatures_wire_batch / tc_decrypt_wire_batch): the FIRST `take` of the n_per_job
 // compressed samples of every job -- exactly the samples interpolate() uses (/root/reference/src/lib.rs:727-730) -- through the
 // CHECKED decode of from_bytes (:140-146, 246-252), written compactly (job-major, take per job); valid[i] = 1 iff sample i
@@ -112,6 +127,21 @@ __global__ __launch_bounds__(kBlock, (JobLanes<F>::N > 1 ? TC_WAVES_G2 : TC_WAVE
   const size_t rec = i / take, k = i % take;
   const uint8_t st = job_decompress<F>(in + (rec * n_per_job + k) * PointIO<F>::CBYTES, out + i * PointIO<F>::BYTES);
   if (L == 1 || pair_leader()) valid[i] = st == TC_JOB_OK ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_decompress_take_g2_x2(const uint8_t* __restrict__ in, size_t n_per_job, size_t take,
+                                                                            size_t n, uint8_t* __restrict__ out, uint8_t* __restrict__ valid) {
+  const size_t p = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
+  const size_t ia = 2 * p;
+  if (ia >= n) return;
+  const bool has_b = ia + 1 < n;
+  const size_t ib = has_b ? ia + 1 : ia;
+  uint8_t sa, sb;
+  job_decompress_g2_x2(in + ((ia / take) * n_per_job + ia % take) * 96, in + ((ib / take) * n_per_job + ib % take) * 96, out + ia * 192,
+                       has_b ? out + ib * 192 : nullptr, sa, sb);
+  if (pair_leader()) {
+    valid[ia] = sa == TC_JOB_OK ? 1 : 0;
+    if (has_b) valid[ib] = sb == TC_JOB_OK ? 1 : 0;
+  }
 }
 // the matching prefix of the index array: out[j * take + k] = idx[j * n_per_job + k]
 __global__ void k_take_u64(const uint64_t* __restrict__ in, size_t n_per_job, size_t take, size_t n, uint64_t* __restrict__ out) {
@@ -177,12 +207,15 @@ void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* 
   if (B) hipLaunchKernelGGL(k_decompress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
-  if (B) hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
+  if (!B) return;
+  if (duo_form(B, kDuoMinDecode)) hipLaunchKernelGGL(k_decompress_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
+  else hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
 }
 void launch_decompress_take(hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid) {
   const size_t n = B * take;
   if (!n) return;
-  if (g2) hipLaunchKernelGGL(k_decompress_take<Fq2>, dim3(grid_for(n * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
+  if (g2 && duo_form(n, kDuoMinDecode)) hipLaunchKernelGGL(k_decompress_take_g2_x2, dim3(grid_for((n + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
+  else if (g2) hipLaunchKernelGGL(k_decompress_take<Fq2>, dim3(grid_for(n * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
   else hipLaunchKernelGGL(k_decompress_take<Fq>, dim3(grid_for(n)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
 }
 void launch_take_u64(hipStream_t st, const uint64_t* in, size_t n_per_job, size_t take, size_t B, uint64_t* out) {

@@ -260,4 +260,102 @@ TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words, bool fix = 
   return res;
 }
 
+// ---- two messages per lane pair (tc_duo.h) --------------------------------------------------------
+// The same function for TWO seeds.  Everything a message does on its own -- its ChaCha20 stream, the rejection sampling of x,
+// the Jacobi symbol of a candidate's norm, the two exponentiations of the square root -- runs on ONE lane (lane 0: message A,
+// lane 1: message B); the Fq2 work -- x^3 + b of a candidate, sign selection, cofactor clearing -- runs for A and then for B
+// with both lanes.  One candidate per message and round (the one-message form tests two candidates of ONE message on its two
+// lanes): per round the pair decides two candidates either way.  Same candidates, same order, same result.
+// the tail of one candidate: the root G2::random keeps (get_point_from_x: the lexicographically larger one iff `greatest`) and
+// scale_by_cofactor.  A real function: the two-message form calls it once per message.
+TC_HD_NOINLINE G2Jac g2_random_finish(const Fq2& x, const Fq2& y, bool greatest, bool fix) {
+  const Fq2 negy = -y;
+  // y < -y  <=>  -y is the lexicographically larger (y != -y unless y = 0)
+  const bool y_lt_negy = fq2_lex_largest(negy) && !(y == negy);
+  const G2Affine cand{x, (y_lt_negy ^ greatest) ? y : negy, false};
+  return g2_clear_cofactor(cand, fix);  // = [h2] cand, the value scale_by_cofactor returns (fix = false: tc_gls.h)
+}
+struct Seed8 {
+  uint32_t w[8];
+};
+TC_HD_NOINLINE void g2_random_from_seed_x2(const Duo<Seed8>& seed, bool fix, G2Jac& ra, G2Jac& rb) {
+  Duo<ChaChaRng> rng;
+  Duo<uint32_t> consumed;  // candidates of the slot's stream used up so far
+  Duo<bool> done;
+  duo_each([&](int s) {
+    consumed.at(s) = 0;
+    done.at(s) = false;
+  });
+#if defined(TC_TEST_HOOKS)
+  int forced = g_tc_force_extra_rounds;
+#endif
+  ra = G2Jac::infinity();
+  rb = G2Jac::infinity();
+  bool all_done = false;
+  TC_NOUNROLL while (wave_any(!all_done)) {
+    if (all_done) continue;
+    Duo<Fq> xre, xim;
+    Duo<bool> greatest, have;
+    duo_each([&](int s) {
+      xre.at(s) = Fq::zero();  // (a finished slot sits the round out with the stand-in x = 0)
+      xim.at(s) = Fq::zero();
+      greatest.at(s) = false;
+      have.at(s) = done.at(s);
+      // (re)position the stream after the candidates already consumed (second rounds: [h2] cand = 0, for exactness only)
+      rng.at(s).init(seed.at(s).w);
+      uint32_t skip = consumed.at(s);
+      TC_NOUNROLL while (wave_any(skip != 0)) {
+        if (skip != 0) {
+          fq_random(rng.at(s));
+          fq_random(rng.at(s));
+          rng.at(s).next_u32();
+          skip--;
+        }
+      }
+    });
+    bool pending = true;
+    TC_NOUNROLL while (wave_any(pending)) {
+      duo_each([&](int s) {
+        if (!have.at(s)) {
+          xre.at(s) = fq_random(rng.at(s));  // c0 is drawn first
+          xim.at(s) = fq_random(rng.at(s));
+          const uint32_t gw = rng.at(s).next_u32();
+          greatest.at(s) = (kHspec & kHspecGreatestMsb) ? (gw >> 31) != 0 : (gw & 1u) != 0;
+          consumed.at(s) += 1;
+        }
+      });
+      Fq2 xa, xb;
+      duo_to_fq2(xre, xim, xa, xb);
+      const Fq2 rhs_a = xa.sqr() * xa + g2_b(), rhs_b = xb.sqr() * xb + g2_b();
+      const Duo<Fq> nm = duo_from(rhs_a.norm_fq(), rhs_b.norm_fq());
+      const Duo<bool> in_fq = duo_from(rhs_a.im().is_zero(), rhs_b.im().is_zero());
+      duo_each([&](int s) {
+        if (!have.at(s)) have.at(s) = in_fq.at(s) || fq_legendre(nm.at(s)) >= 0;
+      });
+      bool ha, hb;
+      duo_to(have, ha, hb);
+      pending = !(ha && hb);
+    }
+    Fq2 xa, xb, ya, yb;
+    duo_to_fq2(xre, xim, xa, xb);
+    bool oka, okb, ga, gb, da, db;
+    fq2_sqrt_x2(xa.sqr() * xa + g2_b(), xb.sqr() * xb + g2_b(), ya, yb, oka, okb);
+    duo_to(greatest, ga, gb);
+    duo_to(done, da, db);
+    const G2Jac res_a = g2_random_finish(xa, ya, ga, fix), res_b = g2_random_finish(xb, yb, gb, fix);
+    if (!da) ra = res_a;
+    if (!db) rb = res_b;
+    da = da || !ra.is_inf();
+    db = db || !rb.is_inf();
+#if defined(TC_TEST_HOOKS)
+    if (forced > 0) {
+      forced--;
+      da = db = false;
+    }
+#endif
+    done = duo_from(da, db);
+    all_done = da && db;
+  }
+}
+
 }  // namespace tc

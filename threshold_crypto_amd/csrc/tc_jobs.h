@@ -490,8 +490,8 @@ TC_HD void job_hash_g2(const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix
   g2_encode_uncompressed(jac_to_affine(hash_g2_point(msg, len, fix)), out_g2);
 }
 
-// hash_g1_g2(g1, msg)   (src/lib.rs:697-707)
-TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, bool fix = true) {
+// hash_g1_g2(g1, msg)   (src/lib.rs:697-707): the ChaCha20 seed -- sha3_256 of (msg, or its digest beyond 64 bytes) || compress(g1)
+TC_HD void hash_g1_g2_seed(const G1Affine& p, const uint8_t* msg, size_t len, uint32_t* seed) {
   uint8_t buf[64 + 48];
   size_t n;
   if (len > 64) {
@@ -510,7 +510,12 @@ TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, 
     n = len;
   }
   g1_encode_compressed(p, buf + n);
-  return hash_g2_point_of_buffer(buf, n + 48, fix);
+  sha3_256_words_call(buf, n + 48, seed);
+}
+TC_HD G2Jac hash_g1_g2_point(const G1Affine& p, const uint8_t* msg, size_t len, bool fix = true) {
+  uint32_t seed[8];
+  hash_g1_g2_seed(p, msg, len, seed);
+  return g2_random_from_seed(seed, fix);
 }
 TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, uint8_t* out_g2, bool fix = true) {
   G1Affine p;
@@ -523,6 +528,53 @@ TC_HD uint8_t job_hash_g1_g2(const uint8_t* g1, const uint8_t* msg, size_t len, 
   }
   g2_encode_uncompressed(jac_to_affine(hash_g1_g2_point(p, msg, len, fix)), out_g2);
   return TC_JOB_OK;
+}
+
+// ---- two messages per lane pair (tc_duo.h, tc_hash.h g2_random_from_seed_x2): batches from 65 536 messages on ----------------
+// SHA3, the streams, the sampling and the Fq exponentiations of message A on lane 0 and of message B on lane 1; out_b may be null
+// (an odd batch: the last pair's second slot repeats the first)
+TC_HD void hash_g2_x2_finish(const Duo<Seed8>& seed, bool fix, uint8_t* out_a, uint8_t* out_b) {
+  G2Jac ra, rb;
+  g2_random_from_seed_x2(seed, fix, ra, rb);
+  G2Affine pa, pb;
+  jac_to_affine_x2(ra, rb, pa, pb);
+  g2_encode_uncompressed(pa, out_a);
+  if (out_b) g2_encode_uncompressed(pb, out_b);
+}
+TC_HD void job_hash_g2_x2(const uint8_t* msg_a, size_t len_a, const uint8_t* msg_b, size_t len_b, uint8_t* out_a, uint8_t* out_b,
+                          bool fix = true) {
+  const Duo<const uint8_t*> msg = duo_pick(msg_a, msg_b);
+  const Duo<size_t> len = duo_pick(len_a, len_b);
+  Duo<Seed8> seed;
+  duo_each([&](int s) { sha3_256_words_call(msg.at(s), len.at(s), seed.at(s).w); });
+  hash_g2_x2_finish(seed, fix, out_a, out_b);
+}
+TC_HD void job_hash_g1_g2_x2(const uint8_t* g1_a, const uint8_t* msg_a, size_t len_a, const uint8_t* g1_b, const uint8_t* msg_b,
+                             size_t len_b, uint8_t* out_a, uint8_t* out_b, bool fix, uint8_t& st_a, uint8_t& st_b) {
+  const Duo<const uint8_t*> g1 = duo_pick(g1_a, g1_b), msg = duo_pick(msg_a, msg_b);
+  const Duo<size_t> len = duo_pick(len_a, len_b);
+  Duo<Seed8> seed;
+  Duo<bool> decoded;
+  duo_each([&](int s) {
+    G1Affine p;
+    decoded.at(s) = g1_decode_uncompressed(g1.at(s), p);
+    if (!decoded.at(s)) p = G1Affine::infinity();  // stand-in: the slot's result is replaced below
+    hash_g1_g2_seed(p, msg.at(s), len.at(s), seed.at(s).w);
+  });
+  hash_g2_x2_finish(seed, fix, out_a, out_b);
+  bool oka, okb;
+  duo_to(decoded, oka, okb);
+  // an undecodable G1 operand: as job_hash_g1_g2 -- infinity + status (public form) / an encoding that does not decode (internal form)
+  if (!oka) {
+    if (fix) g2_encode_uncompressed(G2Affine::infinity(), out_a);
+    else for (int i = 0; i < 192; i++) out_a[i] = 0xff;
+  }
+  if (!okb && out_b) {
+    if (fix) g2_encode_uncompressed(G2Affine::infinity(), out_b);
+    else for (int i = 0; i < 192; i++) out_b[i] = 0xff;
+  }
+  st_a = oka ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+  st_b = okb ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
 }
 
 // out[i] = data[i] ^ (u8) ChaCha20(sha3_256(compress(g1))).next_u32()   (src/lib.rs:710-715)
@@ -650,6 +702,18 @@ TC_HD uint8_t job_decompress<Fq2>(const uint8_t* in, uint8_t* out) {
   if (!ok) p = G2Affine::infinity();
   g2_encode_uncompressed(p, out);
   return ok ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+}
+
+// the same for TWO compressed G2 points on one lane pair (tc_duo.h: the Fq exponentiations of the two square roots run on one
+// lane each); out_b may be null (an odd point count: the pair's second slot repeats the first)
+TC_HD void job_decompress_g2_x2(const uint8_t* in_a, const uint8_t* in_b, uint8_t* out_a, uint8_t* out_b, uint8_t& st_a, uint8_t& st_b) {
+  G2Affine pa, pb;
+  bool oka, okb;
+  g2_decode_compressed_x2(in_a, in_b, pa, pb, oka, okb);
+  g2_encode_uncompressed(pa, out_a);
+  if (out_b) g2_encode_uncompressed(pb, out_b);
+  st_a = oka ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
+  st_b = okb ? TC_JOB_OK : TC_JOB_INVALID_ENCODING;
 }
 
 }  // namespace tc

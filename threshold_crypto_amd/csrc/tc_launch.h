@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "tc_arena.h"
 
 namespace tc {
@@ -26,6 +27,22 @@ namespace tc {
 constexpr int kBlock = 64;  // one wavefront per workgroup: the jobs are register/scratch heavy
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// Two jobs per lane pair (tc_duo.h: checked G2 decodes, hash_g2, hash_g1_g2) halves the lanes of a launch and lengthens each: it
+// pays once the launch is large enough that the halved form still fills the SIMDs.  Measured (profiles/r05_duo_sweep.txt, one
+// MI355X, ms one job per pair / two):
+//   decode   32 768: 2.03 / 2.47    65 536: 3.29 / 2.68   131 072: 6.72 / 4.57   262 144: 12.90 / 9.43
+//   hash_g2  32 768: 5.13 / 8.58    65 536: 8.27 / 9.02   131 072: 15.56 / 14.42 262 144: 30.43 / 27.47
+// A third of a decode is Fq-only work (two exponentiations), so it wins as soon as the one-job form needs a second wave on any
+// SIMD (more than 32 768 points); a hash has 24 % of it and a search loop that runs until the slowest of 64 instead of 32
+// messages has its candidate, so it only wins with two waves per SIMD in the halved form (131 072 messages).
+// TC_DUO_MIN=<jobs> overrides both (tests, experiments); read at every launch.
+constexpr size_t kDuoMinDecode = 32768 + 1;
+constexpr size_t kDuoMinHash = 131072;
+inline bool duo_form(size_t jobs, size_t min_jobs) {
+  const char* e = getenv("TC_DUO_MIN");
+  return jobs >= (e ? (size_t)strtoull(e, nullptr, 10) : min_jobs);
+}
 
 // The G1 ladder kernels keep their per-lane table in the HBM arena and fit 256 registers (two waves per SIMD) at
 // EVERY batch size since the end of r04: the register-table builds they replaced (377 registers + 121 AGPRs, 7 KB of scratch per

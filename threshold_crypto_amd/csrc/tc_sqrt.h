@@ -10,6 +10,7 @@
 #pragma once
 #include "tc_codec.h"
 #include "tc_gls.h"
+#include "tc_duo.h"
 
 namespace tc {
 
@@ -200,6 +201,104 @@ TC_HD bool g2_decode_compressed(const uint8_t* b, G2Affine& p) {
   if (fq2_lex_largest(y) != greatest) y = -y;
   p = G2Affine{x, y, false};
   return g2_in_subgroup(p);
+}
+
+// ---- two jobs per lane pair (tc_duo.h) ----------------------------------------------------------
+// Square roots of TWO Fq2 values through their norms: per value two Fq exponentiations, each executed by ONE lane (lane 0
+// for a, lane 1 for b) instead of by both.
+//   n = sqrt(a0^2 + a1^2);  d = (a0 + n) / 2  (d = a0 when a1 = 0);  w = d^((q-3)/4), s = w d:
+//     d a square (s^2 = d, w = 1/s):       root = (s, a1 w / 2)
+//     d a non-square (s^2 = -d, w = -1/s): (a0 - n) / 2 = -a1^2 / (4 d) = (a1 / (2 s))^2, so  root = (-a1 w / 2, s)
+// -- both candidates of the one-job form (fq2_sqrt_of_square) out of ONE exponentiation.  ok = the result squares to the
+// input (a non-square norm leaves garbage in n and the comparison fails).  Which root comes out is not observable: every
+// caller re-selects by lexicographic order.
+TC_HD void fq2_sqrt_x2(const Fq2& a, const Fq2& b, Fq2& ya, Fq2& yb, bool& oka, bool& okb) {
+  Fq na, nb;
+  {
+    const Duo<Fq> nm = duo_from(a.norm_fq(), b.norm_fq());
+    Duo<Fq> n;
+    duo_each([&](int s) { n.at(s) = fq_pow_qm3d4(nm.at(s)) * nm.at(s); });
+    duo_to(n, na, nb);
+  }
+  const Fq are = a.re(), aim = a.im(), bre = b.re(), bim = b.im();
+  const Fq da = Fq::select(aim.is_zero(), are, fq_half(are + na));
+  const Fq db = Fq::select(bim.is_zero(), bre, fq_half(bre + nb));
+  const Duo<Fq> d = duo_from(da, db);
+  Duo<Fq> w, s;
+  Duo<bool> sq;
+  duo_each([&](int k) {
+    w.at(k) = fq_pow_qm3d4(d.at(k));
+    s.at(k) = w.at(k) * d.at(k);
+    sq.at(k) = s.at(k).sqr() == d.at(k);
+  });
+  Fq wa, wb, sa, sb;
+  bool sqa, sqb;
+  duo_to(w, wa, wb);
+  duo_to(s, sa, sb);
+  duo_to(sq, sqa, sqb);
+  const Fq ha = fq_half(aim * wa), hb = fq_half(bim * wb);
+  ya = Fq2::make(Fq::select(sqa, sa, -ha), Fq::select(sqa, ha, sa));
+  yb = Fq2::make(Fq::select(sqb, sb, -hb), Fq::select(sqb, hb, sb));
+  oka = ya.sqr() == a;
+  okb = yb.sqr() == b;
+}
+
+// 1 / a and 1 / b: the Fq inversions of the two norms on one lane each (0 -> 0)
+TC_HD void fq2_inv_x2(const Fq2& a, const Fq2& b, Fq2& ia, Fq2& ib) {
+  const Duo<Fq> nm = duo_from(a.norm_fq(), b.norm_fq());
+  Duo<Fq> t;
+  duo_each([&](int s) { t.at(s) = nm.at(s).inv(); });
+  Fq ta, tb;
+  duo_to(t, ta, tb);
+  ia = a.scale(ta).conj();
+  ib = b.scale(tb).conj();
+}
+// two Jacobian G2 points to affine, the inversions shared out as above
+TC_HD void jac_to_affine_x2(const G2Jac& p, const G2Jac& q, G2Affine& pa, G2Affine& qa) {
+  const bool pinf = p.is_inf(), qinf = q.is_inf();
+  Fq2 zp, zq;
+  fq2_inv_x2(p.z, q.z, zp, zq);
+  const Fq2 zp2 = zp.sqr(), zq2 = zq.sqr();
+  pa = G2Affine{p.x * zp2, p.y * zp2 * zp, false};
+  qa = G2Affine{q.x * zq2, q.y * zq2 * zq, false};
+  if (pinf) pa = G2Affine::infinity();
+  if (qinf) qa = G2Affine::infinity();
+}
+
+// The checked decode of TWO compressed G2 points (EncodedPoint::into_affine of pairing 0.16 behind from_bytes,
+// /root/reference/src/lib.rs:246-252): same verdicts and points as g2_decode_compressed on each, one control flow for the
+// pair -- a point that fails early keeps a stand-in through the arithmetic and is replaced at the end.
+//   kind: 0 = malformed, 1 = the identity, 2 = a finite point (x parsed, in range)
+TC_HD int g2_parse_compressed(const uint8_t* b, Fq2& x, bool& greatest) {
+  const uint8_t f = b[0];
+  greatest = (f & 0x20) != 0;
+  uint32_t o = f & 0x3f;
+  for (int i = 1; i < 96; i++) o |= b[i];
+  const bool in_range = fq2_from_be96(b, true, x);
+  if (!(f & 0x80)) return 0;
+  if (f & 0x40) return o == 0 ? 1 : 0;
+  return in_range ? 2 : 0;
+}
+TC_HD void g2_decode_compressed_x2(const uint8_t* ba, const uint8_t* bb, G2Affine& pa, G2Affine& pb, bool& oka, bool& okb) {
+  Fq2 xa, xb;
+  bool ga, gb;
+  const int ka = g2_parse_compressed(ba, xa, ga), kb = g2_parse_compressed(bb, xb, gb);
+  // (a malformed or identity encoding walks on with x = 0: y^2 = b has whatever fate it has, the result is discarded)
+  if (ka != 2) xa = Fq2::zero();
+  if (kb != 2) xb = Fq2::zero();
+  Fq2 ya, yb;
+  bool sqa, sqb;
+  fq2_sqrt_x2(xa.sqr() * xa + g2_b(), xb.sqr() * xb + g2_b(), ya, yb, sqa, sqb);
+  if (fq2_lex_largest(ya) != ga) ya = -ya;
+  if (fq2_lex_largest(yb) != gb) yb = -yb;
+  pa = G2Affine{xa, ya, false};
+  pb = G2Affine{xb, yb, false};
+  const bool ina = g2_in_subgroup(pa);
+  const bool inb = g2_in_subgroup(pb);
+  oka = ka == 2 ? (sqa && ina) : ka == 1;
+  okb = kb == 2 ? (sqb && inb) : kb == 1;
+  if (ka != 2 || !oka) pa = G2Affine::infinity();
+  if (kb != 2 || !okb) pb = G2Affine::infinity();
 }
 
 }  // namespace tc
