@@ -62,6 +62,7 @@ MAC_PER_FQMUL = 300
 # Montgomery reduction = 196): counted by running the same per-lane job bodies in the host build
 # (tests/count_ops.py).  Two lanes work on a G2 job; work inside Fq2 operations is split between them, Fq
 # work outside (inversions, root exponentiations) is done by both and counted twice.
+CPU_LEG_JOBS = 8192   # sample of the timed batch the secondary CPU legs (config 3, config 4, wire) run: 2-6 s each on 16 threads
 EXECUTED_MACS = json.load(open(os.path.join(ROOT, "profiles", "executed_macs.json")))
 # the same with the work both lanes of a pair repeat identically counted ONCE (tests/count_ops.py --json-useful): `frac_useful`
 USEFUL_MACS = json.load(open(os.path.join(ROOT, "profiles", "useful_macs.json")))
@@ -195,6 +196,10 @@ def roofline(kernel, unit_key, ref_key, alg_key, t, units, kernel_ms, peak, traf
          "hbm_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, 6),
          "traffic": prof.get("traffic_bytes") if units == prof.get("units") else None,
          "traffic_is": ("L2<->fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), %s" % prof.get("source")) if prof else None}
+    if r["traffic"]:
+        r["traffic_over_algorithmic_bytes"] = round(r["traffic"] / alg_bytes, 1)
+        r["traffic_GBps"] = round(r["traffic"] / sec / 1e9, 1)
+        r["profile_kernel_ms"] = prof.get("profile_kernel_ms")   # the same launches under rocprofv3 --kernel-trace --stats
     if ref:
         r["reference_work_TMACs"] = round(ref / sec / 1e12, 3)
         r["algorithmic_speedup"] = round(ref / executed_total, 3)
@@ -546,6 +551,10 @@ def run_config2(args, eng, dev, rank, world, peak):
 
     extras, legs = {}, {}
     general = config4 = None
+    # the CPU legs run on rank 0 of a one-GPU run only (N ranks would time N oracles against each other on one host)
+    with_cpu = not (args.no_cpu_baseline or world > 1 or harness)
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
     if not args.no_extras and not harness:
         # ---- the same batch through the GENERAL path: share indices the small-index fast path does not take ---------
         # (signers OFFSET + i: abscissae above 65 535; Lagrange coefficients from k_lagrange, two-stage combination)
@@ -566,7 +575,7 @@ def run_config2(args, eng, dev, rank, world, peak):
                    "is": "the same messages and key set with signer indices %d + i (outside the small-index fast path): "
                          "k_lagrange + k_msm_tables + k_msm_ladder; result compared with the fast path's" % OFFSET,
                    "roofline": roofline("k_lagrange + k_msm_tables + k_msm_ladder", "combine_g2_t3_general", "combine_g2_t3", "combine_g2", t, B,
-                                        general_kernel_ms, peak) if t == 3 else None}
+                                        general_kernel_ms, peak, traffic_key="general_path") if t == 3 else None}
         del wg, g_idx, g_shares, gsig
     if not args.no_extras and not harness:
         # ---- verify incl. hashing on the device, hash_g2 alone --------------------------------------------
@@ -586,7 +595,7 @@ def run_config2(args, eng, dev, rank, world, peak):
         extras["hash_g2_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
         assert bool((hh == d_hashes).all().item())
         legs["hash_g2"] = roofline("k_hash_g2_x2" if B >= 131072 else "k_hash_g2", "hash_g2_x2" if B >= 131072 else "hash_g2", "hash_g2", "hash_g2", t, B,
-                                   hash_kernel_ms, peak)
+                                   hash_kernel_ms, peak, traffic_key="hash_g2")
         # ---- config 4: threshold decryption = Ciphertext::verify + G1 combine + keystream -------------------
         we = ThresholdEncWorkload(eng, t, N, B, start=start)
         du, dv, dw = torch.from_numpy(we.u).to(dev), torch.from_numpy(we.v).to(dev), torch.from_numpy(we.w).to(dev)
@@ -611,13 +620,13 @@ def run_config2(args, eng, dev, rank, world, peak):
         assert int(okc.to(torch.int32).sum().item()) == B and int(dst.to(torch.int32).sum().item()) == 0
         assert bool((out.cpu() == torch.from_numpy(we.plain_flat)[: out.numel()]).all().item()), "threshold decryption returned wrong plaintext"
         legs["threshold_decrypt"] = roofline("k_combine_fast_g1_arena + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
-                                             "combine_g1", t, B, dec_kernel_ms, peak)
+                                             "combine_g1", t, B, dec_kernel_ms, peak, traffic_key="threshold_decrypt")
         # (the hashes take two messages per lane pair from 131 072 messages on: csrc/tc_launch.h kDuoMinHash)
         hkey = "hash_g1_g2_x2" if B >= 131072 else "hash_g1_g2"
         cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS[hkey]
         cv_useful = USEFUL_MACS["verify_g2"] + USEFUL_MACS[hkey]
         legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
-                                             cv_kernel_ms, peak, executed=cv_macs, useful=cv_useful)
+                                             cv_kernel_ms, peak, traffic_key="ciphertext_verify", executed=cv_macs, useful=cv_useful)
         config4 = {"value": round(B * world / (e2 - e0), 1), "unit": "threshold_decryptions/s", "ms_per_step": round((e2 - e0) * 1e3, 3),
                    "is": "BASELINE config 4: Ciphertext::verify (hash_g1_g2 + pairing check) then PublicKeySet::decrypt (G1 combine + "
                          "keystream) over the batch; every plaintext compared with the workload's",
@@ -625,6 +634,23 @@ def run_config2(args, eng, dev, rank, world, peak):
                    "roofline": roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast_g1_arena + k_xor_with_hash", None, None,
                                         "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
                                         executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"], useful=cv_useful + USEFUL_MACS["combine_g1_t3_fast"])}
+        _cv, _td = legs["ciphertext_verify"], legs["threshold_decrypt"]
+        if config4["roofline"] and _cv.get("traffic") and _td.get("traffic"):   # the step is the two legs one after the other
+            config4["roofline"]["traffic"] = _cv["traffic"] + _td["traffic"]
+            config4["roofline"]["traffic_is"] = "ciphertext_verify.traffic + threshold_decrypt.traffic (secondary_rooflines)"
+            config4["roofline"]["traffic_over_algorithmic_bytes"] = round(config4["roofline"]["traffic"] / config4["roofline"]["algorithmic_bytes_per_launch"], 1)
+        if with_cpu:
+            import c_oracle as _co
+            plain_gpu = out.cpu().numpy()
+
+            def _c4(k, T):
+                okv = _co.ciphertext_verify_batch(we.u[:k], we.v[:32 * k], 32, we.w[:k], T)
+                pt, rc = _co.threshold_decrypt_batch(t, we.idx[:k], we.shares[:k], we.v[:32 * k], 32, T)
+                return okv, pt, rc
+            config4["cpu_baseline"] = cpu_leg(
+                "threshold_decryptions/s", "config 4", "/root/reference/src/lib.rs:508-512 (Ciphertext::verify), :618-626 (PublicKeySet::decrypt)",
+                min(B, CPU_LEG_JOBS), lambda k: _c4(k, 1), _c4,
+                lambda g, k: int((g[0] != 1).sum()) + int(g[2].any()) + int((g[1].reshape(k, 32) != plain_gpu[:32 * k].reshape(k, 32)).any(axis=1).sum()))
     if not args.no_extras and not harness and not args.profile_run:
         # ---- the headline step with the context's default membership tests on every share -------------------------
         eng.set_input_checks(True)
@@ -665,9 +691,19 @@ def run_config2(args, eng, dev, rank, world, peak):
                       "(square root + membership test each), combined, returned as Signature::to_bytes; result compared with "
                       "compress(combine) of the timed batch" % (t + 1),
                 "algorithmic_bytes_per_job": (t + 1) * (96 + 8) + 96,
-                "roofline": roofline("k_decompress_take_g2_x2 + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak,
+                "roofline": roofline("k_decompress_take_g2_x2 + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak, traffic_key="wire",
                                      executed=wire_macs, useful=wire_useful) if t == 3 else None}
         extras["wire_combine_per_s"] = wire["value"]
+        if with_cpu:
+            import c_oracle as _co
+            wire_np, wsig_np = d_wire.cpu().numpy(), wsig.cpu().numpy()
+
+            def _wire(k, T):
+                return _co.combine_signatures_wire_batch(t, wl.idx[:k], wire_np[:k], T)
+            wire["cpu_baseline"] = cpu_leg(
+                "combine_signatures/s", "wire-level combine", "/root/reference/src/lib.rs:246-252 (from_bytes), :608-615 (combine_signatures), :255-259 (to_bytes)",
+                min(B, CPU_LEG_JOBS), lambda k: _wire(k, 1), _wire,
+                lambda g, k: int(g[1].any()) + int((g[0] != wsig_np[:k]).any(axis=1).sum()))
     if not args.no_extras and not harness and not args.profile_run:
         # ---- the same combine with HOST buffers at the C ABI (pageable numpy memory): PCIe-inclusive ---------
         eng.combine_g2(t, wl.idx, wl.shares)
@@ -701,7 +737,7 @@ def run_config2(args, eng, dev, rank, world, peak):
     if not harness:
         legs["pairing_check"] = roofline("k_miller_lines + k_miller_accumulate + k_final_exp (above 16 384 checks; k_pairing_quad below)", "verify_g2_prepared", "verify_g2", "verify_g2", t, B, verify_kernel_ms, peak,
                                          traffic_key="pairing_check")
-        legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak)
+        legs["g2_sign"] = roofline("k_g2_mul_shared", "g2_mul_4_scalars_per_point", "g2_mul", "g2_mul", t, (t + 1) * B, sign_kernel_ms, peak, traffic_key="g2_sign")
     # the CPU leg runs on rank 0 of a one-GPU run only (N ranks would time N oracles against each other on one host)
     cpu = None if (args.no_cpu_baseline or world > 1 or harness) else cpu_baseline(wl, sig.cpu().numpy(), t, args.cpu_seconds)
     config3 = {"value": round(B * world / verify_dt, 1), "unit": "pairing_verifies/s", "ms_per_step": round(verify_dt * 1e3, 3),
@@ -711,6 +747,13 @@ def run_config2(args, eng, dev, rank, world, peak):
                              if verify_if_dt else None),
                "sustained": verify_sustained,
                "roofline": legs.get("pairing_check")}
+    if with_cpu:
+        import c_oracle as _co
+        bad_np, hashes_np, ok_np, pk_np = bad.cpu().numpy(), d_hashes.cpu().numpy(), ok.cpu().numpy(), bytes(master_pk.cpu().numpy())
+        config3["cpu_baseline"] = cpu_leg(
+            "pairing_verifies/s", "config 3", "/root/reference/src/lib.rs:108-117 (PublicKey::verify_g2: two pairings)", min(B, CPU_LEG_JOBS),
+            lambda k: _co.verify_g2_batch(pk_np, bad_np[:k], hashes_np[:k], 1), lambda k, T: _co.verify_g2_batch(pk_np, bad_np[:k], hashes_np[:k], T),
+            lambda g, k: int((g.astype(np.uint8) != ok_np[:k]).sum()))
     # what is left of each leg's frac once the clock it ran at is taken out (the denominator's loop runs ~5-10 % faster)
     for leg, clock in ((head, sustained and sustained.get("clock")), (config3["roofline"], verify_sustained and verify_sustained.get("clock"))):
         if leg and clock and clock.get("sclk_GHz") and leg.get("peak_clock_GHz"):
@@ -853,6 +896,31 @@ def cpu_baseline(wl, gpu_sigs, t, seconds):
             "sample": "first %d jobs of the timed batch on %d pthreads (oracle/c/tc_oracle.c, gcc -O3 x86-64-v3); "
                       "every sampled job compared bit-exact with the GPU output" % (n, threads),
             "single_thread_per_s": round(1.0 / per, 2)}
+
+
+def cpu_leg(unit, what, ref, n, single, threaded, check):
+    """Oracle B beside a secondary leg of the bench line (BASELINE's metric names the pairing rate too, and
+    north_star asks for the CPU path timed beside each): `single(k)` runs the first k jobs on one thread, `threaded(k, T)` on T
+    pthreads and returns what `check` compares with the GPU's output of the timed batch.  `ref` = the reference lines the leg
+    restates.  kind = port (the reference is Rust with un-vendored crates: no oracle/_ref in this image)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    c_oracle.load()
+    threads = c_oracle.host_threads()
+    n1 = 4
+    t0 = time.perf_counter()
+    single(n1)
+    per = max((time.perf_counter() - t0) / n1, 1e-5)
+    t0 = time.perf_counter()
+    got = threaded(n, threads)
+    dt = time.perf_counter() - t0
+    bad = check(got, n)
+    if bad:
+        raise AssertionError("%s: GPU output differs from the CPU oracle on %d of %d sampled jobs" % (what, bad, n))
+    return {"value": round(n / dt, 2), "unit": unit, "cores": threads, "kind": "port", "reference": ref,
+            "single_thread_per_s": round(1.0 / per, 2), "thread_scaling": round((n / dt) * per, 2),
+            "sample": "first %d jobs of the timed batch on %d pthreads (oracle/c/tc_oracle.c); every sampled job compared with the GPU output"
+                      % (n, threads)}
 
 
 def cpu_baseline_config5(res, t):

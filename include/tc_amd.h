@@ -227,7 +227,10 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u_g1, const uint8_t* 
 /* SecretKeyShare::decrypt_share src/lib.rs:452-457 for ONE key share and B ciphertexts: Ciphertext::verify, then [sk] u.
  * ok[j] = 1 and out_g1[j] = the DecryptionShare when ciphertext j is valid; ok[j] = 0 and the identity's encoding when it is
  * not (the reference returns None: an invalid ciphertext never yields a share).  sk_fr: 32 B LE, wiped from the staging
- * buffers after the call.  One call = hash_g1_g2 + pairing check + G1 multiplication, nothing crosses PCIe in between. */
+ * buffers after the call.  One call = hash_g1_g2 + pairing check + G1 multiplication, nothing crosses PCIe in between.
+ * u and w are tested for membership in G1 / G2 ALWAYS, whatever tc_ctx_set_input_checks says: the pairing check cannot see a
+ * small-order component of u, and the secret key must never multiply a point outside the order-r subgroup (the reference's
+ * Ciphertext only exists after the checked decode, src/lib.rs:140-146).  A non-canonical sk_fr (>= r) gives ok[j] = 0. */
 int tc_decrypt_share_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u_g1, const uint8_t* v, const uint64_t* off,
                            const uint8_t* w_g2, size_t B, uint8_t* out_g1, uint8_t* ok);
 /* SecretKey::decrypt src/lib.rs:384-391: Ciphertext::verify, g = [sk] u, xor_with_hash(g, v).  out bytes[off[j]..off[j+1]] =

@@ -37,6 +37,10 @@ using FrBytes = std::array<std::uint8_t, 32>;
 // An index type beyond u64 -- `T: IntoFr` of combine_signatures / decrypt (src/lib.rs:608-622) for T = Fr, i32, i64
 // (src/into_fr.rs:10-14, 28-56): the field element as 32 little-endian bytes, ordered by its canonical value like the derived
 // Ord of pairing's Fr, so a std::map keyed by it iterates as the reference's BTreeMap<Fr, _> does.
+// CAVEAT: that is the order of BTreeMap<Fr, _> ONLY.  A caller whose reference code keys the map by i32 / i64
+// iterates NEGATIVE keys first (BTreeMap<i64, _> orders by the signed value), while their field images r - |x| sort after every
+// positive key here; with more than t + 1 shares `take(t + 1)` (src/lib.rs:727-730) would then pick a different subset.  For
+// signed keys use the std::map<std::int64_t, _> overloads below: they iterate by the signed value and convert afterwards.
 struct FrIndex {
   FrBytes le{};
   static FrIndex from_u64(std::uint64_t x) {
@@ -439,6 +443,23 @@ class PublicKeySet {
     std::size_t k = 0;
     for (const auto& kv : shares) {
       std::memcpy(&idx[k * 32], kv.first.le.data(), 32);
+      std::memcpy(&sh[k * 192], kv.second.sig.g2.data(), 192);
+      k++;
+    }
+    Signature out;
+    std::uint8_t st = 0;
+    e.check(tc_combine_g2_fr_batch(e.ctx(), threshold(), n, idx.data(), sh.data(), 1, out.g2.data(), &st));
+    raise_status(st);
+    return out;
+  }
+  // `T = i64` (and i32): a BTreeMap<i64, _> iterates by the SIGNED value -- negative keys first -- and interpolate() takes the
+  // first t + 1 samples in THAT order (src/lib.rs:727-730, src/into_fr.rs:42-56); the keys become field elements afterwards
+  Signature combine_signatures(const std::map<std::int64_t, SignatureShare>& shares, Engine& e = Engine::instance()) const {
+    const std::size_t n = shares.size();
+    std::vector<std::uint8_t> idx(n * 32 + 1), sh(n * 192 + 1);
+    std::size_t k = 0;
+    for (const auto& kv : shares) {
+      std::memcpy(&idx[k * 32], FrIndex::from_i64(kv.first).le.data(), 32);
       std::memcpy(&sh[k * 192], kv.second.sig.g2.data(), 192);
       k++;
     }

@@ -19,9 +19,10 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("TC_ORACLE_LIB") or LIB_PATH   # tests: a sanitizer build of the same source (tests/test_hostsim.py)
+        if path == LIB_PATH and not os.path.exists(LIB_PATH):
             build()
-        _lib = ctypes.CDLL(LIB_PATH)
+        _lib = ctypes.CDLL(path)
         _lib.or_fq_mul_count.restype = ctypes.c_uint64
         for name in ("or_hash_g2", "or_sha3_256", "or_fq_mul_count_reset"):
             getattr(_lib, name).restype = None

@@ -127,18 +127,13 @@ fn pack_messages<M: AsRef<[u8]>>(msgs: &[M]) -> (Vec<u8>, Vec<u64>) {
     }
     (flat, off)
 }
-/// Per-job status -> the reference's error type.  The typed entry points below only hand over values that already passed
-/// `from_bytes` / were produced by the crate, so TC_JOB_INVALID_ENCODING (an undecodable or non-member point operand) cannot
-/// come back from them: it is a bug, not an `Error` -- and it must not be reported as `DuplicateEntry`.  The wire-level
-/// functions, whose inputs are raw bytes, map it to `FromBytesError::Invalid` (`WireError::Invalid`).
-fn status_to_result<T>(st: u8, v: T) -> Result<T> {
-    match st {
-        TC_JOB_OK => Ok(v),
-        TC_JOB_NOT_ENOUGH_SHARES => Err(Error::NotEnoughShares),
-        TC_JOB_DUPLICATE_ENTRY => Err(Error::DuplicateEntry),
-        TC_JOB_INVALID_ENCODING => panic!("libtc_amd: TC_JOB_INVALID_ENCODING for an operand that was a valid group element"),
-        other => panic!("libtc_amd: unknown job status {}", other),
-    }
+/// Per-job status -> the per-job result of every batch method.  The reference's hot path has no panic (only the unreachable
+/// `IntoFr` expect, src/into_fr.rs:18), so none here either: TC_JOB_INVALID_ENCODING -- an operand the library could not decode or
+/// that is no group member; typed values of this crate cannot cause it, a context with its membership tests on reports foreign
+/// operands this way -- comes back as `JobError::Invalid(FromBytesError::Invalid)`, never as `DuplicateEntry` and never as an abort.
+/// An unknown status byte is reported the same way.
+fn status_to_result<T>(st: u8, v: T) -> JobResult<T> {
+    wire_status_to_result(st, v)
 }
 /// Errors of the wire-level entry points: the reference's `Error` for the threshold logic, `FromBytesError::Invalid` for a
 /// share that does not decode or is no group member (src/error.rs:37-41).
@@ -147,14 +142,28 @@ pub enum WireError {
     Threshold(Error),
     Invalid(FromBytesError),
 }
+/// The per-job error of the batch methods (the typed ones too: r05).
+pub type JobError = WireError;
+pub type JobResult<T> = std::result::Result<T, JobError>;
 fn wire_status_to_result<T>(st: u8, v: T) -> std::result::Result<T, WireError> {
     match st {
         TC_JOB_OK => Ok(v),
         TC_JOB_NOT_ENOUGH_SHARES => Err(WireError::Threshold(Error::NotEnoughShares)),
         TC_JOB_DUPLICATE_ENTRY => Err(WireError::Threshold(Error::DuplicateEntry)),
-        TC_JOB_INVALID_ENCODING => Err(WireError::Invalid(FromBytesError::Invalid)),
-        other => panic!("libtc_amd: unknown job status {}", other),
+        // (an unknown status byte is an undecodable answer: reported, not a panic)
+        _ => Err(WireError::Invalid(FromBytesError::Invalid)),
     }
+}
+/// `T: IntoFr` abscissae that all fit 64 bits travel as u64 (tc_combine_g2_batch / tc_decrypt_batch: no narrowing kernel, no
+/// scratch array, no host wait inside the library -- ADVICE r04); `None` when one of them does not.
+fn abscissae_as_u64(frs: &[Fr]) -> Option<Vec<u64>> {
+    frs.iter()
+        .map(|f| {
+            let r = f.into_repr();
+            let l = r.as_ref();
+            if l[1..].iter().all(|&w| w == 0) { Some(l[0]) } else { None }
+        })
+        .collect()
 }
 
 // ---- A2: hash_g2 (src/lib.rs:691-694) ---------------------------------------------------------------------------------
@@ -291,27 +300,32 @@ impl PublicKeySet {
     /// u64 / usize, Fr, negative i32 / i64 -- src/into_fr.rs).  `jobs[j]` iterates `(index, share)` in the order the
     /// single-item method would see it (BTreeMap order); every job holds the same number of shares.  The abscissae travel as
     /// Fr values (tc_combine_g2_fr_batch); a batch whose indices all fit 64 bits runs the u64 kernels inside the library.
-    pub fn combine_signatures_batch<'a, T, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<Result<Signature>>
+    pub fn combine_signatures_batch<'a, T, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<JobResult<Signature>>
     where
         T: IntoFr,
         I: Clone + IntoIterator<Item = (T, &'a SignatureShare)>,
     {
         let t = self.threshold();
         let n = jobs.first().map(|j| j.clone().into_iter().count()).unwrap_or(0);
-        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n * FR_BYTES), Vec::with_capacity(jobs.len() * n * G2_BYTES));
+        let (mut frs, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * G2_BYTES));
         for job in jobs {
             for (i, s) in job.clone() {
-                idx.extend_from_slice(&fr_bytes(&i.into_fr()));
+                frs.push(i.into_fr());
                 shares.extend_from_slice(&g2_bytes(&(s.0).0));
             }
         }
-        assert_eq!(idx.len(), jobs.len() * n * FR_BYTES, "every job must hold the same number of shares");
+        assert_eq!(frs.len(), jobs.len() * n, "every job must hold the same number of shares");
         let (mut out, mut st) = (vec![0u8; jobs.len() * G2_BYTES], vec![0u8; jobs.len()]);
-        gpu.check(unsafe { tc_combine_g2_fr_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        if let Some(idx) = abscissae_as_u64(&frs) {
+            gpu.check(unsafe { tc_combine_g2_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        } else {
+            let idx: Vec<u8> = frs.iter().flat_map(|f| fr_bytes(f).to_vec()).collect();
+            gpu.check(unsafe { tc_combine_g2_fr_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr()) });
+        }
         st.iter().enumerate().map(|(j, &s)| status_to_result(s, Signature(g2_from(&out[j * G2_BYTES..(j + 1) * G2_BYTES])))).collect()
     }
     /// The same for plain u64 indices without the detour through Fr (tc_combine_g2_batch).
-    pub fn combine_signatures_batch_u64<'a, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<Result<Signature>>
+    pub fn combine_signatures_batch_u64<'a, I>(&self, gpu: &Gpu, jobs: &[I]) -> Vec<JobResult<Signature>>
     where
         I: Clone + IntoIterator<Item = (u64, &'a SignatureShare)>,
     {
@@ -355,7 +369,7 @@ impl PublicKeySet {
     }
     /// Batch form of `decrypt` (src/lib.rs:618-626), generic over `T: IntoFr`: per job the shares of one ciphertext; returns the
     /// plaintexts.
-    pub fn decrypt_batch<'a, T, I>(&self, gpu: &Gpu, jobs: &[I], cts: &[Ciphertext]) -> Vec<Result<Vec<u8>>>
+    pub fn decrypt_batch<'a, T, I>(&self, gpu: &Gpu, jobs: &[I], cts: &[Ciphertext]) -> Vec<JobResult<Vec<u8>>>
     where
         T: IntoFr,
         I: Clone + IntoIterator<Item = (T, &'a DecryptionShare)>,
@@ -363,20 +377,27 @@ impl PublicKeySet {
         assert_eq!(jobs.len(), cts.len(), "one ciphertext per share set");
         let t = self.threshold();
         let n = jobs.first().map(|j| j.clone().into_iter().count()).unwrap_or(0);
-        let (mut idx, mut shares) = (Vec::with_capacity(jobs.len() * n * FR_BYTES), Vec::with_capacity(jobs.len() * n * G1_BYTES));
+        let (mut frs, mut shares) = (Vec::with_capacity(jobs.len() * n), Vec::with_capacity(jobs.len() * n * G1_BYTES));
         for job in jobs {
             for (i, s) in job.clone() {
-                idx.extend_from_slice(&fr_bytes(&i.into_fr()));
+                frs.push(i.into_fr());
                 shares.extend_from_slice(&g1_bytes(&s.0));
             }
         }
-        assert_eq!(idx.len(), jobs.len() * n * FR_BYTES, "every job must hold the same number of shares");
+        assert_eq!(frs.len(), jobs.len() * n, "every job must hold the same number of shares");
         let vs: Vec<&[u8]> = cts.iter().map(|c| c.1.as_slice()).collect();
         let (flat, off) = pack_messages(&vs);
         let (mut out, mut st) = (vec![0u8; flat.len()], vec![0u8; jobs.len()]);
-        gpu.check(unsafe {
-            tc_decrypt_fr_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
-        });
+        if let Some(idx) = abscissae_as_u64(&frs) {
+            gpu.check(unsafe {
+                tc_decrypt_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
+            });
+        } else {
+            let idx: Vec<u8> = frs.iter().flat_map(|f| fr_bytes(f).to_vec()).collect();
+            gpu.check(unsafe {
+                tc_decrypt_fr_batch(gpu.0, t, n, idx.as_ptr(), shares.as_ptr(), flat.as_ptr(), off.as_ptr(), jobs.len(), out.as_mut_ptr(), st.as_mut_ptr())
+            });
+        }
         st.iter().enumerate().map(|(j, &s)| status_to_result(s, out[off[j] as usize..off[j + 1] as usize].to_vec())).collect()
     }
     /// Wire-level `decrypt`: the decryption shares in their 48-byte compressed form (checked decode on the device).
@@ -577,7 +598,7 @@ pub fn bivar_commitment_rows(gpu: &Gpu, c: &BivarCommitment, xs: &[u64]) -> Vec<
     out.chunks((d + 1) * G1_BYTES).map(|row| Commitment { coeff: row.chunks(G1_BYTES).map(g1_from).collect() }).collect()
 }
 /// `Poly::interpolate` for B sample sets of n points each.
-pub fn interpolate_batch(gpu: &Gpu, samples: &[Vec<(Fr, Fr)>]) -> Vec<Result<Poly>> {
+pub fn interpolate_batch(gpu: &Gpu, samples: &[Vec<(Fr, Fr)>]) -> Vec<JobResult<Poly>> {
     let n = samples.first().map(|s| s.len()).unwrap_or(0);
     let (mut xs, mut ys) = (Vec::new(), Vec::new());
     for job in samples {
@@ -624,7 +645,7 @@ impl GpuGroup {
         self.check(unsafe { tc_group_set_keyset(self.0, pks.threshold(), commit.as_ptr()) });
     }
     /// `combine_signatures` (src/lib.rs:608-615) for B jobs of n shares, sharded over the GPUs of the group.
-    pub fn combine_signatures(&self, n: usize, idx: &[u64], shares: &[u8]) -> Vec<Result<Signature>> {
+    pub fn combine_signatures(&self, n: usize, idx: &[u64], shares: &[u8]) -> Vec<JobResult<Signature>> {
         let b = idx.len() / n;
         assert!(idx.len() == b * n && shares.len() == b * n * G2_BYTES);
         let (mut out, mut st) = (vec![0u8; b * G2_BYTES], vec![0u8; b]);

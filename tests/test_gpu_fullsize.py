@@ -575,8 +575,13 @@ assert (ok == want).all(), np.flatnonzero(ok != want)[:10]
 print("FORM-OK", hashlib.sha256(ok.tobytes()).hexdigest())
 """ % root
     digests = set()
-    for form in ("quad", "lines", "pair", "fused"):
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, TC_PAIRING_FORM=form))
-        assert out.returncode == 0 and "FORM-OK" in out.stdout, (form, out.stderr[-1500:])
+    # (r05, ADVICE r04) the prepared form's line buffer is sized from the memory the call may spend: with room for 16 384
+    # checks the batch runs as two tiles, with none the one-loop form takes over -- same booleans, no failed allocation
+    for form, budget in (("quad", None), ("lines", None), ("pair", None), ("fused", None), ("lines", str(16384 * 2 * 552 * 14 * 4 + 4096)), ("lines", "1000")):
+        env = dict(os.environ, TC_PAIRING_FORM=form)
+        if budget:
+            env["TC_PAIRING_BUDGET"] = budget
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and "FORM-OK" in out.stdout, (form, budget, out.stderr[-1500:])
         digests.add(out.stdout.split("FORM-OK")[1].strip())
     assert len(digests) == 1

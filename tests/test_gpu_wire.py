@@ -196,6 +196,43 @@ def test_decrypt_share_and_secret_key_decrypt_in_one_call_vs_oracle(engine, rnd)
     assert api.SecretKey(sk).decrypt_batch(cts, engine=engine) == [msgs[0], msgs[1], None, None]
 
 
+def test_decrypt_share_never_multiplies_the_secret_by_a_point_outside_g1(engine, rnd):
+    """ADVICE r04: u' = u1 + T with T of small order in E(Fq) passes the pairing check of Ciphertext::verify (e(T, H) = 1), and
+    [sk] u' would leak sk modulo the order of T.  The reference cannot hold such a Ciphertext (checked decode,
+    src/lib.rs:140-146); tc_decrypt_share_batch / tc_secret_key_decrypt_batch therefore test u and w for membership even with the
+    context's input checks OFF.  Also: a non-canonical secret key (>= r) is an error for every job, not an identity share."""
+    sk = rnd.randrange(1, o.R)
+    r_enc = rnd.randrange(1, o.R)
+    v = bytes(rnd.randrange(256) for _ in range(24))
+    T = o.E1.mul(non_member_g1(rnd), o.R)           # the cofactor component of a random curve point: order divides h1
+    assert T is not None and o.E1.mul(T, o.R) is not None
+    u_bad = o.E1.add(o.E1.mul(o.G1_GEN, r_enc), T)
+    w_bad = o.E2.mul(o.hash_g1_g2(u_bad, v), r_enc)
+    u_good = o.E1.mul(o.G1_GEN, r_enc)
+    w_good = o.E2.mul(o.hash_g1_g2(u_good, v), r_enc)
+    u = np.stack([u8(o.g1_uncompressed(u_bad)), u8(o.g1_uncompressed(u_good))])
+    w = np.stack([u8(o.g2_uncompressed(w_bad)), u8(o.g2_uncompressed(w_good))])
+    flat, off = pack_messages([v, v])
+    fr = u8(sk.to_bytes(32, "little"))
+    identity = bytes([0x40]) + bytes(95)
+    was = engine.input_checks()
+    try:
+        engine.set_input_checks(False)
+        assert engine.ciphertext_verify(u, flat, off, w).tolist() == [1, 1]    # the pairing equation alone accepts u'
+        shares, ok = engine.decrypt_share(fr, u, flat, off, w)
+        plain, ok2 = engine.secret_key_decrypt(fr, u, flat, off, w)
+        assert ok.tolist() == [0, 1] == ok2.tolist()
+        assert bytes(shares[0]) == identity and bytes(plain[:24]) == bytes(24)
+        assert bytes(shares[1]) == o.g1_uncompressed(o.E1.mul(u_good, sk))
+        big = u8(o.R.to_bytes(32, "little"))                                     # sk = r: not a canonical Fr
+        shares, ok = engine.decrypt_share(big, u, flat, off, w)
+        assert ok.tolist() == [0, 0] and bytes(shares[1]) == identity
+        engine.set_input_checks(True)
+        assert engine.ciphertext_verify(u, flat, off, w).tolist() == [0, 1]
+    finally:
+        engine.set_input_checks(was)
+
+
 # ---- `T: IntoFr` --------------------------------------------------------------------------------------------------------
 def fr_rows(ids):
     return np.stack([np.stack([u8((i % o.R).to_bytes(32, "little")) for i in row]) for row in ids])

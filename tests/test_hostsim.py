@@ -27,6 +27,9 @@ def L():
         lib = LIB.replace(".so", "_bcall.so")
         subprocess.run(["g++", "-O1", "-std=c++17", "-DTC_TEST_HOOKS", "-DTC_BOUND_CHECK", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", lib], check=True)
         return ctypes.CDLL(lib)
+    if os.environ.get("TC_HOSTSIM_SANITIZE"):
+        # the WHOLE suite against an AddressSanitizer + UBSan build (test_whole_suite_under_the_sanitizers starts this run)
+        return ctypes.CDLL(os.environ["TC_HOSTSIM_SANITIZE"])
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(newest, os.path.getmtime(SRC)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-DTC_TEST_HOOKS", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", LIB], check=True)
     return ctypes.CDLL(LIB)
@@ -622,6 +625,36 @@ def test_whole_suite_under_the_bound_analysis():
                         "-k", "not under_the_bound_analysis and not bound_check_build"],
                        capture_output=True, text=True, timeout=1800, env=env, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_whole_suite_under_the_sanitizers():
+    """SURVEY 5 / VERDICT r04 item 5: the only memory-safety check this code can get (there is no compute-sanitizer on ROCm).  The
+    device source as the host build (tests/hostsim/hostsim.cpp) AND Oracle B (oracle/c/tc_oracle.c) compiled with
+    -fsanitize=address,undefined; every test of this file and the oracle's own differential tests run against them (libasan
+    preloaded into the interpreter, leak detection off: CPython itself leaks).  Any report fails the run: UBSan is built with
+    -fno-sanitize-recover, ASan aborts."""
+    if os.environ.get("TC_HOSTSIM_SANITIZE") or os.environ.get("TC_HOSTSIM_BOUND_CHECK"):
+        pytest.skip("already inside a sanitized / bound-checked run")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan is not installed")
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    lib = LIB.replace(".so", "_asan.so")
+    newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(newest, os.path.getmtime(SRC)):
+        subprocess.run(["g++"] + flags + ["-std=c++17", "-DTC_TEST_HOOKS", "-shared", "-fPIC", "-I" + CSRC, SRC, "-o", lib], check=True)
+    osrc = os.path.join(os.path.dirname(HERE), "oracle", "c", "tc_oracle.c")
+    olib = os.path.join(HERE, "hostsim", "libtc_oracle_asan.so")
+    if not os.path.exists(olib) or os.path.getmtime(olib) < os.path.getmtime(osrc):
+        subprocess.run(["gcc"] + flags + ["-std=gnu11", "-shared", "-fPIC", "-fvisibility=hidden", osrc, "-o", olib, "-lpthread"], check=True)
+    env = dict(os.environ, TC_HOSTSIM_SANITIZE=lib, TC_ORACLE_LIB=olib, LD_PRELOAD=" ".join(p for p in (asan, ubsan) if os.path.isabs(p)),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(HERE, "test_oracle.py"), "-x", "-q",
+                        "-s", "-p", "no:cacheprovider", "-k", "not under_the_bound_analysis and not bound_check_build and not under_the_sanitizers"],
+                       capture_output=True, text=True, timeout=3000, env=env, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and " passed" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (
+        r.stdout[-1500:], r.stderr[-3000:])
 
 
 # ---- DKG algebra (tc_dkg.h; src/poly.rs) ---------------------------------------------------------------

@@ -425,7 +425,12 @@ def _ordered(shares):
     """The reference iterates a BTreeMap / any IntoIterator of (index, share): dicts are taken in
     ascending index order (BTreeMap), sequences of pairs in the order given."""
     if isinstance(shares, dict):
-        return sorted(shares.items())
+        keys = list(shares)
+        # a BTreeMap has ONE key type: plain integers order by their signed value (BTreeMap<i64, _>: negative keys first),
+        # Fr keys by their canonical value (BTreeMap<Fr, _>).  Mixing the two has no counterpart in the reference (ADVICE r04).
+        if any(isinstance(k, Fr) for k in keys) and not all(isinstance(k, Fr) for k in keys):
+            raise TypeError("index keys of one share map must all be integers or all be Fr (a BTreeMap has one key type)")
+        return sorted(shares.items(), key=lambda kv: kv[0])
     return list(shares)
 
 

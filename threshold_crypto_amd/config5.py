@@ -225,12 +225,13 @@ def run_bench(args, eng, dev, rank, world, peak, roofline, cpu_baseline=None):
     whole_step_s = step_s * (emu_world or 1)        # emulated: the slices run one after the other on this GPU
     legs = {
         "combine": roofline("k_lagrange_all + k_msm_tables + k_msm_ladder", "combine_g2_t67_msm", "combine_g2_t67", "combine_g2", t, B,
-                            float(ms[1]), peak),
+                            float(ms[1]), peak, traffic_key="config5_combine"),
         # (csrc/tc_launch.h: the per-message comb from 24 signers and 8192 messages on)
         "share_sign": roofline("k_comb_tables + k_comb_sign" if (t + 1 >= 24 and B >= 8192) else "k_g2_mul_gather",
                                "g2_sign_comb_68_signers" if (t + 1 >= 24 and B >= 8192) else "g2_mul_gather_68_signers", "g2_mul", "g2_mul", t,
-                               (t + 1) * B, float(ms[0]), peak),
-        "pairing_check": roofline("k_miller_lines + k_miller_accumulate + k_final_exp", "verify_g2_prepared", "verify_g2", "verify_g2", t, B, float(ms[2]), peak),
+                               (t + 1) * B, float(ms[0]), peak, traffic_key="config5_sign"),
+        "pairing_check": roofline("k_miller_lines + k_miller_accumulate + k_final_exp", "verify_g2_prepared", "verify_g2", "verify_g2", t, B, float(ms[2]), peak,
+                                  traffic_key="config5_verify"),
     }
     cpu = cpu_baseline(res, t) if (cpu_baseline and not args.no_cpu_baseline and world == 1 and not harness) else None
     return {

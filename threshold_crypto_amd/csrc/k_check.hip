@@ -45,6 +45,12 @@ __global__ void k_invalidate_jobs(const uint8_t* __restrict__ valid, size_t per_
   }
 }
 
+// ok[j] = ok[j] && status[j] == OK
+__global__ void k_ok_and_status(const uint8_t* __restrict__ status, size_t B, uint8_t* __restrict__ ok) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < B && status[j] != TC_JOB_OK) ok[j] = 0;
+}
+
 // r[i] = d0 + d1 |x| + d2 |x|^2 + d3 |x|^3 with four 16-bit digits from ChaCha20(key = seed, block counter = i), d0
 // odd: 2^63 equally likely scalars, pairwise distinct mod r (base-|x| digits are unique), so a bad share survives
 // the combined check with probability <= 2^-63 -- and on G2, where psi = [x], the multiplication is a 16-column
@@ -110,6 +116,9 @@ __global__ void k_gather_rows(const uint8_t* __restrict__ src, size_t row_words,
 __global__ void k_scatter_bytes(const uint8_t* __restrict__ src, const uint32_t* __restrict__ map, size_t rows, uint8_t* __restrict__ dst) {
   const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (r < rows) dst[map[r]] = src[r];
+}
+void launch_ok_and_status(hipStream_t st, const uint8_t* status, size_t B, uint8_t* ok) {
+  if (B) hipLaunchKernelGGL(k_ok_and_status, dim3(grid_for(B)), dim3(kBlock), 0, st, status, B, ok);
 }
 void launch_rlc_scalars(hipStream_t st, const uint8_t* seed32, size_t n, uint8_t* out_fr) {
   if (n) hipLaunchKernelGGL(k_rlc_scalars, dim3(grid_for(n)), dim3(kBlock), 0, st, seed32, n, out_fr);

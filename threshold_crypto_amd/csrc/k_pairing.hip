@@ -158,17 +158,30 @@ static PairingForm pairing_form(size_t B) {
   if (form && form[0] == 'f') return kFormFused;
   return B <= kQuadMaxBatch ? kFormQuad : kFormLines;
 }
-// checks per pass of the prepared form: its line buffer (40 KB per check) is sized for one tile, larger batches run tile by tile
+// checks per pass of the prepared form: its line buffer (kLineWords = 552 x 14 words per lane: 61.8 KB per check, 4.05 GB for
+// 65 536 checks) is sized for one tile, larger batches run tile by tile.  The tile shrinks to what the caller's budget holds
+// (a third of the free HBM: several contexts on one GPU, a smaller card), in whole rounds of 2 048 waves down to 16 384
+// checks; below that the one-loop form (k_miller_loop + k_final_exp, no line buffer) runs instead of failing an allocation.
 constexpr size_t kPreparedTile = 65536;
-size_t pairing_ws_words(size_t B) {
-  const size_t tile = B < kPreparedTile ? B : kPreparedTile;
-  return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64 + (pairing_form(B) == kFormLines ? (size_t)grid_for(tile * kG2Lanes) * kLineWords * 64 : 0);
+constexpr size_t kPreparedMinTile = 16384;
+size_t pairing_tile(size_t B, size_t budget_bytes) {
+  if (pairing_form(B) != kFormLines) return 0;
+  const size_t per_check = (size_t)kG2Lanes * kLineWords * sizeof(int32_t);
+  size_t tile = kPreparedTile;
+  while (tile > kPreparedMinTile && tile * per_check > budget_bytes) tile /= 2;
+  if (tile * per_check > budget_bytes) return 0;
+  return B < tile ? B : tile;
+}
+size_t pairing_ws_words(size_t B, size_t tile) {
+  return (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64 + (tile ? (size_t)grid_for(tile * kG2Lanes) * kLineWords * 64 : 0);
 }
 
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
-                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws) {
+                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, PairingWs pws) {
   if (!B) return;
-  const PairingForm form = pairing_form(B);
+  int32_t* ws = pws.p;
+  PairingForm form = pairing_form(B);
+  if (form == kFormLines && !pws.tile) form = kFormPair;  // no room for the line buffer
   if (form == kFormQuad) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(grid_for(B * kQuadLanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);
     return;
@@ -184,8 +197,8 @@ void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uin
   }
   // prepared form: lines (stage P) -> accumulator (stage M) tile by tile through one line buffer, then ONE final exponentiation launch
   int32_t* lines = ws + (size_t)grid_for(B * kG2Lanes) * kFq12Words * 64;
-  for (size_t lo = 0; lo < B; lo += kPreparedTile) {
-    const size_t cnt = (B - lo < kPreparedTile) ? B - lo : kPreparedTile;
+  for (size_t lo = 0; lo < B; lo += pws.tile) {
+    const size_t cnt = (B - lo < pws.tile) ? B - lo : pws.tile;
     const unsigned grid = grid_for(cnt * kG2Lanes);
     int32_t* fb = ws + (size_t)grid_for(lo * kG2Lanes) * kFq12Words * 64;
     hipLaunchKernelGGL(k_miller_lines, dim3(grid), dim3(kBlock), 0, st, a + lo * sa, sa, b + lo * sb, sb, c + lo * sc, sc, d + lo * sd, sd, cnt,

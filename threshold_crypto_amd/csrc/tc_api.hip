@@ -144,11 +144,14 @@ struct Call {
     return d;
   }
   // the Miller values between the two kernels of a pairing check (k_pairing.hip)
-  int32_t* pairing_ws(size_t B) { return temp<int32_t>(tc::pairing_ws_words(B)); }
+  // (+ the line buffer of the prepared form, one tile of checks sized to the memory this call may spend: msm_table_budget)
+  tc::PairingWs pairing_ws(size_t B);
   // Checked-input mode (tc_ctx_set_input_checks): validate the first `take` points of `records` records of
   // n_per_job points each (stride 0 = ONE point shared by every job); job j owns record j / group.
-  void check_points(bool g2, const uint8_t* d_pts, size_t stride, size_t n_per_job, size_t take, size_t records, size_t group) {
-    if (!c->input_checks || failed || !d_pts || !records || !take) return;
+  // always: the test runs whatever the context's switch says (entries that multiply a SECRET by the operand)
+  void check_points(bool g2, const uint8_t* d_pts, size_t stride, size_t n_per_job, size_t take, size_t records, size_t group,
+                    bool always = false) {
+    if (!(c->input_checks || always) || failed || !d_pts || !records || !take) return;
     const size_t PB = g2 ? 192 : 96;
     if (stride == 0) {
       stride = PB;
@@ -235,6 +238,11 @@ size_t msm_table_budget(Call& k) {
   if (b > kMsmTableBudget) b = kMsmTableBudget;
   if (b < ((size_t)1 << 30)) b = (size_t)1 << 30;
   return b;
+}
+tc::PairingWs Call::pairing_ws(size_t B) {
+  static const char* cap = getenv("TC_PAIRING_BUDGET");  // experiments / tests: bytes the line buffer may take
+  const size_t tile = tc::pairing_tile(B, cap ? (size_t)strtoull(cap, nullptr, 10) : msm_table_budget(*this));
+  return tc::PairingWs{temp<int32_t>(tc::pairing_ws_words(B, tile)), tile};
 }
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
             uint8_t* d_st, int nbits = 64, tc::MsmFilter filter = tc::MsmFilter(), bool secret_scalars = false) {
@@ -1173,13 +1181,19 @@ static int verified_decrypt(tc_ctx* ctx, const uint8_t* sk, const uint8_t* u, co
   uint8_t* d_plain = plain ? k.out(plain, (size_t)total, /*zero=*/true) : nullptr;
   if (plain && d_pt) k.wipe_after_copy.emplace_back(d_pt, B * 96);  // g = [sk] u opens the ciphertext: not left in a staging slot
   k.begin_timing();
-  k.check_points(false, d_u, 96, 1, 1, B, 1);
-  k.check_points(true, d_w, 192, 1, 1, B, 1);
+  // ALWAYS, whatever tc_ctx_set_input_checks says: the pairing check cannot see a small-order component of u
+  // (u = u1 + T, T in E(Fq)[h1]: e(u, H) = e(u1, H)), and [sk] u would leak sk modulo the cofactor's small factors.  The
+  // reference cannot reach that state: Ciphertext deserialisation always runs the subgroup test (src/lib.rs:140-146).
+  k.check_points(false, d_u, 96, 1, 1, B, 1, /*always=*/true);
+  k.check_points(true, d_w, 192, 1, 1, B, 1, /*always=*/true);
   if (!k.failed) {
     tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
     tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok, k.pairing_ws(B));  // src/lib.rs:511
     k.apply_checks(B, nullptr, nullptr, 0, d_ok);
     tc::launch_g1_mul(ctx->stream, k.tables(), d_sk, d_u, 1, B, d_pt, d_st);
+    // a multiplication that reported an error (a non-canonical secret key: >= r) is not a decryption: ok = 0, like the
+    // reference, which cannot hold such an Fr
+    tc::launch_ok_and_status(ctx->stream, d_st, B, d_ok);
     // `if !ct.verify() { return None; }` (src/lib.rs:385, 453): a ciphertext that fails the check gets the identity, never [sk] u
     tc::launch_invalidate_jobs(ctx->stream, d_ok, 1, 1, B, d_st, d_pt, 96, nullptr);
     if (plain) tc::launch_xor_with_hash(ctx->stream, d_pt, d_v, d_off, B, d_plain, d_st);  // skips flagged jobs: zeros

@@ -410,7 +410,7 @@ struct Fq {
   // the same test on the low TWO limbs (56 bits of k p): no call needed afterwards, false positives ~2^-46
   TC_HD bool maybe_zero56() const {
     const uint64_t mask = (1ull << 56) - 1;
-    const uint64_t v = (uint64_t)((int64_t)l[0] + ((int64_t)l[1] << FQ_RADIX));
+    const uint64_t v = (uint64_t)(int64_t)l[0] + ((uint64_t)(int64_t)l[1] << FQ_RADIX);  // (mod 2^64: no shift of a negative value)
     const uint64_t t = (v * FQ_INV56) & mask;
     return ((t + 300u) & mask) <= 600u;
   }
@@ -865,8 +865,8 @@ TC_HD void fq_inv_limbs30(const int32_t* y, int32_t* out) {
       bbar = tb;
       f0 = nf0 - (odd ? nf1 : 0);
       g0 = ng0 - (odd ? ng1 : 0);
-      f1 = nf1 << 1;
-      g1 = ng1 << 1;
+      f1 = nf1 * 2;  // (not `<< 1`: the factors are signed)
+      g1 = ng1 * 2;
     }
     // ---- (a, b) <- exact combinations / 2^30, made non-negative -------------------------------
     int32_t na[FQ_INV_LIMBS], nb[FQ_INV_LIMBS];

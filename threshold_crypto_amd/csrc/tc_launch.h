@@ -156,13 +156,21 @@ void launch_subgroup_check_g1(hipStream_t st, const uint8_t* pts, size_t stride,
                               uint8_t* valid);
 void launch_subgroup_check_g2(hipStream_t st, const uint8_t* pts, size_t stride, size_t n_per_job, size_t take, size_t n,
                               uint8_t* valid);
+void launch_ok_and_status(hipStream_t st, const uint8_t* status, size_t B, uint8_t* ok);  // ok[j] &= status[j] == OK
 void launch_invalidate_jobs(hipStream_t st, const uint8_t* valid, size_t per_job, size_t group, size_t B, uint8_t* status,
                             uint8_t* out, size_t out_bytes, uint8_t* ok);
 
-// ws: pairing_ws_words(B) words -- the Miller values between the two kernels of a check (k_pairing.hip)
-size_t pairing_ws_words(size_t B);
+// ws: the Miller values between the kernels of a check and, for the prepared form, the line buffer of ONE tile of checks
+// (k_pairing.hip).  `tile` = checks per pass of the prepared form, sized by the caller from the memory that is free
+// (pairing_tile): 61.8 KB of line products per check, 4.05 GB for the full 65 536-check tile.
+struct PairingWs {
+  int32_t* p;
+  size_t tile;
+};
+size_t pairing_tile(size_t B, size_t budget_bytes);   // 0 = the line buffer does not fit: the one-loop form runs
+size_t pairing_ws_words(size_t B, size_t tile);
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
-                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, int32_t* ws);
+                          size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, PairingWs ws);
 
 // fix = false: the hash point WITHOUT its last constant multiplication (tc_gls.h g2_clear_cofactor); the
 // caller folds the constant into a scalar (launch_fr_scale_cofactor_fix) or a G1 operand

@@ -1,15 +1,26 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 (rocpd sqlite) output directories into small text/CSV files for profiles/.
-usage: python tools/rocpd_summary.py <dir-with-results.db> [<more dirs>...] > summary.csv"""
+usage: python tools/rocpd_summary.py [--last N] <dir-with-results.db> [<more dirs>...] > summary.csv
+--last N (r05, tools/profile_legs.py): per kernel name only its LAST N dispatches of the process (by start time) -- the timed
+repetitions of one leg, without the launches that set the workload up."""
 import glob
 import sqlite3
 import sys
 
 
+LAST = 0
+if len(sys.argv) > 2 and sys.argv[1] == "--last":
+    LAST = int(sys.argv[2])
+    del sys.argv[1:3]
+
+
 def kernels(db):
     c = sqlite3.connect(db)
+    src = "kernels"
+    if LAST:
+        src = "(select * from (select *, row_number() over (partition by name order by start desc) as rn from kernels) where rn <= %d)" % LAST
     q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(scratch_size), "
-         "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) from kernels "
+         "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(grid_x), max(workgroup_x) from " + src + " "
          "group by name order by sum(duration) desc")
     return list(c.execute(q))
 
@@ -20,7 +31,11 @@ def counters(db):
         cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
         if not cols:
             return []
-        q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+        src = "counters_collection"
+        if LAST:
+            src = ("(select * from (select *, row_number() over (partition by kernel_name, counter_name order by start desc) as rn "
+                   "from counters_collection) where rn <= %d)" % LAST)
+        q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from " + src + " "
              "group by kernel_name, counter_name order by kernel_name")
         return list(c.execute(q))
     except sqlite3.Error:
