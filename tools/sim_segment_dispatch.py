@@ -90,9 +90,59 @@ def sim_least_progress_first(C, S, W, nsimd=1024, paired=0.667, dt=0.002):
     return t
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--split"):
     W = float(sys.argv[1]) if len(sys.argv) > 1 else 2.03
     for S in (1, 2, 4, 8):
         print({"segments": S, "makespan_ms": round(sim(1372, S, W), 3), "one_wave_per_chain_ms": round(W / 0.667, 3)})
     for S in (4, 8):
         print({"policy": "least progress first", "segments": S, "makespan_ms": round(sim_least_progress_first(1372, S, W), 3)})
+
+
+# ---- r05: the [1/D] ladder of a FRACTION of the expensive jobs on two lane pairs --------------------------
+# A split job runs on two adjacent lane pairs of one wave: both compute the short joint ladder, pair A takes the top 25 columns
+# of the 64-column GLS ladder and the 39 doublings that bring it into place, pair B the low 39 columns (equal lengths: 25 x 8 820 +
+# 39 x 3 136 = 39 x 8 820 multiply-adds), one addition merges them.  A split wave holds 16 jobs and lasts 0.61 of the ladder + the
+# short ladder + the merge: 1.38 x the work per job, in shorter waves that the dispatcher can back-fill behind the cheap classes.
+# Lone-wave times from the measured launch: an expensive wave paired for its whole life ends at 5.0 ms => 3.33 ms
+# alone; the classes scale with their executed multiply-adds (profiles/executed_macs.json: 1.55 M / 0.736 M / 0.256 M).
+def sim_split(frac, split_last=True, nsimd=1024, paired=0.667, W=3.33):
+    w_d1, w_p2 = W * 0.256 / 1.55, W * 0.736 / 1.55
+    w_split = w_d1 + 0.61 * (W - w_d1) + 0.05
+    n_exp, n_p2, n_d1 = 1345, 381, 322           # waves per class of the 65 536-job batch (65.7 / 18.6 / 15.7 % of 2048)
+    n_split_jobs = int(round(n_exp * frac))
+    unsplit = [W] * (n_exp - n_split_jobs)
+    split = [w_split] * (2 * n_split_jobs)
+    cheap = [w_p2] * n_p2 + [w_d1] * n_d1
+    order = unsplit + cheap + split if split_last else unsplit + split + cheap
+    slots = [[None, None] for _ in range(nsimd)]
+    free = [(i, k) for k in (1, 0) for i in range(nsimd - 1, -1, -1)]   # slot 0 of every SIMD first, then slot 1
+    nxt, t, running = 0, 0.0, 0
+    while nxt < len(order) or running:
+        while nxt < len(order) and free:
+            i, k = free.pop()
+            slots[i][k] = order[nxt]
+            nxt += 1
+            running += 1
+        # advance to the next completion
+        dt = min((w / (paired if (s[0] is not None and s[1] is not None) else 1.0)) for s in slots for w in s if w is not None)
+        t += dt
+        for i, s in enumerate(slots):
+            rate = paired if (s[0] is not None and s[1] is not None) else 1.0
+            for k in (0, 1):
+                if s[k] is not None:
+                    s[k] -= rate * dt
+                    if s[k] <= 1e-9:
+                        s[k] = None
+                        free.append((i, k))
+                        running -= 1
+    return t
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--split":
+    import json
+    rows = [{"fraction_of_expensive_jobs_split": f, "launch_ms_split_waves_last": round(sim_split(f, True), 2),
+             "launch_ms_split_waves_after_the_unsplit_ones": round(sim_split(f, False), 2)} for f in (0.0, 0.1, 0.2, 0.25, 0.3, 0.4, 0.5, 0.75, 1.0)]
+    best = min(min(r["launch_ms_split_waves_last"], r["launch_ms_split_waves_after_the_unsplit_ones"]) for r in rows)
+    print(json.dumps({"model": "1024 SIMDs x 2 slots, in-order dispatch, two co-resident waves at 0.667 each; lone expensive wave 3.33 ms",
+                      "rows": rows, "best_ms": best, "gate_ms": 4.4, "built": best <= 4.4}))
+    sys.exit(0)
