@@ -56,9 +56,17 @@ def fail(what, rnd_no, j, extra=""):
 checked = 0
 rounds = 0
 t_end = time.time() + SECONDS
+duo_rounds = 0
 while time.time() < t_end:
     rounds += 1
     B = rnd.choice([1, 2, 31, 32, 33, 63, 64, 65, 97, 130])
+    # r05: every other round runs the TWO-jobs-per-lane-pair forms of the checked G2 decode and the G2 hashes (csrc/tc_duo.h), which
+    # the library picks from 32 769 / 131 072 jobs on by itself: TC_DUO_MIN is read at every launch (csrc/tc_launch.h duo_form)
+    if rnd.randrange(2):
+        os.environ["TC_DUO_MIN"] = "1"
+        duo_rounds += 1
+    else:
+        os.environ.pop("TC_DUO_MIN", None)
     # ---- scalar multiplication (S signers x B points) -------------------------------------------
     S = rnd.choice([1, 2, 3])
     ks = [rnd.choice([0, 1, o.R - 1, rnd.randrange(o.R), rnd.randrange(1 << 64)]) for _ in range(S)]
@@ -357,4 +365,4 @@ while time.time() < t_end:
             if (std[j] != 0) != (rc2 != 0) or (rc2 == 0 and bytes(d2[j]) != want2):
                 fail("g2_decompress", rounds, j)
     checked += 2 * B
-print("SOAK-OK seed=%d rounds=%d jobs_checked=%d seconds=%.0f" % (SEED, rounds, checked, SECONDS), flush=True)
+print("SOAK-OK seed=%d rounds=%d (two-jobs-per-lane-pair forms in %d of them) jobs_checked=%d seconds=%.0f" % (SEED, rounds, duo_rounds, checked, SECONDS), flush=True)

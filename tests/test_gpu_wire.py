@@ -455,3 +455,31 @@ def test_two_jobs_per_lane_pair_forms_equal_the_one_job_forms(engine, rnd):
             assert bytes(hg[i]) == o.g2_uncompressed(o.hash_g1_g2(P, msgs[i]))
         else:
             assert bytes(hg[i]) == o.g2_uncompressed(None)
+
+
+def test_hashes_above_the_two_message_threshold_equal_the_one_message_form(engine, rnd):
+    """131 073 messages (odd: the last lane pair holds one) -- the size from which the library hashes two messages per lane pair by
+    itself (csrc/tc_launch.h kDuoMinHash) -- through hash_g2 with the library's own choice and with the one-message form forced:
+    identical bytes for every message, Oracle B on a sample.  Checked decodes the same way at 32 769 points (kDuoMinDecode)."""
+    n = 131073
+    msgs = [b"tc/duo/%d" % i + bytes(i % 5) for i in range(n)]
+    blob, off = pack_messages(msgs)
+    saved = os.environ.pop("TC_DUO_MIN", None)
+    try:
+        own = engine.hash_g2(blob, off)
+        os.environ["TC_DUO_MIN"] = str(10 ** 12)
+        one = engine.hash_g2(blob, off)
+        assert (own == one).all()
+        for j in [0, 1, 65535, 65536, 131071, 131072] + [rnd.randrange(n) for _ in range(10)]:
+            assert bytes(own[j]) == c.hash_g2(msgs[j])
+        pts = [o.g2_compressed(o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))) for _ in range(16)] + [o.g2_compressed(None)]
+        enc = np.frombuffer(b"".join(pts[rnd.randrange(len(pts))] for _ in range(32769)), np.uint8).reshape(32769, 96).copy()
+        enc[777, 5] ^= 0x40                                    # one undecodable encoding (with overwhelming probability)
+        one_p, one_s = engine.g2_decompress(enc)
+        os.environ.pop("TC_DUO_MIN")
+        own_p, own_s = engine.g2_decompress(enc)
+        assert (own_p == one_p).all() and (own_s == one_s).all() and int(own_s.sum()) in (0, 3)
+    finally:
+        os.environ.pop("TC_DUO_MIN", None)
+        if saved is not None:
+            os.environ["TC_DUO_MIN"] = saved
