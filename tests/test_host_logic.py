@@ -134,7 +134,7 @@ def test_config5_two_rank_gloo_pipeline_sharding_broadcast_gather():
         assert eng.L.hs_g2_mul(msk, bytes(single["hashes"][j]), b) == 0 and b.raw == single["sig"][j].tobytes()
 
 
-R05_TAG = "r05_a"   # the capture (tools/capture_r05.sh) committed with the shipped library: profiles/README.md
+R05_TAG = "r05_b"   # the capture (tools/capture_r05.sh) committed with the shipped library: profiles/README.md
 
 
 def _check_round5_lines(root, macs):
