@@ -305,7 +305,8 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
-    if not args.no_cpu_baseline and not args.test_engine:
+    # (the CPU legs run on rank 0 of a one-GPU run only: N ranks would rebuild and time N oracles against each other on one host)
+    if not args.no_cpu_baseline and not args.test_engine and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         oracle_for_this_host()
 
     import torch
