@@ -294,6 +294,11 @@ def test_bench_line_contract():
     s = d["streaming"]
     assert s["overlapped"] is True and s["contexts"] == 2 and s["value"] > 0
     assert d["sustained"]["seconds"] >= 0.15 and d["config3"]["kernel_ms"] > 0
+    # r05: the CPU path beside the pairing half of BASELINE's metric too, rebuilt for this box's cores; duplicated lane work counted once
+    c3 = d["config3"]["cpu_baseline"]
+    assert c3["kind"] == "port" and c3["unit"] == "pairing_verifies/s" and c3["value"] > c3["single_thread_per_s"] > 0
+    assert "march=native" in c["build"] and "march=native" in c3["build"]
+    assert 0 < r["frac_useful"] <= r["frac"] and 0 < d["config3"]["roofline"]["frac_useful"] <= d["config3"]["roofline"]["frac"]
 
 
 @pytest.mark.parametrize("config", [2, 5])
