@@ -99,15 +99,18 @@ if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--split
 
 
 # ---- r05: the [1/D] ladder of a FRACTION of the expensive jobs on two lane pairs --------------------------
-# A split job runs on two adjacent lane pairs of one wave: both compute the short joint ladder, pair A takes the top 25 columns
-# of the 64-column GLS ladder and the 39 doublings that bring it into place, pair B the low 39 columns (equal lengths: 25 x 8 820 +
-# 39 x 3 136 = 39 x 8 820 multiply-adds), one addition merges them.  A split wave holds 16 jobs and lasts 0.61 of the ladder + the
-# short ladder + the merge: 1.38 x the work per job, in shorter waves that the dispatcher can back-fill behind the cheap classes.
+# A split job runs on two adjacent lane pairs of ONE wave (they merge with a DPP exchange), so the two halves execute in lockstep:
+# with pair A on the top k columns (+ 64 - k positioning doublings) and pair B on the low 64 - k, the wave issues
+# (64 - k) x (doubling + addition) + k x doubling -- least at k = 32: 32 x 8 820 + 32 x 3 136 = 0.68 of the 64-column ladder.  Both
+# pairs run the short joint ladder and build the 8-entry psi table; one addition merges.  Per lane (multiply-adds of the generic
+# class, profiles/executed_macs.json / 2): short ladder 0.128 M + table 0.075 M + ladder 0.564 M + rest = 0.775 M, so a split wave
+# lasts 0.165 + 0.097 + 0.68 x 0.728 + 0.015 = 0.77 of a full one for HALF the jobs: 1.54 x the work per job, in shorter waves
+# that the dispatcher can back-fill behind the cheap classes.
 # Lone-wave times from the measured launch: an expensive wave paired for its whole life ends at 5.0 ms => 3.33 ms
-# alone; the classes scale with their executed multiply-adds (profiles/executed_macs.json: 1.55 M / 0.736 M / 0.256 M).
+# alone; the classes scale with their executed multiply-adds (1.55 M / 0.736 M / 0.256 M).
 def sim_split(frac, split_last=True, nsimd=1024, paired=0.667, W=3.33):
     w_d1, w_p2 = W * 0.256 / 1.55, W * 0.736 / 1.55
-    w_split = w_d1 + 0.61 * (W - w_d1) + 0.05
+    w_split = 0.77 * W
     n_exp, n_p2, n_d1 = 1345, 381, 322           # waves per class of the 65 536-job batch (65.7 / 18.6 / 15.7 % of 2048)
     n_split_jobs = int(round(n_exp * frac))
     unsplit = [W] * (n_exp - n_split_jobs)
