@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
   rd(f, &len, 4); Bytes plain(len); rd(f, plain.data(), len);
 
   std::vector<std::pair<std::int64_t, SecretKeyShare>> odd;   // shares at indices u64 cannot carry (IntoFr for i64)
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 5; i++) {
     std::int64_t ix; FrBytes fr;
     rd(f, &ix, 8); rd(f, fr.data(), 32);
     odd.emplace_back(ix, SecretKeyShare(fr));
@@ -90,6 +90,21 @@ int main(int argc, char** argv) {
     for (auto& kv : odd) fsigs[FrIndex::from_i64(kv.first)] = kv.second.sign(msg);
     CHECK(pk_set.combine_signatures(fsigs) == expected);
     CHECK(FrIndex::from_i64(-1) < FrIndex::from_i64(-1) == false && FrIndex::from_u64(5) < FrIndex::from_i64(-7));
+    // (round 5) keys of type i64: a BTreeMap<i64, _> iterates by the SIGNED value, so with t + 2 shares interpolate()
+    // takes {-2^63, -2^40, -1, 7} and never looks at key 9 -- a bad share THERE must not matter.  Keyed by FrIndex (the order of
+    // BTreeMap<Fr, _>) the first t + 1 are {7, 9, ...}: the same bad share spoils the result.  Both behaviours are the reference's,
+    // each for its own key type.
+    std::map<std::int64_t, SignatureShare> isigs;
+    std::map<FrIndex, SignatureShare> fbad;
+    for (auto& kv : odd) {
+      SignatureShare sh = kv.second.sign(msg);
+      if (kv.first == 9) sh = odd[0].second.sign(msg);   // the share of another node under key 9
+      isigs[kv.first] = sh;
+      fbad[FrIndex::from_i64(kv.first)] = sh;
+    }
+    CHECK(isigs.size() == 5 && isigs.begin()->first < 0);
+    CHECK(pk_set.combine_signatures(isigs) == expected);
+    CHECK(!(pk_set.combine_signatures(fbad) == expected));
     std::vector<std::vector<std::pair<std::uint64_t, std::array<std::uint8_t, SIG_SIZE>>>> wjobs(3);
     for (std::size_t j = 0; j < 3; j++)
       for (const auto& kv : jobs[j]) wjobs[j].emplace_back(kv.first, kv.second.sig.to_bytes());

@@ -43,7 +43,7 @@ def test_cpp_api_replays_reference_tests(tmp_path):
     u, v, w = o.encrypt_with_r(commit[0], rnd.randrange(1, o.R), plain)
     fx += o.g1_uncompressed(u) + struct.pack("<I", len(v)) + v + o.g2_uncompressed(w)
     fx += struct.pack("<I", len(plain)) + plain
-    for ix in (-1, -(2 ** 40), 7, -(2 ** 63)):          # shares at i64 indices (IntoFr for i64: negative = -(|x|) mod r)
+    for ix in (-1, -(2 ** 40), 7, -(2 ** 63), 9):       # shares at i64 indices (IntoFr for i64: negative = -(|x|) mod r); t + 2 of them
         fx += struct.pack("<q", ix) + o.fr_to_bytes(o.poly_evaluate(poly, (ix + 1) % o.R))
     path = tmp_path / "fixture.bin"
     path.write_bytes(fx)

@@ -448,3 +448,18 @@ def test_commitment_evaluate_batch_never_re_enters_itself():
     assert e.idx == [0, 2 ** 64 - 2]
     R = poly._R
     assert e.scalars == [[1, 2 ** 64, 2 ** 128 % R], [1, R - 1, 1]]
+
+
+def test_share_maps_iterate_like_the_reference_btreemap():
+    """PublicKeySet::combine_signatures / decrypt take `IntoIterator<Item = (T, &Share)>` and callers pass BTreeMaps: interpolate()
+    uses the FIRST t + 1 samples in the map's order (/root/reference/src/lib.rs:727-730).  The Python mirror orders a dict the way
+    the BTreeMap of ITS key type would: integers by their signed value (BTreeMap<i64, _>: negatives first), `Fr` keys by their
+    canonical value (BTreeMap<Fr, _>: the images of negative integers sort LAST); a dict mixing the two has no counterpart in the
+    reference and is refused; sequences of pairs keep the caller's order."""
+    from threshold_crypto_amd import api
+    assert [k for k, _ in api._ordered({3: "a", -2: "b", 0: "c", -(2 ** 40): "d"})] == [-(2 ** 40), -2, 0, 3]
+    frs = {api.Fr(-2): "b", api.Fr(3): "a", api.Fr(0): "c"}
+    assert [int(k) for k, _ in api._ordered(frs)] == [0, 3, api._R - 2]
+    with pytest.raises(TypeError):
+        api._ordered({api.Fr(1): "x", 2: "y"})
+    assert api._ordered([(5, "x"), (-1, "y")]) == [(5, "x"), (-1, "y")]
