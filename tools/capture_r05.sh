@@ -31,6 +31,13 @@ passes ${tag}_config5 python $R/bench.py --config 5 --steps 3 --warmup 1 --no-cp
 ( echo "$PEAK"; echo "# python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline"
   python tools/rocpd_summary.py gpurun_out/prof_${tag}_config5_stats gpurun_out/prof_${tag}_config5_fetch gpurun_out/prof_${tag}_config5_write gpurun_out/prof_${tag}_config5_sq1 gpurun_out/prof_${tag}_config5_sq2 ) > profiles/${tag}_config5_rocprofv3_summary.csv 2>&1
 for p in stats fetch write sq1 sq2; do rm -rf gpurun_out/prof_${tag}_config5_$p; done
+# the bench command itself under --kernel-trace --stats (the kernel averages of the WHOLE line's process: headline steps, config 3 / 4
+# legs, work-load generation -- what round 4's captures were; the per-leg files above are the ones profile_constants.json reads)
+rm -rf gpurun_out/prof_${tag}_bench_stats
+( cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_bench_stats -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --in-flight 1 --sustain-seconds 0 --profile-run > $R/gpurun_out/prof_${tag}_bench_stats.log 2>&1 )
+( echo "$PEAK"; echo "# python bench.py --steps 8 --warmup 2 --no-cpu-baseline --in-flight 1 --sustain-seconds 0 --profile-run"
+  python tools/rocpd_summary.py gpurun_out/prof_${tag}_bench_stats ) > profiles/${tag}_bench_rocprofv3_summary.csv 2>&1
+rm -rf gpurun_out/prof_${tag}_bench_stats
 cp gpurun_out/legs_${tag}.txt profiles/${tag}_legs.txt
 # the constants of THIS capture, then the line that carries them
 python tools/profile_constants.py $tag > /dev/null && cp profiles/profile_constants.json gpurun_out/profile_constants_${tag}.json
