@@ -265,6 +265,9 @@ TC_HD void jac_to_affine_x2(const G2Jac& p, const G2Jac& q, G2Affine& pa, G2Affi
   if (qinf) qa = G2Affine::infinity();
 }
 
+// (out of line for the two-point decode: two inlined copies cost the kernel 147 spilled registers)
+TC_HD_NOINLINE bool g2_in_subgroup_call(const G2Affine& p) { return g2_in_subgroup(p); }
+
 // The checked decode of TWO compressed G2 points (EncodedPoint::into_affine of pairing 0.16 behind from_bytes,
 // /root/reference/src/lib.rs:246-252): same verdicts and points as g2_decode_compressed on each, one control flow for the
 // pair -- a point that fails early keeps a stand-in through the arithmetic and is replaced at the end.
@@ -293,8 +296,8 @@ TC_HD void g2_decode_compressed_x2(const uint8_t* ba, const uint8_t* bb, G2Affin
   if (fq2_lex_largest(yb) != gb) yb = -yb;
   pa = G2Affine{xa, ya, false};
   pb = G2Affine{xb, yb, false};
-  const bool ina = g2_in_subgroup(pa);
-  const bool inb = g2_in_subgroup(pb);
+  const bool ina = g2_in_subgroup_call(pa);
+  const bool inb = g2_in_subgroup_call(pb);
   oka = ka == 2 ? (sqa && ina) : ka == 1;
   okb = kb == 2 ? (sqb && inb) : kb == 1;
   if (ka != 2 || !oka) pa = G2Affine::infinity();
