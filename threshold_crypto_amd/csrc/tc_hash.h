@@ -260,12 +260,6 @@ TC_HD_NOINLINE G2Jac g2_random_from_seed(const uint32_t* seed_words, bool fix = 
   return res;
 }
 
-// ---- two messages per lane pair (tc_duo.h) --------------------------------------------------------
-// The same function for TWO seeds.  Everything a message does on its own -- its ChaCha20 stream, the rejection sampling of x,
-// the Jacobi symbol of a candidate's norm, the two exponentiations of the square root -- runs on ONE lane (lane 0: message A,
-// lane 1: message B); the Fq2 work -- x^3 + b of a candidate, sign selection, cofactor clearing -- runs for A and then for B
-// with both lanes.  One candidate per message and round (the one-message form tests two candidates of ONE message on its two
-// lanes): per round the pair decides two candidates either way.  Same candidates, same order, same result.
 // the tail of one candidate: the root G2::random keeps (get_point_from_x: the lexicographically larger one iff `greatest`) and
 // scale_by_cofactor.  A real function: the two-message form calls it once per message.
 TC_HD_NOINLINE G2Jac g2_random_finish(const Fq2& x, const Fq2& y, bool greatest, bool fix) {
@@ -275,6 +269,12 @@ TC_HD_NOINLINE G2Jac g2_random_finish(const Fq2& x, const Fq2& y, bool greatest,
   const G2Affine cand{x, (y_lt_negy ^ greatest) ? y : negy, false};
   return g2_clear_cofactor(cand, fix);  // = [h2] cand, the value scale_by_cofactor returns (fix = false: tc_gls.h)
 }
+// ---- two messages per lane pair (tc_duo.h) --------------------------------------------------------
+// The same function for TWO seeds.  Everything a message does on its own -- its ChaCha20 stream, the rejection sampling of x,
+// the Jacobi symbol of a candidate's norm, the two exponentiations of the square root -- runs on ONE lane (lane 0: message A,
+// lane 1: message B); the Fq2 work -- x^3 + b of a candidate, sign selection, cofactor clearing -- runs for A and then for B
+// with both lanes.  One candidate per message and round (the one-message form tests two candidates of ONE message on its two
+// lanes): per round the pair decides two candidates either way.  Same candidates, same order, same result.
 struct Seed8 {
   uint32_t w[8];
 };
