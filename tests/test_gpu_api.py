@@ -267,7 +267,7 @@ def test_encrypt_and_public_key_shares_entry_points(engine, rnd):
 
 
 def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the contract's fields: the headline is K steps on ONE context (launches do not
+    """bench.py prints ONE compact JSON line (< 8 000 bytes, the only JSON object on stdout) with the contract's fields: the headline is K steps on ONE context (launches do not
     overlap, so the per-launch kernel time fits inside the step time), the two-contexts figure is the `streaming` object
     marked overlapped, the roofline fraction is a utilisation (<= 1)."""
     import json
@@ -277,9 +277,21 @@ def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "1", "--batch", "8192",
                           "--no-extras", "--cpu-seconds", "1", "--sustain-seconds", "0.2"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    # what the driver keeps is the LAST line of the last 8 000 bytes of stdout -- one compact JSON object
+    # (tests/benchline.py reads it that way); the explanatory detail object is in bench_detail.json and, tagged, on stderr
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import benchline
+    line, d = benchline.parse(out.stdout, out.stderr)
+    assert len(out.stdout.splitlines()[-1]) < 8000 and json.loads(out.stdout[-8000:].splitlines()[-1]) == line
+    assert json.load(open(os.path.join(root, "bench_detail.json"))) == d
+    for k in ("bound", "kernel", "kernel_ms", "frac", "frac_useful", "executed_macs_per_unit", "algorithmic_bytes_per_launch", "traffic", "peak", "unit", "achieved"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == d["roofline"]["frac"] and 0 < line["roofline"]["frac"] <= 1
+    for k in ("value", "unit", "cores", "kind"):
+        assert line["cpu_baseline"][k] == d["cpu_baseline"][k], k
+    assert line["config"]["t"] == 3 and line["config"]["N"] == 10 and line["config"]["batch_per_gpu"] == 8192 and line["ranks"]["world_size"] == 1
+    assert line["config3"]["value"] == d["config3"]["value"] and line["config3"]["kernel_ms"] == d["config3"]["kernel_ms"]
+    assert line["config3"]["cpu_baseline"]["value"] == d["config3"]["cpu_baseline"]["value"] and 0 < line["config3"]["frac"] <= 1
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "streaming", "sustained", "config3", "ranks"):
         assert k in d, k
@@ -322,9 +334,10 @@ def test_bench_under_the_launcher_runs_its_collectives_over_rccl(config):
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = lines[0]
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import benchline
+    line, d = benchline.parse(out.stdout, out.stderr)
+    assert line["ranks"]["backend"] == "nccl" and line["ranks"]["distinct_devices"] == 1 and line["ranks"]["rccl_version"] == d["ranks"]["rccl_version"]
     assert d["n_gpus"] == 1 and d["ranks"]["backend"] == "nccl" and d["ranks"]["world_size"] == 1 and len(d["ranks"]["devices"]) == 1
     assert d["ranks"]["rccl_version"] not in (None, "unknown") and "external launcher" in d["ranks"]["launched_by"]
     assert d["value"] > 0 and d["scaling"] == "weak"

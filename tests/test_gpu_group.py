@@ -17,11 +17,20 @@ def wl(engine):
     return ThresholdSigWorkload(engine, 3, 10, 300)
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def _device_count():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+# [0, 1]: two PHYSICAL devices -- RCCL's broadcast and all-reduce cross xGMI.  Runs by itself wherever a second GPU is
+# visible (row (e) has never met RCCL across two devices); skipped on the one-GPU boxes of this pool.
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 1]])
 def test_group_matches_single_context(engine, wl, devices):
+    if len(set(devices)) > _device_count():
+        pytest.skip("needs %d GPUs, this node shows %d" % (len(set(devices)), _device_count()))
     g = Group(devices)
     try:
-        assert g.size() == len(devices) and g.uses_rccl() == (len(devices) == 1)
+        assert g.size() == len(devices) and g.uses_rccl() == (len(set(devices)) == len(devices))
         spans = [g.shard(wl.B, r) for r in range(g.size())]
         assert spans[0][0] == 0 and sum(c for _, c in spans) == wl.B and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
         commit = np.stack([np.frombuffer(c, dtype=np.uint8) for c in wl.sks.public_keys(engine).commit])
@@ -74,3 +83,56 @@ def test_group_config5_pipeline(engine):
     h = engine.hash_g2(flat, off)
     msig, st = engine.g2_mul(np.frombuffer(sks.poly[0].to_bytes(32, "little"), dtype=np.uint8)[None].copy(), h)
     assert (msig[:, 0] == sig).all()
+
+
+def test_group_config5_pipeline_on_two_devices(engine):
+    """The same one-call config-5 flow across two PHYSICAL GPUs (key set over RCCL/xGMI, counts all-reduced): equal to the [0, 0]
+    group's and the single context's results.  Skipped unless a second GPU is visible."""
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs, this node shows %d" % _device_count())
+    t, N, B = 8, 12, 70
+    sks = key_set(t)
+    commit = np.stack([np.frombuffer(c, dtype=np.uint8) for c in sks.public_keys(engine).commit])
+    sk_table = np.stack([np.frombuffer(sks.secret_key_share(i)._bytes(), dtype=np.uint8) for i in range(N)])
+    idx = signer_subsets_np(B, N, t)
+    flat, off = pack_messages(messages(B))
+    got = {}
+    for devices in ([0, 0], [0, 1]):
+        g = Group(devices)
+        try:
+            assert g.uses_rccl() == (devices == [0, 1])
+            g.set_keyset(commit)
+            assert all((g.get_keyset(r) == commit).all() for r in range(2))
+            got[tuple(devices)] = g.sign_combine_verify(sk_table, idx, flat, off)
+        finally:
+            g.close()
+    (s0, ok0, n0), (s1, ok1, n1) = got[(0, 0)], got[(0, 1)]
+    assert (s0 == s1).all() and ok0.all() and ok1.all() and n0 == n1 == B
+
+
+def test_bench_gpus_2_on_two_devices():
+    """`bench.py --gpus 2 --config 5` as the driver starts it, on two PHYSICAL GPUs when the node has them: two ranks joined over
+    RCCL (backend nccl), two distinct devices, per-rank records equal to the emulated two-rank run on ONE GPU (same slices, same
+    signatures), and a line that stays inside the driver's 8 KB.  Skipped on a one-GPU box."""
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs, this node shows %d" % _device_count())
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import benchline
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--config", "5", "--batch", "4096", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    line, d = benchline.parse(two.stdout, two.stderr)
+    assert line["n_gpus"] == 2 and line["ranks"] == dict(line["ranks"], world_size=2, backend="nccl", distinct_devices=2)
+    assert d["ranks"]["world_size"] == 2 and len(set(d["ranks"]["devices"])) == 2 and d["valid_total_all_ranks"] == 2 * 4096
+    emu = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--emulate-world", "2"] + common, capture_output=True, text=True,
+                         timeout=1500, cwd=root, env=env)
+    assert emu.returncode == 0, emu.stderr[-3000:]
+    _, e = benchline.parse(emu.stdout, emu.stderr)
+    assert d["rank_records_start_jobs_valid_digest"] == e["rank_records_start_jobs_valid_digest"]
+    assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[0, 4096, 4096], [4096, 4096, 4096]]

@@ -331,8 +331,11 @@ def _run_bench(*argv, timeout=900):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    return out, [json.loads(l) for l in lines]
+    # stdout = the driver's compact line and nothing else (tests/benchline.py checks it the way the driver reads it); the tests
+    # below look at the DETAIL object (stderr, tagged), of which the compact line is a projection
+    import benchline
+    out.compact, detail = benchline.parse(out.stdout, out.stderr)
+    return out, ([detail] if detail is not None else [])
 
 
 def test_bench_gpus_2_starts_two_ranks_by_itself():
@@ -347,6 +350,7 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["devices"] == ["cpu:0", "cpu:1"]
     assert "self-spawn" in d["ranks"]["launched_by"] and d["ranks"]["backend"] == "gloo" and "test_harness" in d
+    assert out.compact["n_gpus"] == 2 and out.compact["ranks"]["distinct_devices"] == 2 and "test_harness" in out.compact
     assert d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["batch_per_gpu"] == 3 and d["verified_all"] is True
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01        # whole-job rate: both ranks' jobs
     assert d["pairing_verify_valid_count_all_ranks"] == 2 * 2                              # 3 jobs per rank, job 0 of each corrupted
@@ -376,6 +380,10 @@ def test_bench_gpus_8_rank_logic_on_gloo():
     d = lines[0]
     assert len(lines) == 1 and d["n_gpus"] == 8 and d["valid_total_all_ranks"] == 8
     assert [r[:3] for r in d["rank_records_start_jobs_valid_digest"]] == [[r, 1, 1] for r in range(8)]
+    # the eight-rank line stays well inside the driver's 8 KB (device list and full digests live in the detail object)
+    assert out.compact["ranks"]["distinct_devices"] == 8 and len(out.stdout.splitlines()[-1]) < 3000
+    assert [r[:3] for r in out.compact["rank_records"]] == [[r, 1, 1] for r in range(8)]
+    assert all(str(full[3]).startswith(short[3]) for full, short in zip(d["rank_records_start_jobs_valid_digest"], out.compact["rank_records"]))
 
 
 def test_config5_emulated_world_equals_the_eight_rank_run():
@@ -411,9 +419,10 @@ def test_bench_under_a_launcher_joins_the_rendezvous_even_as_the_only_rank():
            "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
-    d = lines[0]
-    assert len(lines) == 1 and d["n_gpus"] == 1 and d["ranks"]["backend"] == "gloo" and d["ranks"]["devices"] == ["cpu:0"]
+    import benchline
+    line, d = benchline.parse(out.stdout, out.stderr)
+    assert line["ranks"] == {"world_size": 1, "backend": "gloo", "rccl_version": None, "distinct_devices": 1, "launched_by": line["ranks"]["launched_by"]}
+    assert d["n_gpus"] == 1 and d["ranks"]["backend"] == "gloo" and d["ranks"]["devices"] == ["cpu:0"]
     assert "external launcher" in d["ranks"]["launched_by"] and d["verified_all"] is True
 
 
