@@ -140,6 +140,34 @@ def test_rust_shim_calls_existing_entry_points_with_matching_arity():
         assert need in used, need
 
 
+def test_rust_shim_has_no_panics():
+    """VERDICT r05 item 3 / SURVEY 8b "no panics on the hot path": a call-level failure of the library (TC_ERR_HIP from a failed
+    hipMalloc, a lost device) must come back as `Err(GpuError)`, never abort the node.  Outside `#[cfg(test)]` gpu.rs holds no
+    panicking construct, `check` returns a Result, every call of it is propagated with `?` (or is the function's value), and
+    every public batch method returns `GpuResult<_>` (the reference returns `Result` there too: src/error.rs:7-17,
+    src/lib.rs:608-626)."""
+    src = open(os.path.join(ROOT, "rust", "threshold_crypto_gpu", "gpu.rs")).read()
+    src = src.split("#[cfg(test)]")[0]
+    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("//"))
+    for bad in ("panic!", "unwrap()", ".expect(", "assert!", "assert_eq!", "assert_ne!", "unreachable!", "unimplemented!", "todo!", "process::abort", "process::exit"):
+        assert bad not in code, bad
+    # slice indexing by a value the LIBRARY returned would be a hidden panic: the only indices are the caller's own offsets / sizes
+    assert len(re.findall(r"fn check\(&self, rc: c_int\) -> GpuResult<\(\)>", code)) == 2        # Gpu and GpuGroup
+    checks = re.findall(r"(?:gpu|self)\.check\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\)(.)", code, flags=re.S)
+    assert len(checks) >= 30 and all(c in "?\n" or c == "\r" for c in checks), [c for c in checks if c not in "?\n"]
+    assert "Internal(u8)" in code and "GpuError(rc, msg)" in code
+    pub = re.findall(r"pub fn (\w+)[^{;]*?->\s*([^{]+?)\s*(?:where[^{]*)?\{", code, flags=re.S)
+    assert len(pub) >= 30
+    infallible = {"new", "trusted_operands", "size"}                     # constructors return Result<Self, GpuError>; plain getters
+    for name, ret in pub:
+        if name in infallible:
+            continue
+        assert ret.startswith("GpuResult<"), (name, ret)
+    # ... and functions without a return type are only the getters / setters above
+    for name in re.findall(r"pub fn (\w+)\([^)]*\)\s*\{", code):
+        assert name in infallible, name
+
+
 def test_design_quotes_the_shipped_kernel_resources():
     """DESIGN.md printed 1 931 spilled registers for a kernel whose shipped code object had 2 238.  Register,
     scratch, LDS and spill figures now appear in DESIGN.md ONLY inside the block tools/kernel_resources.py generates from the
