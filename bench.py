@@ -33,7 +33,8 @@ scaling: --gpus 8 is the BASELINE batch), nothing larger than the key set crosse
 
 One process per GPU; for N > 1 the batch is per-rank (weak scaling), the key-set parameters are broadcast from rank 0
 over RCCL and the per-rank valid counts are all-reduced; there is no data-path collective (jobs are independent).
-Prints ONE JSON line (rank 0).  The oracle (oracle/) is used only for the cpu_baseline leg and to check the GPU
+Rank 0 prints ONE compact JSON line to stdout -- the only thing this script writes there, < 8 000 bytes at any world size (what the
+driver parses) -- after the full DETAIL object has gone to bench_detail.json and, tagged `bench_detail `, to stderr.  The oracle (oracle/) is used only for the cpu_baseline leg and to check the GPU
 output of the timed batch bit-for-bit.
 
 --backend gloo --test-engine hostsim (tests/test_host_logic.py): the same rank start-up, rendezvous, broadcast,
@@ -290,7 +291,12 @@ def oracle_for_this_host():
     gcc = shutil.which("gcc")
     if not gcc or os.environ.get("TC_ORACLE_LIB"):
         return
-    out = os.path.join(tempfile.gettempdir(), "libtc_oracle_native_%d.so" % os.getuid())
+    # a directory of this process's own (mkdtemp: mode 0700, unpredictable name -- ADVICE r05: a fixed path under /tmp can be raced by
+    # a concurrent run and pre-created by another user); removed when the process exits
+    import atexit
+    build_dir = tempfile.mkdtemp(prefix="tc_oracle_native_")
+    atexit.register(shutil.rmtree, build_dir, True)
+    out = os.path.join(build_dir, "libtc_oracle_native.so")
     src = os.path.join(ROOT, "oracle", "c", "tc_oracle.c")
     try:
         subprocess.run([gcc, "-O3", "-march=native", "-fPIC", "-std=gnu11", "-fvisibility=hidden", "-shared", "-o", out, src, "-lpthread"],
@@ -741,7 +747,11 @@ def run_config2(args, eng, dev, rank, world, peak):
         sync()
         extras["hash_g2_per_s"] = round(B * world / (time.perf_counter() - e0), 1)
         assert bool((hh == d_hashes).all().item())
-        legs["hash_g2"] = roofline("k_hash_g2_x2" if B >= 131072 else "k_hash_g2", "hash_g2_x2" if B >= 131072 else "hash_g2", "hash_g2", "hash_g2", t, B,
+        # which form ran: the context's own thresholds (tc_ctx_get_tuning; csrc/tc_launch.h kDuoMinHash / kDuoMinDecode unless the
+        # environment said otherwise when the context was created)
+        tuning = eng.tuning()
+        hash_x2 = B >= tuning["duo_min_hash"]
+        legs["hash_g2"] = roofline("k_hash_g2_x2" if hash_x2 else "k_hash_g2", "hash_g2_x2" if hash_x2 else "hash_g2", "hash_g2", "hash_g2", t, B,
                                    hash_kernel_ms, peak, traffic_key="hash_g2")
         # ---- config 4: threshold decryption = Ciphertext::verify + G1 combine + keystream -------------------
         we = ThresholdEncWorkload(eng, t, N, B, start=start)
@@ -769,16 +779,16 @@ def run_config2(args, eng, dev, rank, world, peak):
         legs["threshold_decrypt"] = roofline("k_combine_fast_g1_arena + k_xor_with_hash", "combine_g1_t3_fast", "combine_g1_t3",
                                              "combine_g1", t, B, dec_kernel_ms, peak, traffic_key="threshold_decrypt")
         # (the hashes take two messages per lane pair from 131 072 messages on: csrc/tc_launch.h kDuoMinHash)
-        hkey = "hash_g1_g2_x2" if B >= 131072 else "hash_g1_g2"
+        hkey = "hash_g1_g2_x2" if hash_x2 else "hash_g1_g2"
         cv_macs = EXECUTED_MACS["verify_g2"] + EXECUTED_MACS[hkey]
         cv_useful = USEFUL_MACS["verify_g2"] + USEFUL_MACS[hkey]
-        legs["ciphertext_verify"] = roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
+        legs["ciphertext_verify"] = roofline(("k_hash_g1_g2_x2" if hash_x2 else "k_hash_g1_g2") + " + k_miller_lines + k_miller_accumulate + k_final_exp", None, "ciphertext_verify", "ciphertext_verify", t, B,
                                              cv_kernel_ms, peak, traffic_key="ciphertext_verify", executed=cv_macs, useful=cv_useful)
         config4 = {"value": round(B * world / (e2 - e0), 1), "unit": "threshold_decryptions/s", "ms_per_step": round((e2 - e0) * 1e3, 3),
                    "is": "BASELINE config 4: Ciphertext::verify (hash_g1_g2 + pairing check) then PublicKeySet::decrypt (G1 combine + "
                          "keystream) over the batch; every plaintext compared with the workload's",
                    "kernel_ms": {"ciphertext_verify": round(cv_kernel_ms, 3), "decrypt": round(dec_kernel_ms, 3)},
-                   "roofline": roofline("k_hash_g1_g2 + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast_g1_arena + k_xor_with_hash", None, None,
+                   "roofline": roofline(("k_hash_g1_g2_x2" if hash_x2 else "k_hash_g1_g2") + " + k_miller_lines + k_miller_accumulate + k_final_exp + k_combine_fast_g1_arena + k_xor_with_hash", None, None,
                                         "ciphertext_verify", t, B, cv_kernel_ms + dec_kernel_ms, peak,
                                         executed=cv_macs + EXECUTED_MACS["combine_g1_t3_fast"], useful=cv_useful + USEFUL_MACS["combine_g1_t3_fast"])}
         _cv, _td = legs["ciphertext_verify"], legs["threshold_decrypt"]
@@ -830,7 +840,8 @@ def run_config2(args, eng, dev, rank, world, peak):
         assert int(wst.to(torch.int32).sum().item()) == 0 and bool((wsig == want).all().item()), "wire-level combine differs from compress(combine)"
         wall, kern = min(wire_ms)
         # (more than 32 768 decodes per call run two points per lane pair: csrc/tc_launch.h kDuoMinDecode, tc_duo.h)
-        dkey = "g2_decompress_x2" if B * (t + 1) > 32768 else "g2_decompress"
+        decode_x2 = B * (t + 1) >= eng.tuning()["duo_min_decode"]
+        dkey = "g2_decompress_x2" if decode_x2 else "g2_decompress"
         wire_macs = (t + 1) * EXECUTED_MACS[dkey] + EXECUTED_MACS["combine_g2_t3_fast"]
         wire_useful = (t + 1) * USEFUL_MACS[dkey] + USEFUL_MACS["combine_g2_t3_fast"]
         wire = {"value": round(B * world / wall, 1), "unit": "combine_signatures/s", "ms_per_step": round(wall * 1e3, 3),
@@ -838,7 +849,7 @@ def run_config2(args, eng, dev, rank, world, peak):
                       "(square root + membership test each), combined, returned as Signature::to_bytes; result compared with "
                       "compress(combine) of the timed batch" % (t + 1),
                 "algorithmic_bytes_per_job": (t + 1) * (96 + 8) + 96,
-                "roofline": roofline("k_decompress_take_g2_x2 + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak, traffic_key="wire",
+                "roofline": roofline(("k_decompress_take_g2_x2" if decode_x2 else "k_decompress_take<Fq2>") + " + k_combine_fast<Fq2> + k_compress<Fq2>", None, None, "combine_g2_wire", t, B, kern, peak, traffic_key="wire",
                                      executed=wire_macs, useful=wire_useful) if t == 3 else None}
         extras["wire_combine_per_s"] = wire["value"]
         if with_cpu:
@@ -999,6 +1010,18 @@ def latency_table(eng):
             lambda j: (c_oracle.ciphertext_verify(bytes(we.u[j]), bytes(we.v[32 * j:32 * j + 32]), bytes(we.w[j])),
                        c_oracle.threshold_decrypt(t, [int(i) for i in we.idx[j]], [bytes(x) for x in we.shares[j]], bytes(we.v[32 * j:32 * j + 32])))),
     }
+    # what one PublicKey::verify at B = 1 ... 64 is made of (could a check spread over a whole wave reach one CPU
+    # core's 3.8 ms?): the three device phases alone, kernel time.  hash_g2 is a chain of Fq2 operations on ONE lane pair (two square-
+    # root exponentiations, the cofactor ladder): no spreading of the PAIRING over more lanes shortens it.
+    for B in (1, 8, 64):
+        m = msgs(B)
+        ph = {"hash_g2": med(lambda: eng.hash_g2(m[0], m[1]))[1],
+              "signature_membership_test": med(lambda: eng.g2_subgroup_check(sig[:B].copy()))[1]}
+        eng.set_input_checks(False)
+        ph["pairing_check_four_lanes_per_check"] = med(lambda: eng.verify_g2(wl.master_pk, sig[:B].copy(), wl.hashes[:B].copy()))[1]
+        eng.set_input_checks(True)
+        print(json.dumps({"entry": "verify phases (kernel ms, each phase alone)", "B": B, **{k: round(v, 3) for k, v in ph.items()},
+                          "sum_ms": round(sum(ph.values()), 3)}), flush=True)
     for name, (gpu, cpu) in entries.items():
         cpu_ms = cpu_time(cpu, 6)
         rows, crossover = [], None

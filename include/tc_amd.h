@@ -101,6 +101,13 @@ int tc_ctx_trim(tc_ctx* ctx);
 /* Bytes this context's own staging copies have moved over PCIe since it was created (host-I/O mode: every operand up,
  * every result down; device-I/O mode: the 8-byte read-back of off[B] per message-taking call and nothing else). */
 int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
+/* The form choices this context makes (no counterpart in the reference: a measurement reports which kernels ran).
+ * out4[0] / out4[1] = jobs from which a checked G2 decode / a hash takes two jobs per lane pair, out4[2] = the pairing form
+ * (0 = by batch size: four lanes per check up to 16 384 checks, the prepared three-kernel form above; 1 quad, 2 lines,
+ * 3 pair, 4 fused), out4[3] = bytes the prepared form's line buffer may take (0 = a third of the free HBM).  The defaults
+ * are the measured thresholds (csrc/tc_launch.h); the environment variables TC_DUO_MIN, TC_PAIRING_FORM,
+ * TC_PAIRING_BUDGET (tests, experiments) are read ONCE, by tc_ctx_create -- never on the launch path. */
+int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out4);
 const char* tc_version(void);
 
 /* ---- hashing onto G2 -------------------------------------------------------------------- */

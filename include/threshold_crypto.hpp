@@ -40,7 +40,8 @@ using FrBytes = std::array<std::uint8_t, 32>;
 // CAVEAT: that is the order of BTreeMap<Fr, _> ONLY.  A caller whose reference code keys the map by i32 / i64
 // iterates NEGATIVE keys first (BTreeMap<i64, _> orders by the signed value), while their field images r - |x| sort after every
 // positive key here; with more than t + 1 shares `take(t + 1)` (src/lib.rs:727-730) would then pick a different subset.  For
-// signed keys use the std::map<std::int64_t, _> overloads below: they iterate by the signed value and convert afterwards.
+// signed keys use the std::map<std::int64_t, _> overloads of combine_signatures AND decrypt below: they iterate by the signed value
+// and convert afterwards.
 struct FrIndex {
   FrBytes le{};
   static FrIndex from_u64(std::uint64_t x) {
@@ -514,8 +515,38 @@ class PublicKeySet {
     out.resize(ct.v.size());
     return out;
   }
+  // the same with `T: IntoFr` keys beyond u64 -- tc_decrypt_fr_batch.  FrIndex keys iterate as BTreeMap<Fr, _> does; std::int64_t
+  // keys by the SIGNED value (negative keys first, as BTreeMap<i64, _>: src/lib.rs:618-626 takes the first t + 1 in THAT order,
+  // src/into_fr.rs:42-56) and become field elements afterwards (combine_signatures had the signed overload, decrypt not).
+  Bytes decrypt(const std::map<FrIndex, DecryptionShare>& shares, const Ciphertext& ct, Engine& e = Engine::instance()) const {
+    std::vector<std::pair<FrIndex, const DecryptionShare*>> ordered;
+    for (const auto& kv : shares) ordered.emplace_back(kv.first, &kv.second);
+    return decrypt_fr(ordered, ct, e);
+  }
+  Bytes decrypt(const std::map<std::int64_t, DecryptionShare>& shares, const Ciphertext& ct, Engine& e = Engine::instance()) const {
+    std::vector<std::pair<FrIndex, const DecryptionShare*>> ordered;
+    for (const auto& kv : shares) ordered.emplace_back(FrIndex::from_i64(kv.first), &kv.second);
+    return decrypt_fr(ordered, ct, e);
+  }
 
  private:
+  Bytes decrypt_fr(const std::vector<std::pair<FrIndex, const DecryptionShare*>>& ordered, const Ciphertext& ct, Engine& e) const {
+    const std::size_t n = ordered.size();
+    std::vector<std::uint8_t> idx(n * 32 + 1), sh(n * 96 + 1);
+    for (std::size_t k = 0; k < n; k++) {
+      std::memcpy(&idx[k * 32], ordered[k].first.le.data(), 32);
+      std::memcpy(&sh[k * 96], ordered[k].second->g1.data(), 96);
+    }
+    Bytes out(ct.v.size() + 1);
+    std::uint64_t off[2] = {0, ct.v.size()};
+    std::uint8_t st = 0;
+    const std::uint8_t dummy = 0;
+    e.check(tc_decrypt_fr_batch(e.ctx(), threshold(), n, idx.data(), sh.data(), ct.v.empty() ? &dummy : ct.v.data(), off, 1,
+                                out.data(), &st));
+    raise_status(st);
+    out.resize(ct.v.size());
+    return out;
+  }
   static void reduce_mod_r(std::array<std::uint64_t, 5>& p) {
     // p < 2^320; subtract r * 2^k while possible (binary long division: r is 255 bits)
     static const std::uint64_t R[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};

@@ -21,3 +21,32 @@ def engine():
     library or device is a hard failure, never a skip or a fallback."""
     from threshold_crypto_amd.engine import Engine
     return Engine(0)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def engine_with_env(**env):
+    """A fresh context created while `env` is in the environment: TC_DUO_MIN / TC_PAIRING_FORM / TC_PAIRING_BUDGET are read ONCE, by
+    tc_ctx_create (csrc/tc_launch.h Tuning), so a test that forces a form builds its own context instead of toggling the variable
+    under a live one.  The environment is restored before the context is used."""
+    from threshold_crypto_amd.engine import Engine
+    saved = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        eng = Engine(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        yield eng
+    finally:
+        eng.close()

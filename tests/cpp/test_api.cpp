@@ -135,6 +135,25 @@ int main(int argc, char** argv) {
     dsh[i] = *d;
   }
   CHECK(pk_set.decrypt(dsh, ct) == plain);
+  {
+    // (round 6) decrypt with `T: IntoFr` keys beyond u64, as combine_signatures above: with t + 2 shares keyed by i64 the
+    // first t + 1 in SIGNED order are {-2^63, -2^40, -1, 7}, so another node's share under key 9 is never looked at; keyed by FrIndex
+    // (the order of BTreeMap<Fr, _>) the first t + 1 start {7, 9, ...} and the same bad share spoils the plaintext.
+    std::map<std::int64_t, DecryptionShare> idsh;
+    std::map<FrIndex, DecryptionShare> fdsh, fbad;
+    for (auto& kv : odd) {
+      auto d = kv.second.decrypt_share(ct);
+      CHECK(d.has_value());
+      fdsh[FrIndex::from_i64(kv.first)] = *d;
+      if (kv.first == 9) d = odd[0].second.decrypt_share(ct);
+      idsh[kv.first] = *d;
+      fbad[FrIndex::from_i64(kv.first)] = *d;
+    }
+    CHECK(idsh.size() == 5 && idsh.begin()->first < 0);
+    CHECK(pk_set.decrypt(fdsh, ct) == plain);
+    CHECK(pk_set.decrypt(idsh, ct) == plain);
+    CHECK(!(pk_set.decrypt(fbad, ct) == plain));
+  }
   Ciphertext fake = ct;
   fake.v[0] ^= 1;
   CHECK(!fake.verify());

@@ -19,7 +19,14 @@ SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(SEED)
 c_oracle.load()
-e = Engine(0)
+# two contexts: the library's own form thresholds, and the TWO-jobs-per-lane-pair forms forced at every size (TC_DUO_MIN is read
+# once, when a context is created: csrc/tc_launch.h Tuning)
+e_default = Engine(0)
+os.environ["TC_DUO_MIN"] = "1"
+e_duo = Engine(0)
+os.environ.pop("TC_DUO_MIN")
+assert e_duo.tuning()["duo_min_hash"] == 1 and e_default.tuning()["duo_min_hash"] == 131072
+e = e_default
 
 
 def u8(b):
@@ -61,12 +68,12 @@ while time.time() < t_end:
     rounds += 1
     B = rnd.choice([1, 2, 31, 32, 33, 63, 64, 65, 97, 130])
     # r05: every other round runs the TWO-jobs-per-lane-pair forms of the checked G2 decode and the G2 hashes (csrc/tc_duo.h), which
-    # the library picks from 32 769 / 131 072 jobs on by itself: TC_DUO_MIN is read at every launch (csrc/tc_launch.h duo_form)
+    # the library picks from 32 769 / 131 072 jobs on by itself: those rounds go through the context created with TC_DUO_MIN=1
     if rnd.randrange(2):
-        os.environ["TC_DUO_MIN"] = "1"
+        e = e_duo
         duo_rounds += 1
     else:
-        os.environ.pop("TC_DUO_MIN", None)
+        e = e_default
     # ---- scalar multiplication (S signers x B points) -------------------------------------------
     S = rnd.choice([1, 2, 3])
     ks = [rnd.choice([0, 1, o.R - 1, rnd.randrange(o.R), rnd.randrange(1 << 64)]) for _ in range(S)]

@@ -376,7 +376,7 @@ def test_g1_combination_grouped_by_class_equals_ungrouped(engine):
 def test_two_jobs_per_lane_pair_forms_equal_the_one_job_forms(engine, rnd):
     """r05 (tc_duo.h): from 65 536 jobs on the checked G2 decode (from_bytes, /root/reference/src/lib.rs:246-252), hash_g2
     (:691-694) and hash_g1_g2 (:697-707) give a lane pair TWO jobs and run each job's Fq-only phases on one lane.  Forced on
-    and off (TC_DUO_MIN, read at every launch) over the SAME odd-sized batches -- members, the identity, points outside G2, x
+    and off (TC_DUO_MIN, read when a context is created: one context per form) over the SAME odd-sized batches -- members, the identity, points outside G2, x
     without a point, x >= q, flag errors in either slot of a pair; ragged messages on both sides of the SHA3 rate and of the
     64-byte switch; undecodable G1 operands -- both forms must return identical bytes and statuses, and a sample of them is
     recomputed by Oracle A here.  (The full-size tests run the two-job form against Oracle B on every job.)"""
@@ -421,19 +421,15 @@ def test_two_jobs_per_lane_pair_forms_equal_the_one_job_forms(engine, rnd):
     g1_a = np.frombuffer(b"".join(g1rows), np.uint8).reshape(n, 96).copy()
     blob, off = pack_messages(msgs)
     res = {}
-    saved = os.environ.get("TC_DUO_MIN")
-    try:
-        for form, minimum in (("two", "1"), ("one", str(10 ** 12))):
-            os.environ["TC_DUO_MIN"] = minimum  # read by the library at every launch (tc_launch.h duo_form)
-            pts, st = engine.g2_decompress(enc_a)
-            h = engine.hash_g2(blob, off)
-            hg, hst = engine.hash_g1_g2(g1_a, blob, off)
+    from conftest import engine_with_env
+    for form, minimum in (("two", 1), ("one", 10 ** 12)):
+        with engine_with_env(TC_DUO_MIN=minimum) as eng:    # read once, when the context is created (tc_launch.h Tuning)
+            assert eng.tuning()["duo_min_hash"] == eng.tuning()["duo_min_decode"] == minimum
+            pts, st = eng.g2_decompress(enc_a)
+            h = eng.hash_g2(blob, off)
+            hg, hst = eng.hash_g1_g2(g1_a, blob, off)
             res[form] = (pts, st, h, hg, hst)
-    finally:
-        if saved is None:
-            os.environ.pop("TC_DUO_MIN", None)
-        else:
-            os.environ["TC_DUO_MIN"] = saved
+    assert engine.tuning() == {"duo_min_decode": 32769, "duo_min_hash": 131072, "pairing_form": 0, "pairing_budget": 0}   # the defaults
     for x, y in zip(res["two"], res["one"]):
         assert (x == y).all(), np.flatnonzero((x != y).reshape(n, -1).any(axis=1))[:16]
     pts, st, h, hg, hst = res["two"]
@@ -464,22 +460,18 @@ def test_hashes_above_the_two_message_threshold_equal_the_one_message_form(engin
     n = 131073
     msgs = [b"tc/duo/%d" % i + bytes(i % 5) for i in range(n)]
     blob, off = pack_messages(msgs)
-    saved = os.environ.pop("TC_DUO_MIN", None)
-    try:
-        own = engine.hash_g2(blob, off)
-        os.environ["TC_DUO_MIN"] = str(10 ** 12)
-        one = engine.hash_g2(blob, off)
-        assert (own == one).all()
-        for j in [0, 1, 65535, 65536, 131071, 131072] + [rnd.randrange(n) for _ in range(10)]:
-            assert bytes(own[j]) == c.hash_g2(msgs[j])
-        pts = [o.g2_compressed(o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))) for _ in range(16)] + [o.g2_compressed(None)]
-        enc = np.frombuffer(b"".join(pts[rnd.randrange(len(pts))] for _ in range(32769)), np.uint8).reshape(32769, 96).copy()
-        enc[777, 5] ^= 0x40                                    # one undecodable encoding (with overwhelming probability)
-        one_p, one_s = engine.g2_decompress(enc)
-        os.environ.pop("TC_DUO_MIN")
-        own_p, own_s = engine.g2_decompress(enc)
-        assert (own_p == one_p).all() and (own_s == one_s).all() and int(own_s.sum()) in (0, 3)
-    finally:
-        os.environ.pop("TC_DUO_MIN", None)
-        if saved is not None:
-            os.environ["TC_DUO_MIN"] = saved
+    from conftest import engine_with_env
+    pts = [o.g2_compressed(o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))) for _ in range(16)] + [o.g2_compressed(None)]
+    enc = np.frombuffer(b"".join(pts[rnd.randrange(len(pts))] for _ in range(32769)), np.uint8).reshape(32769, 96).copy()
+    enc[777, 5] ^= 0x40                                    # one undecodable encoding (with overwhelming probability)
+    with engine_with_env(TC_DUO_MIN=None) as own_eng:      # the library's own thresholds
+        assert own_eng.tuning()["duo_min_hash"] == 131072 and own_eng.tuning()["duo_min_decode"] == 32769
+        own = own_eng.hash_g2(blob, off)
+        own_p, own_s = own_eng.g2_decompress(enc)
+    with engine_with_env(TC_DUO_MIN=10 ** 12) as one_eng:  # the one-job form forced
+        one = one_eng.hash_g2(blob, off)
+        one_p, one_s = one_eng.g2_decompress(enc)
+    assert (own == one).all()
+    for j in [0, 1, 65535, 65536, 131071, 131072] + [rnd.randrange(n) for _ in range(10)]:
+        assert bytes(own[j]) == c.hash_g2(msgs[j])
+    assert (own_p == one_p).all() and (own_s == one_s).all() and int(own_s.sum()) in (0, 3)

@@ -70,7 +70,7 @@ PROTOTYPES = {
 
 CONTEXT_SYMBOLS = ["tc_ctx_create", "tc_ctx_destroy", "tc_ctx_set_device_io", "tc_ctx_set_stream", "tc_sync",
                    "tc_last_error", "tc_ctx_set_timing", "tc_last_kernel_ms", "tc_version", "tc_ctx_set_input_checks",
-                   "tc_ctx_get_input_checks", "tc_ctx_transfer_bytes", "tc_ctx_trim", "tc_ctx_get_device_io"]
+                   "tc_ctx_get_input_checks", "tc_ctx_transfer_bytes", "tc_ctx_trim", "tc_ctx_get_device_io", "tc_ctx_get_tuning"]
 
 # the multi-GPU surface (tc_group_*): name -> (restype, argtypes); the group handle is an opaque pointer
 _grp = ctypes.c_void_p
@@ -136,6 +136,8 @@ def load():
     lib.tc_ctx_get_input_checks.restype = ctypes.c_int
     lib.tc_ctx_get_device_io.argtypes = [_ctx]
     lib.tc_ctx_get_device_io.restype = ctypes.c_int
+    lib.tc_ctx_get_tuning.argtypes = [_ctx, ctypes.POINTER(ctypes.c_uint64)]
+    lib.tc_ctx_get_tuning.restype = ctypes.c_int
     lib.tc_ctx_transfer_bytes.argtypes = [_ctx, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.tc_ctx_transfer_bytes.restype = ctypes.c_int
     lib.tc_last_kernel_ms.argtypes = [_ctx]

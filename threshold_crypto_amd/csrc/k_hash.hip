@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g1_g2(const uint8_
   if (status && pair_leader()) status[j] = st;
 }
 
-// batches from 65 536 messages on: a lane pair takes TWO messages (tc_duo.h) -- pair p hashes messages 2p and 2p + 1
+// batches from 131 072 messages on (tc_launch.h kDuoMinHash): a lane pair takes TWO messages (tc_duo.h) -- pair p hashes messages 2p and 2p + 1
 __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_hash_g2_x2(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
                                                                  size_t B, uint8_t* __restrict__ out, int fix) {
   const size_t p = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kG2Lanes;
@@ -91,15 +91,15 @@ void launch_commitment_evaluate(hipStream_t st, const uint8_t* commit, size_t t,
                                 uint8_t* status) {
   if (M) hipLaunchKernelGGL(k_commitment_evaluate, dim3(grid_for(M)), dim3(kBlock), 0, st, commit, t, idx, M, out, status);
 }
-void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix) {
+void launch_hash_g2(const Tuning& tn, hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix) {
   if (!B) return;
-  if (duo_form(B, kDuoMinHash)) hipLaunchKernelGGL(k_hash_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
+  if (duo_form(B, tn.duo_min_hash)) hipLaunchKernelGGL(k_hash_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
   else hipLaunchKernelGGL(k_hash_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, msgs, off, B, out, fix ? 1 : 0);
 }
-void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
+void launch_hash_g1_g2(const Tuning& tn, hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
                        uint8_t* out, uint8_t* status, bool fix) {
   if (!B) return;
-  if (duo_form(B, kDuoMinHash)) hipLaunchKernelGGL(k_hash_g1_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
+  if (duo_form(B, tn.duo_min_hash)) hipLaunchKernelGGL(k_hash_g1_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
   else hipLaunchKernelGGL(k_hash_g1_g2, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, g1, msgs, off, B, out, status, fix ? 1 : 0);
 }
 void launch_xor_with_hash(hipStream_t st, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,

@@ -206,15 +206,15 @@ void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* ou
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (B) hipLaunchKernelGGL(k_decompress<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, in, B, out, status);
 }
-void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
+void launch_g2_decompress(const Tuning& tn, hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status) {
   if (!B) return;
-  if (duo_form(B, kDuoMinDecode)) hipLaunchKernelGGL(k_decompress_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
+  if (duo_form(B, tn.duo_min_decode)) hipLaunchKernelGGL(k_decompress_g2_x2, dim3(grid_for((B + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
   else hipLaunchKernelGGL(k_decompress<Fq2>, dim3(grid_for(B * kG2Lanes)), dim3(kBlock), 0, st, in, B, out, status);
 }
-void launch_decompress_take(hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid) {
+void launch_decompress_take(const Tuning& tn, hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid) {
   const size_t n = B * take;
   if (!n) return;
-  if (g2 && duo_form(n, kDuoMinDecode)) hipLaunchKernelGGL(k_decompress_take_g2_x2, dim3(grid_for((n + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
+  if (g2 && duo_form(n, tn.duo_min_decode)) hipLaunchKernelGGL(k_decompress_take_g2_x2, dim3(grid_for((n + 1) / 2 * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
   else if (g2) hipLaunchKernelGGL(k_decompress_take<Fq2>, dim3(grid_for(n * kG2Lanes)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
   else hipLaunchKernelGGL(k_decompress_take<Fq>, dim3(grid_for(n)), dim3(kBlock), 0, st, in, n_per_job, take, n, out, valid);
 }

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_quad(const uint
   if (live && (threadIdx.x & (kQuadLanes - 1)) == 0) ok[j] = r;
 }
 
-// Which form runs (TC_PAIRING_FORM = quad | lines | pair | fused overrides the choice for experiments):
+// Which form runs (Tuning::pairing_form, from TC_PAIRING_FORM = quad | lines | pair | fused when the context was created, overrides
+// the choice for experiments):
 //   four lanes per check (k_pairing_quad) up to kQuadMaxBatch checks -- the batch alone cannot give every SIMD two waves of
 //     the lane-pair kernels, and a check finishes in about 0.6 of the time (6.9 instead of 10.9 ms at 4 096 checks, 8.5
 //     instead of 11.4 ms at 16 384: profiles/r03_pairing_forms.txt);
@@ -150,14 +151,11 @@ __global__ __launch_bounds__(kBlock, TC_WAVES_G2) void k_pairing_quad(const uint
 //   `pair` = r03's k_miller_loop + k_final_exp, `fused` = r02's single kernel.
 constexpr size_t kQuadMaxBatch = 16384;
 enum PairingForm { kFormQuad, kFormLines, kFormPair, kFormFused };
-static PairingForm pairing_form(size_t B) {
-  static const char* form = getenv("TC_PAIRING_FORM");
-  if (form && form[0] == 'q') return kFormQuad;
-  if (form && form[0] == 'l') return kFormLines;
-  if (form && form[0] == 'p') return kFormPair;
-  if (form && form[0] == 'f') return kFormFused;
+int pairing_form(size_t B, const Tuning& tn) {
+  if (tn.pairing_form >= 1 && tn.pairing_form <= 4) return tn.pairing_form - 1;
   return B <= kQuadMaxBatch ? kFormQuad : kFormLines;
 }
+bool pairing_form_needs_lines(int form) { return form == kFormLines; }
 // checks per pass of the prepared form: its line buffer (kLineWords = 552 x 14 words per lane: 61.8 KB per check, 4.05 GB for
 // 65 536 checks) is sized for one tile, larger batches run tile by tile.  The tile shrinks to what the caller's budget holds
 // (a third of the free HBM: several contexts on one GPU, a smaller card), in whole rounds of 2 048 waves down to 16 384
@@ -165,7 +163,6 @@ static PairingForm pairing_form(size_t B) {
 constexpr size_t kPreparedTile = 65536;
 constexpr size_t kPreparedMinTile = 16384;
 size_t pairing_tile(size_t B, size_t budget_bytes) {
-  if (pairing_form(B) != kFormLines) return 0;
   const size_t per_check = (size_t)kG2Lanes * kLineWords * sizeof(int32_t);
   size_t tile = kPreparedTile;
   while (tile > kPreparedMinTile && tile * per_check > budget_bytes) tile /= 2;
@@ -180,7 +177,7 @@ void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uin
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, PairingWs pws) {
   if (!B) return;
   int32_t* ws = pws.p;
-  PairingForm form = pairing_form(B);
+  int form = pws.form;
   if (form == kFormLines && !pws.tile) form = kFormPair;  // no room for the line buffer
   if (form == kFormQuad) {
     hipLaunchKernelGGL(k_pairing_quad, dim3(grid_for(B * kQuadLanes)), dim3(kBlock), 0, st, a, sa, b, sb, c, sc, d, sd, B, ok);

@@ -44,6 +44,7 @@ struct tc_ctx {
   uint32_t* tbl_flags = nullptr;
   bool tbl_reset = false;  // a call failed: a kernel may have died holding slots, clear the flags before the next use
   int cus = 0;
+  tc::Tuning tuning;  // form choices, fixed when the context is created (tc_launch.h)
   uint64_t h2d_bytes = 0, d2h_bytes = 0;  // bytes this context's staging copies moved over PCIe (tc_ctx_transfer_bytes)
 };
 
@@ -239,10 +240,25 @@ size_t msm_table_budget(Call& k) {
   if (b < ((size_t)1 << 30)) b = (size_t)1 << 30;
   return b;
 }
+// What the line buffer of the prepared pairing form may take: a third of the HBM that is free right now (plus the context's own
+// staging slots), at most 24 GiB -- and NO floor (the smallest tile's buffer is 1.013 GB, just under msm_table_budget's
+// 1 GiB floor, so with the floor a card with less than that free still tried the allocation and failed; without it pairing_tile
+// answers 0 and the one-loop form, which needs no line buffer, runs).
+size_t pairing_line_budget(Call& k) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  size_t held = 0;
+  for (auto& s : k.c->slots) held += s.cap;
+  const size_t b = (free_b + held) / 3;
+  return b > kMsmTableBudget ? kMsmTableBudget : b;
+}
 tc::PairingWs Call::pairing_ws(size_t B) {
-  static const char* cap = getenv("TC_PAIRING_BUDGET");  // experiments / tests: bytes the line buffer may take
-  const size_t tile = tc::pairing_tile(B, cap ? (size_t)strtoull(cap, nullptr, 10) : msm_table_budget(*this));
-  return tc::PairingWs{temp<int32_t>(tc::pairing_ws_words(B, tile)), tile};
+  const tc::Tuning& tn = c->tuning;
+  const int form = tc::pairing_form(B, tn);
+  // (the budget -- hipMemGetInfo and a walk over the slots -- is only looked up by the form that has a line buffer: small
+  // batches, which run the four-lane form, pay nothing for it)
+  const size_t tile = tc::pairing_form_needs_lines(form) ? tc::pairing_tile(B, tn.pairing_budget ? tn.pairing_budget : pairing_line_budget(*this)) : 0;
+  return tc::PairingWs{temp<int32_t>(tc::pairing_ws_words(B, tile)), tile, form};
 }
 void msm_g2(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const uint32_t* d_scalars, size_t B, uint8_t* d_out,
             uint8_t* d_st, int nbits = 64, tc::MsmFilter filter = tc::MsmFilter(), bool secret_scalars = false) {
@@ -282,6 +298,15 @@ void msm_g1(Call& k, size_t n, size_t pts_stride, const uint8_t* d_pts, const ui
   }
 }
 
+// TC_DUO_MIN / TC_PAIRING_FORM / TC_PAIRING_BUDGET (tests, experiments): read here, once per context, never on the launch path
+tc::Tuning tuning_from_env() {
+  tc::Tuning tn;
+  if (const char* e = getenv("TC_DUO_MIN")) tn.duo_min_decode = tn.duo_min_hash = (size_t)strtoull(e, nullptr, 10);
+  if (const char* f = getenv("TC_PAIRING_FORM")) tn.pairing_form = f[0] == 'q' ? 1 : f[0] == 'l' ? 2 : f[0] == 'p' ? 3 : f[0] == 'f' ? 4 : 0;
+  if (const char* b = getenv("TC_PAIRING_BUDGET")) tn.pairing_budget = (size_t)strtoull(b, nullptr, 10);
+  return tn;
+}
+
 #define TC_REQUIRE(cond)            \
   do {                              \
     if (!(cond)) {                  \
@@ -305,6 +330,7 @@ int tc_ctx_create(tc_ctx** out, int device) {
   if (hipSetDevice(device) != hipSuccess) return TC_ERR_HIP;
   tc_ctx* c = new tc_ctx();
   c->device = device;
+  c->tuning = tuning_from_env();
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipMalloc((void**)&c->g1_gen, 96) != hipSuccess || hipMalloc((void**)&c->g1_gen_unfix, 96) != hipSuccess) {
@@ -379,6 +405,14 @@ int tc_ctx_trim(tc_ctx* ctx) {
 
 int tc_ctx_get_input_checks(const tc_ctx* ctx) { return (ctx && ctx->input_checks) ? 1 : 0; }
 int tc_ctx_get_device_io(const tc_ctx* ctx) { return (ctx && ctx->device_io) ? 1 : 0; }
+int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out4) {
+  if (!ctx || !out4) return TC_ERR_INVALID_ARG;
+  out4[0] = ctx->tuning.duo_min_decode;
+  out4[1] = ctx->tuning.duo_min_hash;
+  out4[2] = (uint64_t)ctx->tuning.pairing_form;
+  out4[3] = ctx->tuning.pairing_budget;
+  return TC_OK;
+}
 
 int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
   if (!ctx) return TC_ERR_INVALID_ARG;
@@ -416,7 +450,7 @@ int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size
   const uint64_t* d_off = k.in(off, B + 1);
   uint8_t* d_out = k.out(out_g2, B * 192);
   k.begin_timing();
-  if (!k.failed) tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_out);
+  if (!k.failed) tc::launch_hash_g2(ctx->tuning, ctx->stream, d_msgs, d_off, B, d_out);
   k.end_timing();
   return k.finish();
 }
@@ -437,7 +471,7 @@ int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, con
   uint8_t* d_st = k.out(status, B);
   k.begin_timing();
   k.check_points(false, d_g1, 96, 1, 1, B, 1);
-  if (!k.failed) tc::launch_hash_g1_g2(ctx->stream, d_g1, d_msgs, d_off, B, d_out, d_st);
+  if (!k.failed) tc::launch_hash_g1_g2(ctx->tuning, ctx->stream, d_g1, d_msgs, d_off, B, d_out, d_st);
   k.apply_checks(B, d_st, d_out, 192, nullptr);
   k.end_timing();
   return k.finish();
@@ -532,7 +566,7 @@ int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uin
   k.begin_timing();
   if (!k.failed) {
     // sk * hash_g2(m) = (sk c) * Q': the hash skips its last constant multiplication, the scalars carry it
-    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
+    tc::launch_hash_g2(ctx->tuning, ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     tc::launch_fr_scale_cofactor_fix(ctx->stream, d_fr, S, d_frc);
     tc::launch_g2_mul(ctx->stream, k.tables(), d_frc, d_hash, S, B, d_out, d_st);
   }
@@ -663,7 +697,7 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
     uint8_t* d_dec = k.temp<uint8_t>(B * (t + 1) * PB);
     uint8_t* d_valid = k.temp<uint8_t>(B * (t + 1));
     if (!k.failed) {
-      tc::launch_decompress_take(ctx->stream, g2, d_sh, n, t + 1, B, d_dec, d_valid);
+      tc::launch_decompress_take(ctx->tuning, ctx->stream, g2, d_sh, n, t + 1, B, d_dec, d_valid);
       k.checks.push_back({d_valid, t + 1, 1});
       if (d_idx_fr) {
         uint32_t* d_fr2 = k.temp<uint32_t>(B * (t + 1) * 8);
@@ -873,7 +907,7 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
   if (!k.failed) {
     // e(pk, [c] Q') == e(g1, sig)  <=>  e(pk, Q') == e([1/c] g1, sig): the hash skips its last constant
     // multiplication and the generator side uses the context's pre-scaled generator
-    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
+    tc::launch_hash_g2(ctx->tuning, ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     tc::launch_pairing_check(ctx->stream, d_pk, pk_stride, d_hash, 192, ctx->g1_gen_unfix, 0, d_sig, 192, B, d_ok, k.pairing_ws(B));
   }
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
@@ -926,7 +960,7 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
     k.check(hipMemsetAsync(d_stS, 0, B, ctx->stream), "memset");
     msm_g2(k, N, N * 192, d_sig, reinterpret_cast<const uint32_t*>(d_r), B, d_S, d_stS, /*nbits=*/16, tc::MsmFilter(), /*secret_scalars=*/true);
     tc::launch_lincomb_g1(ctx->stream, N, d_r, d_pk, B, d_P, nullptr, /*shared_points=*/true);
-    tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
+    tc::launch_hash_g2(ctx->tuning, ctx->stream, d_msgs, d_off, B, d_hash, /*fix=*/false);
     // e(P, [c] Q') == e(g1, S)  <=>  e(P, Q') == e([1/c] g1, S)   (the folded hash constant of tc_verify_sig_batch)
     tc::launch_pairing_check(ctx->stream, d_P, 96, d_hash, 192, ctx->g1_gen_unfix, 0, d_S, 192, B, d_okmsg, k.pairing_ws(B));
     // a share that does not decode (status below) or, in checked-input mode, is no group member sends its
@@ -1034,7 +1068,7 @@ static int verify_rlc(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const 
   if (hash) k.check_points(true, d_hash, 192, 1, 1, B, 1);
   std::vector<uint8_t> h_okg(NG), h_st(2 * NG), h_valid;
   if (!k.failed) {
-    if (!hash) tc::launch_hash_g2(ctx->stream, d_msgs, d_off, B, d_hash_own, /*fix=*/false);
+    if (!hash) tc::launch_hash_g2(ctx->tuning, ctx->stream, d_msgs, d_off, B, d_hash_own, /*fix=*/false);
     tc::launch_rlc_scalars(ctx->stream, d_seed, B, d_r);
     k.check(hipMemsetAsync(d_st, 0, 2 * NG, ctx->stream), "memset");
     const uint32_t* rr = reinterpret_cast<const uint32_t*>(d_r);
@@ -1149,7 +1183,7 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
   k.check_points(true, d_w, 192, 1, 1, B, 1);
   if (!k.failed) {
     // an undecodable u leaves an infinity hash; the pairing kernel then rejects u itself
-    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
+    tc::launch_hash_g1_g2(ctx->tuning, ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
     // e(g1, w) == e(u, [c] Q')  <=>  e([1/c] g1, w) == e(u, Q')         (src/lib.rs:511)
     tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok, k.pairing_ws(B));
   }
@@ -1187,7 +1221,7 @@ static int verified_decrypt(tc_ctx* ctx, const uint8_t* sk, const uint8_t* u, co
   k.check_points(false, d_u, 96, 1, 1, B, 1, /*always=*/true);
   k.check_points(true, d_w, 192, 1, 1, B, 1, /*always=*/true);
   if (!k.failed) {
-    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
+    tc::launch_hash_g1_g2(ctx->tuning, ctx->stream, d_u, d_v, d_off, B, d_hash, nullptr, /*fix=*/false);
     tc::launch_pairing_check(ctx->stream, ctx->g1_gen_unfix, 0, d_w, 192, d_u, 96, d_hash, 192, B, d_ok, k.pairing_ws(B));  // src/lib.rs:511
     k.apply_checks(B, nullptr, nullptr, 0, d_ok);
     tc::launch_g1_mul(ctx->stream, k.tables(), d_sk, d_u, 1, B, d_pt, d_st);
@@ -1241,7 +1275,7 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
   k.check_points(false, d_u, 96, 1, 1, B, 1);
   k.check_points(true, d_w, 192, 1, 1, B, 1);
   if (!k.failed) {
-    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st, /*fix=*/false);
+    tc::launch_hash_g1_g2(ctx->tuning, ctx->stream, d_u, d_v, d_off, B, d_hash, d_st, /*fix=*/false);
     tc::launch_g1_scale_cofactor_fix(ctx->stream, d_share, 96, B, d_sharec);
     // e(share, hash) = e([c] share, Q') == e(pk_share, w)               (src/lib.rs:185)
     tc::launch_pairing_check(ctx->stream, d_sharec, 96, d_hash, 192, d_pk, pk_stride, d_w, 192, B, d_ok, k.pairing_ws(B));
@@ -1302,7 +1336,7 @@ int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares,
     const uint32_t* rr = reinterpret_cast<const uint32_t*>(d_r);
     msm_g1(k, N, N * 96, d_sh, rr, B, d_D, d_st, /*nbits=*/32, /*secret_scalars=*/true);
     msm_g1(k, N, 0, d_pk, rr, B, d_P, d_st + B, 32, true);   // the N key shares are the same for every ciphertext: one table set
-    tc::launch_hash_g1_g2(ctx->stream, d_u, d_v, d_off, B, d_hash, d_st + 2 * B, /*fix=*/false);
+    tc::launch_hash_g1_g2(ctx->tuning, ctx->stream, d_u, d_v, d_off, B, d_hash, d_st + 2 * B, /*fix=*/false);
     tc::launch_g1_scale_cofactor_fix(ctx->stream, d_D, 96, B, d_Dc);
     // e(D, [c] Q') = e([c] D, Q') == e(P, w)      (the folded hash constant of tc_verify_decryption_share_batch)
     tc::launch_pairing_check(ctx->stream, d_Dc, 96, d_hash, 192, d_P, 96, d_w, 192, B, d_okct, k.pairing_ws(B));
@@ -1559,7 +1593,7 @@ int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* 
   uint8_t* d_out = k.out(out192, B * 192);
   uint8_t* d_st = k.out(status, B);
   k.begin_timing();
-  if (!k.failed) tc::launch_g2_decompress(ctx->stream, d_in, B, d_out, d_st);
+  if (!k.failed) tc::launch_g2_decompress(ctx->tuning, ctx->stream, d_in, B, d_out, d_st);
   k.end_timing();
   return k.finish();
 }

@@ -36,13 +36,19 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 // A third of a decode is Fq-only work (two exponentiations), so it wins as soon as the one-job form needs a second wave on any
 // SIMD (more than 32 768 points); a hash has 24 % of it and a search loop that runs until the slowest of 64 instead of 32
 // messages has its candidate, so it only wins with two waves per SIMD in the halved form (131 072 messages).
-// TC_DUO_MIN=<jobs> overrides both (tests, experiments); read at every launch.
 constexpr size_t kDuoMinDecode = 32768 + 1;
 constexpr size_t kDuoMinHash = 131072;
-inline bool duo_form(size_t jobs, size_t min_jobs) {
-  const char* e = getenv("TC_DUO_MIN");
-  return jobs >= (e ? (size_t)strtoull(e, nullptr, 10) : min_jobs);
-}
+inline bool duo_form(size_t jobs, size_t min_jobs) { return jobs >= min_jobs; }
+
+// The form choices of a context.  The defaults are the measured thresholds above / in k_pairing.hip; the environment
+// (TC_DUO_MIN=<jobs>, TC_PAIRING_FORM=quad|lines|pair|fused, TC_PAIRING_BUDGET=<bytes>: tests and experiments) is read ONCE,
+// when the context is created (tc_api.hip tuning_from_env) -- no getenv on the launch path, nothing a concurrent setenv can race
+// with -- and tc_ctx_get_tuning reports what a context uses.
+struct Tuning {
+  size_t duo_min_decode = kDuoMinDecode, duo_min_hash = kDuoMinHash;
+  int pairing_form = 0;       // 0 = by batch size; 1 quad, 2 lines (prepared), 3 pair (one loop), 4 fused
+  size_t pairing_budget = 0;  // bytes the prepared form's line buffer may take; 0 = a third of the HBM that is free
+};
 
 // The G1 ladder kernels keep their per-lane table in the HBM arena and fit 256 registers (two waves per SIMD) at
 // EVERY batch size since the end of r04: the register-table builds they replaced (377 registers + 121 AGPRs, 7 KB of scratch per
@@ -79,10 +85,10 @@ void launch_comb_sign(hipStream_t st, TableArena ta, const uint8_t* sk, size_t N
 void launch_g1_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g2_compress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 void launch_g1_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
-void launch_g2_decompress(hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
+void launch_g2_decompress(const Tuning& tn, hipStream_t st, const uint8_t* in, size_t B, uint8_t* out, uint8_t* status);
 // wire ingest of the combiners: the first `take` of n_per_job compressed samples per job, checked decode, compact output
 // (B x take points) + one validity byte per sample; and the matching prefix of the index array
-void launch_decompress_take(hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid);
+void launch_decompress_take(const Tuning& tn, hipStream_t st, bool g2, const uint8_t* in, size_t n_per_job, size_t take, size_t B, uint8_t* out, uint8_t* valid);
 void launch_take_u64(hipStream_t st, const uint64_t* in, size_t n_per_job, size_t take, size_t B, uint64_t* out);
 
 // need_general: one zeroed device word; the Lagrange stage counts the jobs the small-index fast path
@@ -166,8 +172,11 @@ void launch_invalidate_jobs(hipStream_t st, const uint8_t* valid, size_t per_job
 struct PairingWs {
   int32_t* p;
   size_t tile;
+  int form;  // pairing_form's choice for this batch (a PairingForm of k_pairing.hip)
 };
-size_t pairing_tile(size_t B, size_t budget_bytes);   // 0 = the line buffer does not fit: the one-loop form runs
+int pairing_form(size_t B, const Tuning& tn);          // which kernels run a batch of B checks
+bool pairing_form_needs_lines(int form);               // the prepared form: the only one with a line buffer
+size_t pairing_tile(size_t B, size_t budget_bytes);    // checks per pass of the prepared form; 0 = the line buffer does not fit
 size_t pairing_ws_words(size_t B, size_t tile);
 void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok, PairingWs ws);
@@ -175,8 +184,8 @@ void launch_pairing_check(hipStream_t st, const uint8_t* a, size_t sa, const uin
 // fix = false: the hash point WITHOUT its last constant multiplication (tc_gls.h g2_clear_cofactor); the
 // caller folds the constant into a scalar (launch_fr_scale_cofactor_fix) or a G1 operand
 // (launch_g1_scale_cofactor_fix)
-void launch_hash_g2(hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix = true);
-void launch_hash_g1_g2(hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
+void launch_hash_g2(const Tuning& tn, hipStream_t st, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out, bool fix = true);
+void launch_hash_g1_g2(const Tuning& tn, hipStream_t st, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
                        uint8_t* out, uint8_t* status, bool fix = true);
 void launch_fr_scale_cofactor_fix(hipStream_t st, const uint8_t* fr, size_t S, uint8_t* out);
 void launch_g1_scale_cofactor_fix(hipStream_t st, const uint8_t* in, size_t stride, size_t n, uint8_t* out);

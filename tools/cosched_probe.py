@@ -17,8 +17,12 @@ from threshold_crypto_amd.engine import Engine, pack_messages
 from threshold_crypto_amd.workload import ThresholdSigWorkload
 
 dev = torch.device("cuda", 0)
-a, b = Engine(0), Engine(0)
-for e in (a, b):
+# TC_DUO_MIN is read when a context is created: one hashing context per form, one context for the pairing work
+os.environ["TC_DUO_MIN"] = str(10 ** 12); a1 = Engine(0)
+os.environ["TC_DUO_MIN"] = "1"; a2 = Engine(0)
+os.environ.pop("TC_DUO_MIN"); b = Engine(0)
+a = a1
+for e in (a1, a2, b):
     e.set_timing(False); e.set_input_checks(False)
 for B in (65536, 131072):
     wl = ThresholdSigWorkload(a, 3, 10, B)
@@ -28,10 +32,10 @@ for B in (65536, 131072):
     d_msgs, d_off = torch.from_numpy(wl.msg_flat).to(dev), torch.from_numpy(wl.msg_off.view(np.int64)).to(dev)
 
     def sync():
-        a.sync(); b.sync(); torch.cuda.synchronize()
+        a1.sync(); a2.sync(); b.sync(); torch.cuda.synchronize()
 
     def run(form, overlapped, reps=5):
-        os.environ["TC_DUO_MIN"] = "1" if form == "x2" else str(10 ** 12)
+        a = a2 if form == "x2" else a1
         best, outs = 1e9, None
         for _ in range(reps + 1):
             sync(); t0 = time.perf_counter()
@@ -50,8 +54,8 @@ for B in (65536, 131072):
             sync(); t0 = time.perf_counter(); fn(); eng.sync(); best = min(best, time.perf_counter() - t0)
         return best * 1e3
 
-    os.environ["TC_DUO_MIN"] = str(10 ** 12); h1 = alone(lambda: a.hash_g2(d_msgs, d_off), a)
-    os.environ["TC_DUO_MIN"] = "1"; h2 = alone(lambda: a.hash_g2(d_msgs, d_off), a)
+    h1 = alone(lambda: a1.hash_g2(d_msgs, d_off), a1)
+    h2 = alone(lambda: a2.hash_g2(d_msgs, d_off), a2)
     v = alone(lambda: b.verify_g2(d_pk, d_sig, d_hash), b)
     seq1, seq2 = run("single", False), run("x2", False)
     co1, co2 = run("single", True), run("x2", True)
