@@ -233,7 +233,7 @@ def parse_args(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the `sustained` leg of config 2 (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (general path, configs 3 and 4, PCIe-inclusive rate)")
     ap.add_argument("--profile-run", action="store_true",
-                    help="for rocprofv3 captures of the whole line (tools/capture_r04.sh; r05 captures one leg at a time, tools/profile_legs.py): skip the legs that launch the headline kernels on OTHER work "
+                    help="for rocprofv3 captures of the whole line (r04's captures; since r05 one leg at a time: tools/capture_legs.sh, tools/profile_legs.py): skip the legs that launch the headline kernels on OTHER work "
                          "(general-path and checked-input combines), so that a kernel's per-launch averages describe one kind of launch")
     ap.add_argument("--latency-table", action="store_true",
                     help="instead of the bench line: call latency (host buffers in, results back) of sign / combine / verify / decrypt at "

@@ -134,17 +134,18 @@ def test_config5_two_rank_gloo_pipeline_sharding_broadcast_gather():
         assert eng.L.hs_g2_mul(msk, bytes(single["hashes"][j]), b) == 0 and b.raw == single["sig"][j].tobytes()
 
 
-R05_TAG = "r05_c"   # the capture (tools/capture_r05.sh) committed with the shipped library: profiles/README.md
+R05_TAG = "r05_c"   # round 5's capture (then tools/capture_r05.sh)
+R06_TAG = "r06_c"   # the capture (tools/capture_legs.sh) committed with the SHIPPED library: profiles/README.md, profile_constants.json
 
 
-def _check_round5_lines(root, macs):
-    """round 5: every roofline object of the line carries `traffic` from a capture of ITS OWN leg
+def _check_leg_lines(root, macs, tag, d, c5, constants):
+    """rounds 5 and 6: every roofline object of the line carries `traffic` from a capture of ITS OWN leg
     (tools/profile_legs.py: the leg's timed launches only) with the ratio to the algorithmic bytes and the VALU cross-check,
-    `frac_useful` beside `frac`; configs 3 and 4 and the wire leg carry a CPU baseline; the wire leg runs two decodes per lane pair."""
+    `frac_useful` beside `frac`; configs 3 and 4 and the wire leg carry a CPU baseline; the wire leg runs two decodes per lane pair.
+    constants: the line belongs to the capture profile_constants.json was generated from (the newest tag only)."""
     import json
     useful = json.load(open(os.path.join(root, "profiles", "useful_macs.json")))
     prof = json.load(open(os.path.join(root, "profiles", "profile_constants.json")))
-    d = json.loads([l for l in open(os.path.join(root, "profiles", R05_TAG + "_bench.txt")) if l.startswith("{")][-1])
     B, t = d["config"]["batch_per_gpu"], d["config"]["t"]
     assert d["metric"] == "combine_signatures/sec" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["config"]["overlapped"] is False
     assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3 and d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001
@@ -154,15 +155,16 @@ def _check_round5_lines(root, macs):
         assert 0 < r["frac_useful"] <= r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3, key
         want = r["executed_macs_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12
         assert abs(r["achieved"] - want) / want < 2e-3 and r["useful_macs_per_unit"] <= r["executed_macs_per_unit"], key
-        p = prof[key]
-        assert p["source"] == "profiles/%s_%s_rocprofv3_summary.csv" % (R05_TAG, {"combine_g2_t3": "combine", "pairing_check": "verify_g2"}.get(key, key)), key
-        assert os.path.exists(os.path.join(root, p["source"])), key
-        assert r["traffic"] == p["traffic_bytes"] and r["traffic"] > 50 * r["algorithmic_bytes_per_launch"], key
+        assert r["traffic"] > 50 * r["algorithmic_bytes_per_launch"], key
         assert abs(r["traffic_over_algorithmic_bytes"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 0.06, key
         assert 0.4 < r["executed_cross_check"]["implied_v_mad_share_of_valu"] < 0.85, key
         # the same launches under rocprofv3 last as long as the line's HIP events say (the first launches of a process run a
         # little slower, and the 3 ms G1 leg shows it most: 2.87-3.11 ms over its four profiled launches, 2.72-2.79 in the line)
         assert abs(r["profile_kernel_ms"] - r["kernel_ms"]) / r["kernel_ms"] < 0.12, key
+        src = "profiles/%s_%s_rocprofv3_summary.csv" % (tag, {"combine_g2_t3": "combine", "pairing_check": "verify_g2"}.get(key, key))
+        assert src in r["traffic_is"] and os.path.exists(os.path.join(root, src)), key
+        if constants:
+            assert prof[key]["source"] == src and r["traffic"] == prof[key]["traffic_bytes"], key
     assert d["roofline"]["executed_macs_per_unit"] == macs["combine_g2_t3_fast"] and d["roofline"]["useful_macs_per_unit"] == useful["combine_g2_t3_fast"]
     w = d["wire"]["roofline"]
     assert w["executed_macs_per_unit"] == (t + 1) * macs["g2_decompress_x2"] + macs["combine_g2_t3_fast"] and "k_decompress_take_g2_x2" in w["kernel"]
@@ -175,12 +177,53 @@ def _check_round5_lines(root, macs):
         assert c["kind"] == "port" and c["unit"] == unit and c["cores"] >= 1 and "/root/reference/src/lib.rs" in c["reference"], leg
         assert "8192 jobs" in c["sample"] and c["value"] > c["single_thread_per_s"] and d[leg]["value"] / c["value"] > 100, leg
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] / d["cpu_baseline"]["value"] > 100
-    c5 = json.loads([l for l in open(os.path.join(root, "profiles", R05_TAG + "_config5_bench.txt")) if l.startswith("{")][-1])
     assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True and c5["config"]["batch_per_gpu"] == 131072
     for key, leg in (("config5_sign", "share_sign"), ("config5_combine", "combine"), ("config5_verify", "pairing_check")):
         r = c5["secondary_rooflines"][leg]
-        assert r["traffic"] == prof[key]["traffic_bytes"] and prof[key]["source"] == "profiles/%s_config5_rocprofv3_summary.csv" % R05_TAG, key
+        assert "profiles/%s_config5_rocprofv3_summary.csv" % tag in r["traffic_is"], key
+        if constants:
+            assert r["traffic"] == prof[key]["traffic_bytes"] and prof[key]["source"] == "profiles/%s_config5_rocprofv3_summary.csv" % tag, key
         assert abs(r["profile_kernel_ms"] - r["kernel_ms"]) / r["kernel_ms"] < 0.05 and 0.4 < r["executed_cross_check"]["implied_v_mad_share_of_valu"] < 0.85, key
+
+
+def _check_round5_lines(root, macs):
+    import json
+    d = json.loads([l for l in open(os.path.join(root, "profiles", R05_TAG + "_bench.txt")) if l.startswith("{")][-1])
+    c5 = json.loads([l for l in open(os.path.join(root, "profiles", R05_TAG + "_config5_bench.txt")) if l.startswith("{")][-1])
+    _check_leg_lines(root, macs, R05_TAG, d, c5, constants=False)
+
+
+def _check_round6_lines(root, macs):
+    """round 6 (BENCH_r05.json came back `parsed: null` on a 23.6 KB line): the committed bench output is what
+    the driver sees -- ONE compact JSON object under 8 000 bytes that carries the contract's fields, a compact `roofline` and
+    `cpu_baseline`, one object per secondary BASELINE configuration -- and the detail object beside it (bench_detail.json) obeys
+    everything round 5's 23 KB line obeyed; the compact line is a projection of it."""
+    import json
+    import benchline
+    for name in ("_bench", "_config5_bench"):
+        text = open(os.path.join(root, "profiles", R06_TAG + name + ".txt")).read()
+        detail = json.load(open(os.path.join(root, "profiles", R06_TAG + name + "_detail.json")))
+        line, _ = benchline.parse(text)
+        assert len(text.splitlines()[-1]) < 8000 and json.loads(text[-8000:].splitlines()[-1]) == line
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling"):
+            assert line[k] == detail[k], (name, k)
+        for k in ("kernel_ms", "frac", "frac_useful", "achieved", "peak", "traffic", "executed_macs_per_unit", "algorithmic_bytes_per_launch"):
+            assert line["roofline"][k] == detail["roofline"][k], (name, k)
+        assert line["roofline"]["bound"] == "valu_int32_mac" and line["roofline"]["unit"] == "TMAC/s" and line["ranks"]["world_size"] == 1
+        if name == "_bench":
+            d = detail
+            assert line["config"]["t"] == 3 and line["config"]["N"] == 10 and line["config"]["batch_per_gpu"] == 65536 and "batch=65536" in line["config"]["workload"]
+            for k in ("value", "unit", "cores", "kind"):
+                assert line["cpu_baseline"][k] == detail["cpu_baseline"][k], k
+            for leg in ("config3", "config4", "wire"):
+                assert line[leg]["value"] == detail[leg]["value"] and line[leg]["frac"] == detail[leg]["roofline"]["frac"], leg
+                assert line[leg]["cpu_baseline"]["value"] == detail[leg]["cpu_baseline"]["value"] and line[leg]["kernel_ms"] > 0, leg
+        else:
+            c5 = detail
+            assert line["config"]["t"] == 67 and line["config"]["N"] == 200 and line["valid_total_all_ranks"] == 131072
+    _check_leg_lines(root, macs, R06_TAG, d, c5, constants=True)
+    # the form labels of the line are the library's own thresholds (tc_ctx_get_tuning), not constants of bench.py
+    assert d["secondary_rooflines"]["hash_g2"]["kernel"] == "k_hash_g2" and "k_hash_g1_g2 +" in d["secondary_rooflines"]["ciphertext_verify"]["kernel"]
 
 
 def _check_round4_lines(root, macs):
@@ -309,6 +352,7 @@ def test_committed_bench_lines_are_self_consistent():
     assert abs(avg["tc::k_combine_fast<tc::Fq2>"] - d["roofline"]["kernel_ms"]) / d["roofline"]["kernel_ms"] < 0.08   # (+ the small grouping kernels)
     _check_round4_lines(root, macs)
     _check_round5_lines(root, macs)
+    _check_round6_lines(root, macs)
     c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r03_config5_1gpu_bench.txt")) if l.startswith("{")][-1])
     assert c5["config"]["t"] == 67 and c5["config"]["N"] == 200 and c5["verified_all"] is True and c5["ranks"]["world_size"] == 1
     c5 = json.loads([l for l in open(os.path.join(root, "profiles", "r02_config5_1gpu_bench.txt")) if l.startswith("{")][-1])

@@ -1,8 +1,8 @@
-# rocprofv3 capture for profiles/r05_*: ONE capture per leg of the bench line (tools/profile_legs.py: the leg's timed launches are
+# rocprofv3 capture for profiles/<tag>_* (r05_c, r06_c): ONE capture per leg of the bench line (tools/profile_legs.py: the leg's timed launches are
 # the last launches of its kernels in the process; tools/rocpd_summary.py --last averages exactly those), each a stats pass and
 # separate PMC passes (TCC fetch, TCC write, two SQ passes -- never combined with a trace domain other than --kernel-trace), then
 # the same for `bench.py --config 5`, THEN the constants of this capture (tools/profile_constants.py) and the bench line that
-# embeds them -- profiles and line on ONE lease.  usage (on the GPU box): bash tools/capture_r05.sh <tag> [extra bench.py args]
+# embeds them -- profiles and line on ONE lease.  usage (on the GPU box): bash tools/capture_legs.sh <tag> [extra bench.py args]
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 REPS=4
@@ -41,8 +41,9 @@ rm -rf gpurun_out/prof_${tag}_bench_stats
 cp gpurun_out/legs_${tag}.txt profiles/${tag}_legs.txt
 # the constants of THIS capture, then the line that carries them
 python tools/profile_constants.py $tag > /dev/null && cp profiles/profile_constants.json gpurun_out/profile_constants_${tag}.json
+# (stdout = the driver's compact line, < 8 KB; the detail object goes to bench_detail.json and, tagged, to stderr)
 timeout 1200 python bench.py "$@" > gpurun_out/bench_${tag}.txt 2>gpurun_out/bench_${tag}.err
-cp gpurun_out/bench_${tag}.txt profiles/${tag}_bench.txt
-timeout 600 python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_${tag}_config5.txt 2>gpurun_out/bench_${tag}_config5.err && cp gpurun_out/bench_${tag}_config5.txt profiles/${tag}_config5_bench.txt
-cp profiles/${tag}_*.csv profiles/${tag}_*.txt profiles/profile_constants.json gpurun_out/ 2>/dev/null
-tail -c 300 gpurun_out/bench_${tag}.txt
+cp gpurun_out/bench_${tag}.txt profiles/${tag}_bench.txt; cp bench_detail.json profiles/${tag}_bench_detail.json
+timeout 600 python bench.py --config 5 --no-cpu-baseline > gpurun_out/bench_${tag}_config5.txt 2>gpurun_out/bench_${tag}_config5.err && cp gpurun_out/bench_${tag}_config5.txt profiles/${tag}_config5_bench.txt && cp bench_detail.json profiles/${tag}_config5_bench_detail.json
+cp profiles/${tag}_*.csv profiles/${tag}_*.txt profiles/${tag}_*.json profiles/profile_constants.json gpurun_out/ 2>/dev/null
+wc -c gpurun_out/bench_${tag}.txt; head -c 400 gpurun_out/bench_${tag}.txt

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_<leg>_rocprofv3_summary.csv (tools/capture_r05.sh: one capture per leg of the bench line, the leg's timed
+"""profiles/<tag>_<leg>_rocprofv3_summary.csv (tools/capture_legs.sh: one capture per leg of the bench line, the leg's timed
 launches only) -> profiles/profile_constants.json: per leg the L2<->fabric traffic, VALU instruction count and kernel time PER
 LAUNCH that bench.py prints next to its live timings (`traffic`, `executed_cross_check`, `profile_kernel_ms`).
 usage: python tools/profile_constants.py <tag> [units]        e.g. r05_c"""

@@ -1,4 +1,4 @@
-"""One leg of the bench line, alone, for rocprofv3 (tools/capture_r05.sh): the workload is set up first, then the leg runs `reps`
+"""One leg of the bench line, alone, for rocprofv3 (tools/capture_legs.sh): the workload is set up first, then the leg runs `reps`
 times as the LAST launches of its kernels in the process -- tools/rocpd_summary.py --last <reps> then averages exactly those
 launches (duration, FETCH_SIZE, WRITE_SIZE, SQ_*), so a kernel's per-launch figures describe ONE kind of launch.
     python tools/profile_legs.py <leg> [reps]
