@@ -692,6 +692,9 @@ def run_config2(args, eng, dev, rank, world, peak):
         e.close()
     n_valid = total_count(int(ok.to(torch.int64).sum().item()), world, dev if cuda else None)   # per-rank valid counts, summed over RCCL
     assert n_valid == int(expect_ok.sum().item()) * world
+    _sh, _st = eng.g2_mul(d_sk, d_hashes)      # (untimed: the first call allocates the 50 MB result and the context's table arena)
+    sync()
+    del _sh, _st
     s0 = time.perf_counter()
     _sh, _st = eng.g2_mul(d_sk, d_hashes)
     sign_kernel_ms = eng.last_kernel_ms()
