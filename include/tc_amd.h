@@ -102,12 +102,14 @@ int tc_ctx_trim(tc_ctx* ctx);
  * every result down; device-I/O mode: the 8-byte read-back of off[B] per message-taking call and nothing else). */
 int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 /* The form choices this context makes (no counterpart in the reference: a measurement reports which kernels ran).
- * out4[0] / out4[1] = jobs from which a checked G2 decode / a hash takes two jobs per lane pair, out4[2] = the pairing form
+ * out8[0] / out8[1] = jobs from which a checked G2 decode / a hash takes two jobs per lane pair, out8[2] = the pairing form
  * (0 = by batch size: four lanes per check up to 16 384 checks, the prepared three-kernel form above; 1 quad, 2 lines,
- * 3 pair, 4 fused), out4[3] = bytes the prepared form's line buffer may take (0 = a third of the free HBM).  The defaults
- * are the measured thresholds (csrc/tc_launch.h); the environment variables TC_DUO_MIN, TC_PAIRING_FORM,
- * TC_PAIRING_BUDGET (tests, experiments) are read ONCE, by tc_ctx_create -- never on the launch path. */
-int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out4);
+ * 3 pair, 4 fused), out8[3] = bytes the prepared form's line buffer may take (0 = a third of the free HBM), out8[4] = 1 when
+ * the membership tests of checked-input mode run on the context's second stream beside the main kernels of a call (default)
+ * and 0 when they run before them; out8[5..7] = 0 (reserved).  The defaults are the measured choices (csrc/tc_launch.h); the
+ * environment variables TC_DUO_MIN, TC_PAIRING_FORM, TC_PAIRING_BUDGET, TC_CHECKS_BESIDE (tests, experiments) are read ONCE,
+ * by tc_ctx_create -- never on the launch path. */
+int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8);
 const char* tc_version(void);
 
 /* ---- hashing onto G2 -------------------------------------------------------------------- */

@@ -429,7 +429,7 @@ def test_two_jobs_per_lane_pair_forms_equal_the_one_job_forms(engine, rnd):
             h = eng.hash_g2(blob, off)
             hg, hst = eng.hash_g1_g2(g1_a, blob, off)
             res[form] = (pts, st, h, hg, hst)
-    assert engine.tuning() == {"duo_min_decode": 32769, "duo_min_hash": 131072, "pairing_form": 0, "pairing_budget": 0}   # the defaults
+    assert engine.tuning() == {"duo_min_decode": 32769, "duo_min_hash": 131072, "pairing_form": 0, "pairing_budget": 0, "checks_beside": 1}   # the defaults
     for x, y in zip(res["two"], res["one"]):
         assert (x == y).all(), np.flatnonzero((x != y).reshape(n, -1).any(axis=1))[:16]
     pts, st, h, hg, hst = res["two"]
@@ -475,3 +475,88 @@ def test_hashes_above_the_two_message_threshold_equal_the_one_message_form(engin
     for j in [0, 1, 65535, 65536, 131071, 131072] + [rnd.randrange(n) for _ in range(10)]:
         assert bytes(own[j]) == c.hash_g2(msgs[j])
     assert (own_p == one_p).all() and (own_s == one_s).all() and int(own_s.sum()) in (0, 3)
+
+
+def test_membership_tests_beside_the_main_kernels_equal_the_one_stream_order(engine, rnd):
+    """r06: in checked-input mode (the context's default; the reference tests every value once, in from_bytes:
+    /root/reference/src/lib.rs:140-146, 246-252) the membership tests of a call run on the context's SECOND stream beside the
+    call's main kernels and are joined before their verdicts are applied (tc_api.hip Call::apply_checks).  The order of execution
+    must not be observable: with non-members, off-curve points and the identity planted in every operand position, every entry
+    returns the same bytes, statuses and ok-vectors as a context created with TC_CHECKS_BESIDE=0 (tests first, one stream) --
+    host buffers and device buffers, a batch with a wave boundary inside and one large enough for several waves per SIMD."""
+    import torch
+    from conftest import engine_with_env
+    from threshold_crypto_amd.workload import ThresholdSigWorkload, ThresholdEncWorkload
+    bad2 = [u8(o.g2_uncompressed(non_member_g2(rnd))) for _ in range(3)]
+    bad1 = [u8(o.g1_uncompressed(non_member_g1(rnd))) for _ in range(3)]
+    off_curve2 = u8(o.g2_uncompressed(o.E2.mul(o.G2_GEN, 7))); off_curve2[100] ^= 1
+    t, N = 3, 10
+    for B in (70, 9000):
+        wl = ThresholdSigWorkload(engine, t, N, B)
+        we = ThresholdEncWorkload(engine, t, N, B)
+        sig, st = engine.combine_g2(t, wl.idx, wl.shares)
+        assert not st.any()
+        shares, sigs, hashes = wl.shares.copy(), sig.copy(), wl.hashes.copy()
+        u, w, dsh = we.u.copy(), we.w.copy(), we.shares.copy()
+        pks = np.tile(wl.master_pk[None], (B, 1))
+        for n_planted, j in enumerate(sorted(rnd.sample(range(B), 24))):
+            k = n_planted % 8
+            if k == 0:
+                shares[j, rnd.randrange(t + 1)] = bad2[n_planted % 3]
+            elif k == 1:
+                shares[j, rnd.randrange(t + 1)] = off_curve2
+            elif k == 2:
+                sigs[j] = bad2[n_planted % 3]
+            elif k == 3:
+                hashes[j] = bad2[n_planted % 3]
+            elif k == 4:
+                pks[j] = bad1[n_planted % 3]
+            elif k == 5:
+                u[j] = bad1[n_planted % 3]
+            elif k == 6:
+                w[j] = bad2[n_planted % 3]
+            else:
+                dsh[j, rnd.randrange(t + 1)] = bad1[n_planted % 3]
+        fr = np.stack([u8(o.fr_to_bytes(rnd.randrange(1, o.R))) for _ in range(2)])
+        rs = np.stack([u8(o.fr_to_bytes(rnd.randrange(1, o.R))) for _ in range(B)])
+        blob, moff = pack_messages(wl.msgs)
+
+        def run(eng, dev):
+            # device-I/O calls return before their kernels have run (the caller's stream orders them): every operand tensor stays
+            # alive in `keep` until the context has been synchronised -- torch would hand a dead tensor's memory to the next one
+            keep = []
+
+            def to(a):
+                if not dev:
+                    return a
+                keep.append(torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev))
+                return keep[-1]
+            host = (lambda x: x.cpu().numpy()) if dev else (lambda x: x)
+            out = []
+            out += list(eng.combine_g2(t, to(wl.idx), to(shares)))
+            out += list(eng.g2_mul(to(fr), to(hashes)))
+            out += [eng.verify_g2(to(pks), to(sigs), to(hashes))]
+            out += [eng.verify_sig(to(pks), to(sigs), to(blob), to(moff))]
+            out += [eng.pairing_check(to(pks), to(hashes), to(pks), to(hashes))]
+            out += [eng.ciphertext_verify(to(u), to(we.v), to(we.off), to(w))]
+            out += list(eng.decrypt(t, to(we.idx), to(dsh), to(we.v), to(we.off)))
+            out += list(eng.decrypt_share(to(fr[0]), to(u), to(we.v), to(we.off), to(w)))
+            out += list(eng.encrypt(to(pks), to(rs), to(blob), to(moff)))
+            out += list(eng.hash_g1_g2(to(u), to(blob), to(moff)))
+            eng.sync()
+            return [host(x) for x in out]
+
+        with engine_with_env(TC_CHECKS_BESIDE=0) as plain:
+            assert plain.tuning()["checks_beside"] == 0 and engine.tuning()["checks_beside"] == 1
+            want = run(plain, None)
+            want_dev = run(plain, torch.device("cuda", 0)) if B == 70 else None
+        for dev in (None, torch.device("cuda", 0)):
+            got = run(engine, dev)
+            assert len(got) == len(want)
+            for i, (g, x) in enumerate(zip(got, want)):
+                assert g.shape == x.shape and (g == x).all(), (B, dev, i)
+        if want_dev is not None:
+            for g, x in zip(want_dev, want):
+                assert (g == x).all()
+        # ... and the planted operands did fail their jobs (the tests ran): statuses / ok of the checked entries are not all-OK
+        assert want[1].any() and not want[4].all() and not want[6].all() and want[9].any() and not want[11].all() and want[15].any()

@@ -29,6 +29,10 @@ struct tc_ctx {
   // passed the checked decode
   bool input_checks = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the membership tests of checked-input mode run on a SECOND stream beside the call's main kernels (Call::apply_checks):
+  // stream and the two ordering events, created with the context
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double last_ms = 0.0;
   std::string err;
   std::vector<Slot> slots;  // grow-only device staging buffers, reused across calls
@@ -65,6 +69,10 @@ struct Call {
   struct Pending {
     const uint8_t* valid;
     size_t per_job, group;
+    // the membership-test launch that will fill `valid` (pts == nullptr: already filled, e.g. by a checked decode)
+    bool g2 = false;
+    const uint8_t* pts = nullptr;
+    size_t stride = 0, n_per_job = 0, take = 0, n = 0;
   };
   std::vector<Pending> checks;  // checked-input mode: validity bytes waiting to be applied to the jobs
 
@@ -163,12 +171,36 @@ struct Call {
     const size_t n = records * take;
     uint8_t* v = temp<uint8_t>(n);
     if (!v) return;
-    if (g2) tc::launch_subgroup_check_g2(c->stream, d_pts, stride, n_per_job, take, n, v);
-    else tc::launch_subgroup_check_g1(c->stream, d_pts, stride, n_per_job, take, n, v);
-    checks.push_back({v, take, group});
+    // The tests are NOT launched here.  They read operands only and nothing reads their verdict before apply_checks, so they
+    // run on the context's second stream BESIDE the main kernels of the call, submitted after them (apply_checks): a launch
+    // that ends with idle SIMDs -- the 65 536-job combination's last third, DESIGN.md 5.2 -- gets its tail filled (default-mode
+    // combine_signatures 9.9 -> 9.2 ms, profiles/r06_checks_overlap_probe.txt), and a small batch runs both at once.
+    // ev_fork marks where the operands are ready in the main stream (every check_points call precedes the main kernels).
+    if (c->tuning.checks_beside && !check(hipEventRecord(c->ev_fork, c->stream), "event record")) return;
+    checks.push_back({v, take, group, g2, d_pts, stride, n_per_job, take, n});
+    if (!c->tuning.checks_beside) launch_pending(checks.back(), c->stream);
+  }
+  void launch_pending(Pending& p, hipStream_t st) {
+    if (!p.pts) return;
+    if (p.g2) tc::launch_subgroup_check_g2(st, p.pts, p.stride, p.n_per_job, p.take, p.n, const_cast<uint8_t*>(p.valid));
+    else tc::launch_subgroup_check_g1(st, p.pts, p.stride, p.n_per_job, p.take, p.n, const_cast<uint8_t*>(p.valid));
+    p.pts = nullptr;  // launched
+  }
+  // the tests check_points deferred: submitted now (after the call's main kernels) on the second stream, their verdicts
+  // ordered before whatever the main stream does next.  Every reader of Pending::valid goes through here first.
+  void run_checks() {
+    if (failed) return;
+    bool beside = false;
+    for (auto& p : checks) beside = beside || p.pts != nullptr;
+    if (!beside) return;
+    // second stream: wait for the operands, run the tests, hand the verdicts back to the main stream
+    if (!check(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0), "stream wait")) return;
+    for (auto& p : checks) launch_pending(p, c->side_stream);
+    if (check(hipEventRecord(c->ev_join, c->side_stream), "event record")) check(hipStreamWaitEvent(c->stream, c->ev_join, 0), "stream wait");
   }
   // after the main kernels: jobs that own an invalid point fail like undecodable ones
   void apply_checks(size_t B, uint8_t* status, uint8_t* out, size_t out_bytes, uint8_t* ok) {
+    run_checks();
     if (!failed)
       for (auto& p : checks) tc::launch_invalidate_jobs(c->stream, p.valid, p.per_job, p.group, B, status, out, out_bytes, ok);
     checks.clear();
@@ -304,6 +336,7 @@ tc::Tuning tuning_from_env() {
   if (const char* e = getenv("TC_DUO_MIN")) tn.duo_min_decode = tn.duo_min_hash = (size_t)strtoull(e, nullptr, 10);
   if (const char* f = getenv("TC_PAIRING_FORM")) tn.pairing_form = f[0] == 'q' ? 1 : f[0] == 'l' ? 2 : f[0] == 'p' ? 3 : f[0] == 'f' ? 4 : 0;
   if (const char* b = getenv("TC_PAIRING_BUDGET")) tn.pairing_budget = (size_t)strtoull(b, nullptr, 10);
+  if (const char* o = getenv("TC_CHECKS_BESIDE")) tn.checks_beside = o[0] != '0';
   return tn;
 }
 
@@ -332,6 +365,9 @@ int tc_ctx_create(tc_ctx** out, int device) {
   c->device = device;
   c->tuning = tuning_from_env();
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipMalloc((void**)&c->g1_gen, 96) != hipSuccess || hipMalloc((void**)&c->g1_gen_unfix, 96) != hipSuccess) {
     tc_ctx_destroy(c);
@@ -364,6 +400,12 @@ void tc_ctx_destroy(tc_ctx* c) {
   if (c->tbl_flags) (void)hipFree(c->tbl_flags);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->side_stream) {
+    (void)hipStreamSynchronize(c->side_stream);
+    (void)hipStreamDestroy(c->side_stream);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -405,12 +447,14 @@ int tc_ctx_trim(tc_ctx* ctx) {
 
 int tc_ctx_get_input_checks(const tc_ctx* ctx) { return (ctx && ctx->input_checks) ? 1 : 0; }
 int tc_ctx_get_device_io(const tc_ctx* ctx) { return (ctx && ctx->device_io) ? 1 : 0; }
-int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out4) {
-  if (!ctx || !out4) return TC_ERR_INVALID_ARG;
-  out4[0] = ctx->tuning.duo_min_decode;
-  out4[1] = ctx->tuning.duo_min_hash;
-  out4[2] = (uint64_t)ctx->tuning.pairing_form;
-  out4[3] = ctx->tuning.pairing_budget;
+int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8) {
+  if (!ctx || !out8) return TC_ERR_INVALID_ARG;
+  out8[0] = ctx->tuning.duo_min_decode;
+  out8[1] = ctx->tuning.duo_min_hash;
+  out8[2] = (uint64_t)ctx->tuning.pairing_form;
+  out8[3] = ctx->tuning.pairing_budget;
+  out8[4] = ctx->tuning.checks_beside ? 1 : 0;
+  out8[5] = out8[6] = out8[7] = 0;  // reserved
   return TC_OK;
 }
 
@@ -1087,6 +1131,7 @@ static int verify_rlc(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const 
     ctx->d2h_bytes += 3 * NG;
     // checked-input mode: a group that owns a non-member operand goes to the per-job path as well
     std::vector<const uint8_t*> valid_ptrs;
+    k.run_checks();  // (the membership tests ran beside the two sums and the group checks; their verdicts are read back below)
     for (auto& p : k.checks) valid_ptrs.push_back(p.valid);
     const size_t n_checks = k.checks.size();
     k.checks.clear();
@@ -1543,6 +1588,7 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uin
   if (!k.checks.empty()) {
     // an invalid key fails the job: status + identity u and w (v keeps the kernel's bytes and must be ignored)
     auto pending = k.checks;
+    for (auto& p : pending) p.pts = nullptr;  // (the first apply_checks launches the tests; the second only applies their verdicts)
     k.apply_checks(B, d_st, d_u, 96, nullptr);
     k.checks = pending;
     k.apply_checks(B, nullptr, d_w, 192, nullptr);

@@ -41,13 +41,14 @@ constexpr size_t kDuoMinHash = 131072;
 inline bool duo_form(size_t jobs, size_t min_jobs) { return jobs >= min_jobs; }
 
 // The form choices of a context.  The defaults are the measured thresholds above / in k_pairing.hip; the environment
-// (TC_DUO_MIN=<jobs>, TC_PAIRING_FORM=quad|lines|pair|fused, TC_PAIRING_BUDGET=<bytes>: tests and experiments) is read ONCE,
+// (TC_DUO_MIN=<jobs>, TC_PAIRING_FORM=quad|lines|pair|fused, TC_PAIRING_BUDGET=<bytes>, TC_CHECKS_BESIDE=0|1: tests and experiments) is read ONCE,
 // when the context is created (tc_api.hip tuning_from_env) -- no getenv on the launch path, nothing a concurrent setenv can race
 // with -- and tc_ctx_get_tuning reports what a context uses.
 struct Tuning {
   size_t duo_min_decode = kDuoMinDecode, duo_min_hash = kDuoMinHash;
   int pairing_form = 0;       // 0 = by batch size; 1 quad, 2 lines (prepared), 3 pair (one loop), 4 fused
   size_t pairing_budget = 0;  // bytes the prepared form's line buffer may take; 0 = a third of the HBM that is free
+  bool checks_beside = true;  // checked-input mode: the membership tests on a second stream beside the call's main kernels (TC_CHECKS_BESIDE=0: before them, one stream)
 };
 
 // The G1 ladder kernels keep their per-lane table in the HBM arena and fit 256 registers (two waves per SIMD) at
