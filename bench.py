@@ -813,13 +813,17 @@ def run_config2(args, eng, dev, rank, world, peak):
                 lambda g, k: int((g[0] != 1).sum()) + int(g[2].any()) + int((g[1].reshape(k, 32) != plain_gpu[:32 * k].reshape(k, 32)).any(axis=1).sum()))
     if not args.no_extras and not harness and not args.profile_run:
         # ---- the headline step with the context's default membership tests on every share -------------------------
+        # (r06: the tests run on the context's second stream beside the combination, tc_api.hip Call::run_checks; best of three calls)
         eng.set_input_checks(True)
         csig, cst = eng.combine_g2(t, d_idx, d_shares)
-        sync()
-        c0 = time.perf_counter()
-        csig, cst = eng.combine_g2(t, d_idx, d_shares)
-        sync()
-        extras["combine_with_input_checks_per_s"] = round(B * world / (time.perf_counter() - c0), 1)
+        checked_dt = 1e9
+        for _ in range(3):
+            sync()
+            c0 = time.perf_counter()
+            csig, cst = eng.combine_g2(t, d_idx, d_shares)
+            sync()
+            checked_dt = min(checked_dt, time.perf_counter() - c0)
+        extras["combine_with_input_checks_per_s"] = round(B * world / checked_dt, 1)
         eng.set_input_checks(False)
         assert bool((csig == sig).all().item()) and int(cst.to(torch.int32).sum().item()) == 0
     wire = None

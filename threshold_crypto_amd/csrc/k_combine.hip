@@ -331,7 +331,7 @@ size_t combine_group_slots(size_t B) { return B + (size_t)kCombineClasses * kCom
 // perm = nullptr to run the jobs in their own order
 void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
-                       uint32_t* perm, const uint32_t* need_general) {
+                       uint32_t* perm, const uint32_t* need_general, hipEvent_t before_main) {
   if (!B || !ta.mem || !ta.flags) return;
   if (t >= 1 && t <= 3) {
     size_t slots = B;
@@ -343,6 +343,10 @@ void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job
       hipLaunchKernelGGL(k_combine_classify, dim3(gb), dim3(kGroupBlock), 0, st, idx, n_per_job, t, B, cls, counters);
       hipLaunchKernelGGL(k_combine_scatter, dim3(gb), dim3(kGroupBlock), 0, st, cls, B, counters, perm);
     }
+    // before_main: recorded where the stream reaches the ONE long kernel of the call -- work the caller runs beside this call on
+    // another stream (the membership tests of checked-input mode, tc_api.hip Call::run_checks) waits for it, so that it starts
+    // BEHIND this launch and fills the slots its cheap waves free instead of delaying them
+    if (before_main) (void)hipEventRecord(before_main, st);
     hipLaunchKernelGGL(k_combine_fast<Fq2>, dim3(grid_for(slots * kG2Lanes)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)perm, slots, ta);
   }
   // t >= 1: the jobs the fast path leaves go through the two-stage kernels of k_msm.hip (the caller launches them);

@@ -29,8 +29,10 @@ struct tc_ctx {
   // passed the checked decode
   bool input_checks = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // the membership tests of checked-input mode run on a SECOND stream beside the call's main kernels (Call::apply_checks):
-  // stream and the two ordering events, created with the context
+  // the membership tests of checked-input mode run on a SECOND stream beside the call's main kernels (Call::run_checks): a
+  // LOW-priority stream, created by the first call that needs it -- a context whose caller opted out of the tests never has
+  // one (HIP multiplexes its streams onto a few hardware queues: a stream nobody uses must not take a queue from the main
+  // streams of several contexts that run side by side, bench.py `streaming`) -- and the two ordering events
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double last_ms = 0.0;
@@ -176,9 +178,31 @@ struct Call {
     // that ends with idle SIMDs -- the 65 536-job combination's last third, DESIGN.md 5.2 -- gets its tail filled (default-mode
     // combine_signatures 9.9 -> 9.2 ms, profiles/r06_checks_overlap_probe.txt), and a small batch runs both at once.
     // ev_fork marks where the operands are ready in the main stream (every check_points call precedes the main kernels).
-    if (c->tuning.checks_beside && !check(hipEventRecord(c->ev_fork, c->stream), "event record")) return;
+    const bool beside = c->tuning.checks_beside && side_stream_ready();
+    if (beside && !check(hipEventRecord(c->ev_fork, c->stream), "event record")) return;
     checks.push_back({v, take, group, g2, d_pts, stride, n_per_job, take, n});
-    if (!c->tuning.checks_beside) launch_pending(checks.back(), c->stream);
+    if (!beside) launch_pending(checks.back(), c->stream);
+  }
+  // the context's second stream, made on first use: non-blocking and of the LOWEST priority the device offers, so that its
+  // kernels take the wave slots the main kernels leave idle instead of competing with them for the dispatcher, and so that it
+  // draws its hardware queue from another pool than the normal-priority streams
+  bool side_stream_ready() {
+    if (c->side_stream) return true;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, c->tuning.checks_beside == 2 ? 0 : least) != hipSuccess) {
+      c->side_stream = nullptr;
+      (void)hipGetLastError();
+      return false;  // no second stream: the tests run before the main kernels, on the one stream (correct, just not overlapped)
+    }
+    return true;
+  }
+  // the event a launcher may re-record just before the call's one long kernel (k_combine.hip launch_combine_g2): the deferred
+  // tests then start behind that kernel instead of beside the small kernels in front of it; nullptr when nothing is deferred
+  hipEvent_t fork_event() const {
+    for (auto& p : checks)
+      if (p.pts) return c->ev_fork;
+    return nullptr;
   }
   void launch_pending(Pending& p, hipStream_t st) {
     if (!p.pts) return;
@@ -336,7 +360,7 @@ tc::Tuning tuning_from_env() {
   if (const char* e = getenv("TC_DUO_MIN")) tn.duo_min_decode = tn.duo_min_hash = (size_t)strtoull(e, nullptr, 10);
   if (const char* f = getenv("TC_PAIRING_FORM")) tn.pairing_form = f[0] == 'q' ? 1 : f[0] == 'l' ? 2 : f[0] == 'p' ? 3 : f[0] == 'f' ? 4 : 0;
   if (const char* b = getenv("TC_PAIRING_BUDGET")) tn.pairing_budget = (size_t)strtoull(b, nullptr, 10);
-  if (const char* o = getenv("TC_CHECKS_BESIDE")) tn.checks_beside = o[0] != '0';
+  if (const char* o = getenv("TC_CHECKS_BESIDE")) tn.checks_beside = o[0] - '0';
   return tn;
 }
 
@@ -365,7 +389,6 @@ int tc_ctx_create(tc_ctx** out, int device) {
   c->device = device;
   c->tuning = tuning_from_env();
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -453,7 +476,7 @@ int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8) {
   out8[1] = ctx->tuning.duo_min_hash;
   out8[2] = (uint64_t)ctx->tuning.pairing_form;
   out8[3] = ctx->tuning.pairing_budget;
-  out8[4] = ctx->tuning.checks_beside ? 1 : 0;
+  out8[4] = (uint64_t)ctx->tuning.checks_beside;
   out8[5] = out8[6] = out8[7] = 0;  // reserved
   return TC_OK;
 }
@@ -655,7 +678,8 @@ static void combine_launch(Call& k, bool g2, size_t t, size_t n, const uint64_t*
     msm_g2(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds: every job, coefficients from the one-inversion kernels
   } else if (g2) {
     // t <= 3: small-index fast path first; then (t >= 1) the jobs it left, through the two-stage kernels
-    tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need);
+    tc::launch_combine_g2(ctx->stream, k.tables(), t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_cls, d_counters, d_perm, d_need,
+                          k.fork_event());
     if (t >= 1) {
       tc::MsmFilter f;
       f.need = d_need;

@@ -48,7 +48,7 @@ struct Tuning {
   size_t duo_min_decode = kDuoMinDecode, duo_min_hash = kDuoMinHash;
   int pairing_form = 0;       // 0 = by batch size; 1 quad, 2 lines (prepared), 3 pair (one loop), 4 fused
   size_t pairing_budget = 0;  // bytes the prepared form's line buffer may take; 0 = a third of the HBM that is free
-  bool checks_beside = true;  // checked-input mode: the membership tests on a second stream beside the call's main kernels (TC_CHECKS_BESIDE=0: before them, one stream)
+  int checks_beside = 1;  // checked-input mode: the membership tests on a second stream beside the call's main kernels (TC_CHECKS_BESIDE=0: before them, one stream)
 };
 
 // The G1 ladder kernels keep their per-lane table in the HBM arena and fit 256 registers (two waves per SIMD) at
@@ -121,7 +121,7 @@ void launch_lagrange_fr(hipStream_t st, const uint32_t* idx_fr, size_t n_per_job
 size_t combine_group_slots(size_t B);
 void launch_combine_g2(hipStream_t st, TableArena ta, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, uint8_t* cls, uint32_t* counters,
-                       uint32_t* perm, const uint32_t* need_general);
+                       uint32_t* perm, const uint32_t* need_general, hipEvent_t before_main = nullptr);
 // shared_points: every job combines the SAME n points (points holds n of them) with its own n scalars
 void launch_lincomb_g1(hipStream_t st, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
                        uint8_t* status, bool shared_points = false);

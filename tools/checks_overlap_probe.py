@@ -62,6 +62,23 @@ r, (ok3, (sig3, st3)) = best(co_rev)
 dflt, (sig4, st4) = best(lambda: c.combine_g2(t, d_idx, d_sh))
 assert bool(ok.all().item()) and bool(ok2.all().item()) and bool(ok3.all().item())
 assert bool((sig == sig2).all().item()) and bool((sig == sig3).all().item()) and bool((sig == sig4).all().item())
+# two contexts in flight (bench.py `streaming`): with the tests OFF (two main streams) and with the tests ON (two main + two second streams)
+c2 = Engine(0); c2.set_timing(False); c2.set_input_checks(True)
+
+
+def in_flight(e1, e2, n=8):
+    outs = [(e1 if i % 2 == 0 else e2).combine_g2(t, d_idx, d_sh) for i in range(n)]
+    e1.sync(); e2.sync()
+    return outs
+
+
+for e1, e2 in ((a, b), (c, c2)):
+    in_flight(e1, e2)
+fl_off, _ = best(lambda: in_flight(a, b), reps=3)
+fl_on, outs = best(lambda: in_flight(c, c2), reps=3)
+assert all(bool((o_sig == sig).all().item()) and not bool(o_st.any().item()) for o_sig, o_st in outs)
 print(json.dumps({"jobs": B, "membership_tests_alone_ms": round(chk, 3), "combine_alone_ms": round(cmb, 3), "seq_ms": round(s, 3),
                   "combine_then_tests_beside_ms": round(o, 3), "tests_then_combine_beside_ms": round(r, 3), "default_one_call_ms": round(dflt, 3),
-                  "saved_ms": round(s - min(o, r), 3), "saved_frac_of_default": round((s - min(o, r)) / dflt, 4)}), flush=True)
+                  "saved_ms": round(s - min(o, r), 3), "saved_frac_of_default": round((s - min(o, r)) / dflt, 4),
+                  "two_contexts_in_flight_ms_per_batch": {"tests_off": round(fl_off / 8, 3), "tests_on_default": round(fl_on / 8, 3)},
+                  "context_tuning": c.tuning()}), flush=True)
