@@ -237,6 +237,8 @@ if lib.tc_ctx_set_stream(None, None) != _native.TC_ERR_INVALID_ARG:
     bad.append(("tc_ctx_set_stream", "rc"))
 if lib.tc_ctx_transfer_bytes(None, None, None) != _native.TC_ERR_INVALID_ARG:
     bad.append(("tc_ctx_transfer_bytes", "rc"))
+if lib.tc_ctx_get_tuning(None, None) != _native.TC_ERR_INVALID_ARG or lib.tc_ctx_get_tuning(None, (ctypes.c_uint64 * 8)()) != _native.TC_ERR_INVALID_ARG:
+    bad.append(("tc_ctx_get_tuning", "rc"))
 lib.tc_last_error(None)
 print("BAD", bad)
 """ % ROOT
