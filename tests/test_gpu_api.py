@@ -377,3 +377,36 @@ print("BAD", bad)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
     assert "BAD []" in out.stdout, out.stdout[-2000:]
+
+
+def test_device_operands_passed_as_temporaries_stay_alive_until_sync(engine):
+    """Device-I/O calls return before their kernels have run (INTEGRATION.md "Device-I/O calls are asynchronous").  The Python mirror
+    keeps the operand tensors of every call since the last sync() alive, so the natural `eng.verify_sig(pk.to(dev), ...)` with
+    temporaries is not a use-after-free: torch would hand a dead tensor's memory to the next `.to(dev)` while the kernels still read it
+    (round 6: a test of this repository did exactly that and hung the GPU on garbage message offsets).  Twenty calls with fresh
+    temporaries each, interleaved with allocations of the same sizes, then one sync: every result equals the host-buffer call's."""
+    import torch
+    from threshold_crypto_amd.engine import pack_messages
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    dev = torch.device("cuda", 0)
+    t, N, B = 3, 10, 300
+    wl = ThresholdSigWorkload(engine, t, N, B)
+    sig, st = engine.combine_g2(t, wl.idx, wl.shares)
+    blob, off = pack_messages(wl.msgs)
+    bad = sig.copy()
+    bad[5] = sig[6]
+    want_ok = engine.verify_sig(wl.master_pk, bad, blob, off)
+    want_sig = sig
+    assert want_ok.tolist() == [1] * 5 + [0] + [1] * (B - 6)
+    to = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.copy()).to(dev)
+    results = []
+    for i in range(20):
+        ok = engine.verify_sig(to(wl.master_pk), to(bad), to(blob), to(off))
+        s2, st2 = engine.combine_g2(t, to(wl.idx), to(wl.shares))
+        junk = [to(np.full_like(x, 0xAB)) for x in (bad, blob, wl.shares)]      # what torch would place into freed operand memory
+        del junk
+        results.append((ok, s2, st2))
+    engine.sync()
+    assert not engine._keep
+    for ok, s2, st2 in results:
+        assert (ok.cpu().numpy() == want_ok).all() and (s2.cpu().numpy() == want_sig).all() and not st2.cpu().numpy().any()

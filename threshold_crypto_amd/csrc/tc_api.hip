@@ -176,7 +176,7 @@ struct Call {
     // The tests are NOT launched here.  They read operands only and nothing reads their verdict before apply_checks, so they
     // run on the context's second stream BESIDE the main kernels of the call, submitted after them (apply_checks): a launch
     // that ends with idle SIMDs -- the 65 536-job combination's last third, DESIGN.md 5.2 -- gets its tail filled (default-mode
-    // combine_signatures 9.9 -> 9.2 ms, profiles/r06_checks_overlap_probe.txt), and a small batch runs both at once.
+    // combine_signatures 10.2 -> 9.3 ms per call, profiles/r06_checks_beside_ab.txt), and a small batch runs both at once.
     // ev_fork marks where the operands are ready in the main stream (every check_points call precedes the main kernels).
     const bool beside = c->tuning.checks_beside && side_stream_ready();
     if (beside && !check(hipEventRecord(c->ev_fork, c->stream), "event record")) return;
@@ -414,6 +414,8 @@ int tc_ctx_create(tc_ctx** out, int device) {
 void tc_ctx_destroy(tc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // device-I/O calls may still be running on the context's (or the caller's) stream: nothing is freed under them
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& s : c->slots)
     if (s.p) (void)hipFree(s.p);
   if (c->g1_gen) (void)hipFree(c->g1_gen);

@@ -57,11 +57,16 @@ class Engine:
         self._ctx = ctx
         self.device = int(device)
         self._device_io = False
+        # device-I/O calls return before their kernels have run: the operand tensors of the calls since the last sync() are
+        # kept alive here, so that `eng.verify_sig(pk.to(dev), ...)` with temporaries is not a use-after-free (torch would hand a
+        # dead tensor's memory to the next allocation while the kernels still read it)
+        self._keep = {}
 
     def close(self):
         if getattr(self, "_ctx", None):
-            self._lib.tc_ctx_destroy(self._ctx)
+            self._lib.tc_ctx_destroy(self._ctx)     # (waits for the context's streams)
             self._ctx = None
+            self._keep.clear()
 
     def __del__(self):
         try:
@@ -111,6 +116,7 @@ class Engine:
 
     def sync(self):
         self._lib.tc_sync(self._ctx)
+        self._keep.clear()
 
     def version(self):
         return self._lib.tc_version().decode()
@@ -120,6 +126,8 @@ class Engine:
         if dev and len(dev) != len([a for a in arrays if a is not None]):
             raise ValueError("mixing host (numpy) and device (torch) arrays in one call")
         want = bool(dev)
+        for a in dev:
+            self._keep[id(a)] = a
         if want != self._device_io:
             self._lib.tc_ctx_set_device_io(self._ctx, 1 if want else 0)
             self._device_io = want
