@@ -302,7 +302,7 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
 // Lagrange stage, the general kernel takes every job)
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general, TableArena ta,
-                       uint8_t* cls, uint32_t* counters, uint32_t* perm) {
+                       uint8_t* cls, uint32_t* counters, uint32_t* perm, hipEvent_t before_main) {
   if (!B) return;
   if (idx && t >= 1 && t <= 3) {
     if (!ta.mem || !ta.flags) return;   // (the arena could not be allocated: the call has failed already)
@@ -317,6 +317,7 @@ void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_
     } else {
       perm = nullptr;
     }
+    if (before_main) (void)hipEventRecord(before_main, st);  // (as in launch_combine_g2: work beside this call starts behind its long kernel)
 #if TC_G1_ARENA_MIN > 0
     if (B <= kG1ArenaMinJobs)
       hipLaunchKernelGGL(k_combine_fast<Fq>, dim3(grid_for(B)), dim3(kBlock), 0, st, t, n_per_job, idx, shares, B, out, status, (const uint32_t*)nullptr, B, TableArena{nullptr, nullptr});

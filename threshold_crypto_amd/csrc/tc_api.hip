@@ -693,7 +693,7 @@ static void combine_launch(Call& k, bool g2, size_t t, size_t n, const uint64_t*
   }
   else if (t + 1 >= tc::kMsmMinPoints) msm_g1(k, t + 1, n * PB, d_sh, d_lam, B, d_pt, d_st);  // large thresholds in G1: the same two stages
   else tc::launch_combine_g1(ctx->stream, t, n, d_idx, d_sh, d_lam, B, d_pt, d_st, d_need,
-                             k.tables(), d_cls, d_counters, d_perm);
+                             k.tables(), d_cls, d_counters, d_perm, k.fork_event());
 }
 
 // samples.len() <= t  =>  Err(NotEnoughShares) for every job        (src/lib.rs:731-733)

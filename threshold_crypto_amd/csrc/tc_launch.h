@@ -105,7 +105,7 @@ void launch_lagrange_all(hipStream_t st, const uint64_t* idx, size_t n_per_job, 
 void launch_combine_g1(hipStream_t st, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
                        const uint32_t* lam, size_t B, uint8_t* out, uint8_t* status, const uint32_t* need_general,
                        TableArena ta = TableArena{nullptr, nullptr}, uint8_t* cls = nullptr, uint32_t* counters = nullptr,
-                       uint32_t* perm = nullptr);
+                       uint32_t* perm = nullptr, hipEvent_t before_main = nullptr);
 // From this many jobs on the G1 fast path groups its jobs by denominator class (a wave of D = 1 jobs -- a fifth of the 4-of-10
 // subsets -- skips the [1 / D] ladder).  It only pays once a SIMD sees several rounds of waves: measured 3.5 % slower at 131 072
 // jobs (every wave resident at once: the launch lasts as long as two generic waves on one SIMD, grouped or not), equal at
