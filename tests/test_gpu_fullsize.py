@@ -585,3 +585,39 @@ print("FORM-OK", hashlib.sha256(ok.tobytes()).hexdigest())
         assert out.returncode == 0 and "FORM-OK" in out.stdout, (form, budget, out.stderr[-1500:])
         digests.add(out.stdout.split("FORM-OK")[1].strip())
     assert len(digests) == 1
+
+
+def test_default_mode_full_batch_with_planted_bad_shares(engine, sig_workload, combined):
+    """BASELINE config 2 in the context's DEFAULT mode (every share tested for group membership, as from_bytes does once per value:
+    /root/reference/src/lib.rs:246-252) at the full 65 536 jobs, device-resident operands: since round 6 the 262 144 membership tests
+    run on the context's second stream BESIDE k_combine_fast (8 192 + 2 048 waves in flight: tc_api.hip Call::run_checks).  A
+    non-member share is planted in every 1 024th job (+3), an off-curve one in every 1 024th (+7), a non-member BEYOND the first
+    t + 1 samples in every 1 024th (+11: interpolate() never looks at it).  Every other job must equal the all-valid batch's result
+    (which test_config2 compared with Oracle B), the planted jobs must fail with TC_JOB_INVALID_ENCODING and the identity -- five
+    calls in a row without a host wait between them, all identical."""
+    import torch
+    wl = sig_workload
+    B = wl.B
+    rnd = random.Random(99)
+    outsider = u8(o.g2_uncompressed(_point_outside_g2(rnd)))
+    off_curve = wl.shares[0, 0].copy()
+    off_curve[150] ^= 1
+    n = 6                                                     # six shares per job: interpolate() takes the first four
+    shares = np.concatenate([wl.shares, wl.shares[:, :2]], axis=1).copy()
+    idx = np.concatenate([wl.idx, wl.idx[:, :2] + 100], axis=1).copy()
+    shares[3::1024, 1] = outsider
+    shares[7::1024, 2] = off_curve
+    shares[11::1024, 5] = outsider
+    bad = np.zeros(B, bool)
+    bad[3::1024] = True
+    bad[7::1024] = True
+    dev = torch.device("cuda", 0)
+    d_idx, d_sh = torch.from_numpy(idx.view(np.int64)).to(dev), torch.from_numpy(shares).to(dev)
+    assert engine.input_checks() and engine.tuning()["checks_beside"] == 1
+    outs = [engine.combine_g2(3, d_idx, d_sh) for _ in range(5)]
+    engine.sync()
+    identity = u8(o.g2_uncompressed(None))
+    for sig, st in outs:
+        sig, st = sig.cpu().numpy(), st.cpu().numpy()
+        assert ((st == 3) == bad).all() and not st[~bad].any()
+        assert (sig[~bad] == combined[~bad]).all() and (sig[bad] == identity).all()
