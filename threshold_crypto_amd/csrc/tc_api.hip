@@ -360,7 +360,7 @@ tc::Tuning tuning_from_env() {
   if (const char* e = getenv("TC_DUO_MIN")) tn.duo_min_decode = tn.duo_min_hash = (size_t)strtoull(e, nullptr, 10);
   if (const char* f = getenv("TC_PAIRING_FORM")) tn.pairing_form = f[0] == 'q' ? 1 : f[0] == 'l' ? 2 : f[0] == 'p' ? 3 : f[0] == 'f' ? 4 : 0;
   if (const char* b = getenv("TC_PAIRING_BUDGET")) tn.pairing_budget = (size_t)strtoull(b, nullptr, 10);
-  if (const char* o = getenv("TC_CHECKS_BESIDE")) tn.checks_beside = o[0] - '0';
+  if (const char* o = getenv("TC_CHECKS_BESIDE")) tn.checks_beside = (o[0] >= '0' && o[0] <= '2') ? o[0] - '0' : 1;  // 0 one stream, 1 low priority, 2 normal
   return tn;
 }
 
