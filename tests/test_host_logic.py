@@ -517,3 +517,34 @@ def test_share_maps_iterate_like_the_reference_btreemap():
     with pytest.raises(TypeError):
         api._ordered({api.Fr(1): "x", 2: "y"})
     assert api._ordered([(5, "x"), (-1, "y")]) == [(5, "x"), (-1, "y")]
+
+
+def test_compact_bench_line_never_exceeds_the_limit():
+    """bench.compact() (the line the driver parses) keeps the contract's fields, `roofline`, `cpu_baseline` and `ranks` whatever
+    happens and drops its OPTIONAL groups -- per-rank records first -- before it would reach 8 000 bytes: a 512-rank record list,
+    oversized extras and secondary legs on top of round 5's real 23 KB line still give a parseable line under the limit."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = json.loads([l for l in open(os.path.join(root, "profiles", "r05_c_bench.txt")) if l.startswith("{")][-1])
+    base = bench.compact(d)
+    assert len(base) < 4000 and json.loads(base)["secondary"]["hash_g2"]["frac"] == d["secondary_rooflines"]["hash_g2"]["frac"]
+    big = dict(d)
+    big["rank_records_start_jobs_valid_digest"] = [[131072 * r, 131072, 131072, "%064x" % r] for r in range(512)]
+    big["extras"] = dict(d["extras"], **{"extra_number_%03d" % i: float(i) for i in range(300)})
+    big["secondary_rooflines"] = dict(d["secondary_rooflines"], **{"leg_%03d" % i: d["secondary_rooflines"]["hash_g2"] for i in range(120)})
+    big["ranks"] = {"world_size": 512, "backend": "nccl", "rccl_version": "2.26.6", "devices": ["AMD Instinct MI355X gpu%d uuid-%032x" % (r, r) for r in range(512)],
+                    "launched_by": "torch.distributed.run (external launcher)"}
+    text = bench.compact(big)
+    line = json.loads(text)
+    assert len(text) < bench.LINE_LIMIT
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "ranks"):
+        assert k in line, k
+    assert line["ranks"]["distinct_devices"] == 512 and "devices" not in line["ranks"]
+    assert line["roofline"]["frac"] == d["roofline"]["frac"] and line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"]
+    assert "rank_records" not in line and "secondary" not in line          # the optional groups went first
+    assert line["config3"]["value"] == d["config3"]["value"]               # ... the BASELINE configurations stayed
