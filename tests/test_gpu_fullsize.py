@@ -621,3 +621,51 @@ def test_default_mode_full_batch_with_planted_bad_shares(engine, sig_workload, c
         sig, st = sig.cpu().numpy(), st.cpu().numpy()
         assert ((st == 3) == bad).all() and not st[~bad].any()
         assert (sig[~bad] == combined[~bad]).all() and (sig[bad] == identity).all()
+
+
+def test_operand_buffers_beyond_four_gib(engine, sig_workload, combined):
+    """Maximum sizes: ONE tc_combine_g2_batch call whose share buffer is larger than 2^32 bytes (112 x the BASELINE batch =
+    7 340 032 jobs: shares 5.6 GB, indices 235 MB, results 1.4 GB, device-resident), and ONE verify_g2 call over the same job
+    count (results + hash points 1.4 GB each).  Every tile is the BASELINE batch rotated by its tile number, so a job's
+    operands and its result sit at a different offset modulo any power of two in every tile; results must equal the
+    (Oracle-B-checked) 65 536-job result row for row, and the verifier must accept exactly the rows left unswapped."""
+    import torch
+    if B_FULL != 65536:
+        pytest.skip("full-size run only")
+    wl = sig_workload
+    reps = 112
+    free, _total = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs 40 GB of free HBM")
+    B = wl.B
+    base_idx = torch.from_numpy(wl.idx.astype(np.int64)).cuda()
+    base_sh = torch.from_numpy(wl.shares).cuda()
+    base_out = torch.from_numpy(combined).cuda()
+    base_h = torch.from_numpy(wl.hashes).cuda()
+    idx = torch.cat([torch.roll(base_idx, k, 0) for k in range(reps)])
+    sh = torch.cat([torch.roll(base_sh, k, 0) for k in range(reps)])
+    want = torch.cat([torch.roll(base_out, k, 0) for k in range(reps)])
+    assert sh.numel() > (1 << 32) and idx.shape[0] == reps * B
+    was = engine.input_checks()
+    engine.set_input_checks(False)   # (the operands are this library's own outputs; the default-mode path has its own full-size test)
+    try:
+        out, st = engine.combine_g2(3, idx, sh)
+        engine.sync()
+        assert not bool(st.any())
+        bad_rows = torch.nonzero((out != want).any(dim=1)).flatten()
+        assert bad_rows.numel() == 0, "rows differ beyond the 4 GiB mark: first %s" % bad_rows[:8].tolist()
+        del sh, idx
+        # verify_g2 over the same 7.3 M rows: every 1 000 003rd signature replaced by its neighbour's
+        hs = torch.cat([torch.roll(base_h, k, 0) for k in range(reps)])
+        swapped = torch.arange(0, reps * B, 1000003, device="cuda")
+        sig = out.clone()
+        sig[swapped] = out[swapped + 1]
+        ok = engine.verify_g2(torch.from_numpy(wl.master_pk).cuda(), sig, hs)
+        engine.sync()
+        ok = ok.bool()
+        expect = torch.ones(reps * B, dtype=torch.bool, device="cuda")
+        expect[swapped] = False
+        assert bool((ok == expect).all()), "verify_g2 verdicts differ at rows %s" % torch.nonzero(ok != expect).flatten()[:8].tolist()
+    finally:
+        engine.set_input_checks(was)
+        engine.trim()
