@@ -669,3 +669,34 @@ def test_operand_buffers_beyond_four_gib(engine, sig_workload, combined):
     finally:
         engine.set_input_checks(was)
         engine.trim()
+
+
+def test_message_blob_beyond_four_gib(engine):
+    """Maximum sizes on the message side: ONE tc_hash_g2_batch call over 4 718 592 messages of 1 024 bytes -- a 4.8 GB blob,
+    u64 offsets past 2^32, device-resident; every tile repeats the same 65 536 messages, so every tile must reproduce the first
+    tile's points, and the first tile is checked against Oracle B on a sample."""
+    import torch
+    if B_FULL != 65536:
+        pytest.skip("full-size run only")
+    free, _total = torch.cuda.mem_get_info()
+    if free < 24 << 30:
+        pytest.skip("needs 24 GB of free HBM")
+    c.load()
+    L, B, reps = 1024, 65536, 72
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x7C5EED)
+    base = torch.randint(0, 256, (B, L), dtype=torch.uint8, device="cuda", generator=gen)
+    blob = base.repeat(reps, 1).reshape(-1)
+    off = torch.arange(0, reps * B + 1, dtype=torch.int64, device="cuda") * L
+    assert blob.numel() > (1 << 32) and int(off[-1]) == blob.numel()
+    out = engine.hash_g2(blob, off)
+    engine.sync()
+    first = out[:B]
+    diff = torch.nonzero((out.view(reps, B, 192) != first[None]).any(dim=2).any(dim=1)).flatten()
+    assert diff.numel() == 0, "tiles %s differ from the first" % diff[:8].tolist()
+    host_msgs = base[::4099].cpu().numpy()
+    got = first[::4099].cpu().numpy()
+    for k in range(host_msgs.shape[0]):
+        assert c.hash_g2(bytes(host_msgs[k])) == bytes(got[k]), "hash_g2 differs from Oracle B at message %d" % (k * 4099)
+    del blob, out
+    engine.trim()
