@@ -4,7 +4,8 @@
 //! Drop-in: the single-item methods of the crate stay as they are (the `pairing` crate on the CPU); every method here is
 //! the same computation for B independent jobs and returns exactly what B calls of the single-item method return -- the
 //! library's results are bit-identical encodings of the same group elements.  The module lives INSIDE the crate because
-//! the tuple fields of `PublicKey(G1)`, `Signature(G2)`, `SecretKey(Box<Fr>)`, ... are private (src/lib.rs:80,194,296).
+//! the tuple fields of `PublicKey(G1)`, `Signature(G2)`, `SecretKey(Fr)`, ... are private (src/lib.rs:79,202,302) and
+//! `Commitment::coeff` / `Poly::coeff` are `pub(super)` (src/poly.rs:43,432).
 //!
 //! NO PANICS (SURVEY 8b "Errors"; the reference's hot path returns `Result` / `Option` / `bool`, src/error.rs:7-17, src/lib.rs:608-626):
 //! every method here returns `GpuResult<_>`.  A call-level failure of the library (TC_ERR_HIP from a failed hipMalloc, a lost device,
@@ -38,7 +39,7 @@ use crate::{
     Ciphertext, DecryptionShare, Fr, G1Affine, G2Affine, IntoFr, PublicKey, PublicKeySet, PublicKeyShare, SecretKey, SecretKeySet,
     SecretKeyShare, Signature, SignatureShare, G1, G2, PK_SIZE, SIG_SIZE,
 };
-use ff::{PrimeField, PrimeFieldRepr};
+use ff::{Field, PrimeField, PrimeFieldRepr};
 use group::{CurveAffine, CurveProjective, EncodedPoint};
 use pairing::bls12_381::{FrRepr, G1Uncompressed, G2Uncompressed};
 use std::os::raw::c_int;
@@ -291,7 +292,9 @@ impl SecretKeySet {
         table.iter_mut().for_each(|x| *x = 0);
         gpu.check(rc)?;
         all_ok(&st)?;
-        out.chunks(n * G2_BYTES).map(|job| Ok(g2_vec(job)?.into_iter().map(|p| SignatureShare(Signature(p))).collect())).collect()
+        out.chunks(n * G2_BYTES)
+            .map(|job| -> GpuResult<Vec<SignatureShare>> { Ok(g2_vec(job)?.into_iter().map(|p| SignatureShare(Signature(p))).collect()) })
+            .collect()
     }
 }
 
@@ -580,12 +583,13 @@ impl PublicKey {
         gpu.check(unsafe { tc_verify_sig_rlc_batch(gpu.0, pk.as_ptr(), s.as_ptr(), flat.as_ptr(), off.as_ptr(), sigs.len(), 0, seed.as_ptr(), ok.as_mut_ptr(), &mut fallback) })?;
         Ok(ok.into_iter().map(|b| b == 1).collect())
     }
-    /// `encrypt_with_rng` for B messages (src/lib.rs:128-137); the Fr draws come from the caller's RNG, in order.
-    pub fn encrypt_batch<R: rand::Rng, M: AsRef<[u8]>>(&self, gpu: &Gpu, rng: &mut R, msgs: &[M]) -> GpuResult<Vec<Ciphertext>> {
+    /// `encrypt_with_rng` for B messages (src/lib.rs:128-137); the Fr draws come from the caller's RNG, in order
+    /// (`Fr::random(rng)` per message, as at src/lib.rs:129).
+    pub fn encrypt_batch<R: rand::RngCore, M: AsRef<[u8]>>(&self, gpu: &Gpu, rng: &mut R, msgs: &[M]) -> GpuResult<Vec<Ciphertext>> {
         let pk = g1_bytes(&self.0);
         let mut r = Vec::with_capacity(msgs.len() * FR_BYTES);
         for _ in msgs {
-            let f: Fr = rng.gen04();
+            let f: Fr = Fr::random(rng);
             r.extend_from_slice(&fr_bytes(&f));
         }
         let (flat, off) = pack_messages(msgs);
@@ -597,7 +601,9 @@ impl PublicKey {
         gpu.check(rc)?;
         all_ok(&st)?;
         (0..msgs.len())
-            .map(|j| Ok(Ciphertext(g1_from(&u[j * G1_BYTES..(j + 1) * G1_BYTES])?, v[off[j] as usize..off[j + 1] as usize].to_vec(), g2_from(&w[j * G2_BYTES..(j + 1) * G2_BYTES])?)))
+            .map(|j| -> GpuResult<Ciphertext> {
+                Ok(Ciphertext(g1_from(&u[j * G1_BYTES..(j + 1) * G1_BYTES])?, v[off[j] as usize..off[j + 1] as usize].to_vec(), g2_from(&w[j * G2_BYTES..(j + 1) * G2_BYTES])?))
+            })
             .collect()
     }
 }
@@ -703,7 +709,7 @@ pub fn bivar_commitment_rows(gpu: &Gpu, c: &BivarCommitment, xs: &[u64]) -> GpuR
     let (mut out, mut st) = (vec![0u8; xs.len() * (d + 1) * G1_BYTES], vec![0u8; xs.len() * (d + 1)]);
     gpu.check(unsafe { tc_bivar_commitment_row_batch(gpu.0, inp.as_ptr(), d, xs.as_ptr(), xs.len(), out.as_mut_ptr(), st.as_mut_ptr()) })?;
     all_ok(&st)?;
-    out.chunks((d + 1) * G1_BYTES).map(|row| Ok(Commitment { coeff: g1_vec(row)? })).collect()
+    out.chunks((d + 1) * G1_BYTES).map(|row| -> GpuResult<Commitment> { Ok(Commitment { coeff: g1_vec(row)? }) }).collect()
 }
 /// `Poly::interpolate` for B sample sets of n points each.
 pub fn interpolate_batch(gpu: &Gpu, samples: &[Vec<(Fr, Fr)>]) -> GpuResult<Vec<JobResult<Poly>>> {
