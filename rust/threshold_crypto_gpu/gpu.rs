@@ -33,13 +33,13 @@
 //!   f3  PublicKey::encrypt              PublicKey::encrypt_batch
 //!   f4  Poly::commitment, BivarCommitment::row, Poly::interpolate   commitment_batch, bivar_commitment_rows, interpolate_batch
 //!   (e) several GPUs of one node        GpuGroup
-use crate::error::{Error, FromBytesError, Result};
+use crate::error::{Error, FromBytesError};
 use crate::poly::{BivarCommitment, Commitment, Poly};
 use crate::{
-    Ciphertext, DecryptionShare, Fr, G1Affine, G2Affine, IntoFr, PublicKey, PublicKeySet, PublicKeyShare, SecretKey, SecretKeySet,
+    Ciphertext, DecryptionShare, Fr, G2Affine, IntoFr, PublicKey, PublicKeySet, PublicKeyShare, SecretKey, SecretKeySet,
     SecretKeyShare, Signature, SignatureShare, G1, G2, PK_SIZE, SIG_SIZE,
 };
-use ff::{Field, PrimeField, PrimeFieldRepr};
+use ff::{Field, PrimeField};
 use group::{CurveAffine, CurveProjective, EncodedPoint};
 use pairing::bls12_381::{FrRepr, G1Uncompressed, G2Uncompressed};
 use std::os::raw::c_int;
