@@ -700,3 +700,37 @@ def test_message_blob_beyond_four_gib(engine):
         assert c.hash_g2(bytes(host_msgs[k])) == bytes(got[k]), "hash_g2 differs from Oracle B at message %d" % (k * 4099)
     del blob, out
     engine.trim()
+
+
+def test_threshold_above_the_256_sample_boundary_vs_oracle(engine):
+    """Maximum thresholds: t = 299 (300 samples per job, one surplus) in BOTH groups -- past kLagMaxN = 256, where the Lagrange
+    stage falls back to one lane per job (k_lagrange_all) and the two-stage kernels walk 300 tables per job -- and t = 255 /
+    t = 256 either side of that boundary.  Shares made on the device from a random polynomial; every job against Oracle B, job 0
+    against [f(0)] h; a repeated index and an unsorted head as in the t = 9 / 21 test."""
+    rnd = random.Random(299)
+    for t, B in ((255, 5), (256, 5), (299, 9)):
+        N = t + 40
+        poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+        fr = np.stack([u8(o.secret_key_share(poly, i).to_bytes(32, "little")) for i in range(N)])
+        h2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+        h1 = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+        s2, st = engine.g2_mul(fr, u8(o.g2_uncompressed(h2))[None])      # (1, N, 192): every node's share of ONE hash point
+        s1, st1 = engine.g1_mul(fr, u8(o.g1_uncompressed(h1))[None])
+        assert not st.any() and not st1.any()
+        idx = np.zeros((B, t + 2), dtype=np.uint64)
+        for j in range(B):
+            idx[j] = sorted(rnd.sample(range(N), t + 2))
+        idx[1, 7] = idx[1, 3]                                   # duplicate index (filtered by value, src/lib.rs:758)
+        idx[2, :4] = idx[2, :4][::-1].copy()                    # unsorted head
+        sh2 = np.ascontiguousarray(s2[0][idx.astype(np.int64)])
+        sh1 = np.ascontiguousarray(s1[0][idx.astype(np.int64)])
+        out2, st2 = engine.combine_g2(t, idx, sh2)
+        out1, st1 = engine.combine_g1(t, idx, sh1)
+        assert not st2.any() and not st1.any()
+        for j in range(B):
+            ids = [int(i) for i in idx[j]]
+            rc, want = c.combine_g2(t, ids, [bytes(x) for x in sh2[j]])
+            assert rc == 0 and bytes(out2[j]) == want, (t, j)
+            rc, want = c.combine_g1(t, ids, [bytes(x) for x in sh1[j]])
+            assert rc == 0 and bytes(out1[j]) == want, (t, j)
+        assert bytes(out2[0]) == o.g2_uncompressed(o.E2.mul(h2, poly[0])) and bytes(out1[0]) == o.g1_uncompressed(o.E1.mul(h1, poly[0]))

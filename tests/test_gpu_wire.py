@@ -560,3 +560,43 @@ def test_membership_tests_beside_the_main_kernels_equal_the_one_stream_order(eng
                 assert (g == x).all()
         # ... and the planted operands did fail their jobs (the tests ran): statuses / ok of the checked entries are not all-OK
         assert want[1].any() and not want[4].all() and not want[6].all() and want[9].any() and not want[11].all() and want[15].any()
+
+
+def test_ragged_and_megabyte_plaintexts_encrypt_verify_decrypt_vs_oracle(engine, rnd):
+    """Maximum sizes on the plaintext side: PublicKey::encrypt_with_rng (src/lib.rs:128-137), Ciphertext::verify (:508-512) and
+    SecretKey::decrypt (:384-391) over ONE batch whose plaintexts are 0, 1, 15, 16, 17, 63, 64, 65 (both sides of hash_g1_g2's
+    64-byte switch), 1 023, 4 096, 65 537 and 1 048 576 bytes long -- xor_with_hash draws one ChaCha word per BYTE, so the last
+    job walks 65 536 keystream blocks in one lane while its neighbours finished long ago.  Every ciphertext equals Oracle B's
+    composition (u = [r] g1, v = xor_with_hash([r] pk, m), w = [r] hash_g1_g2(u, v)), verifies in both, and decrypts to m."""
+    lens = [0, 1, 15, 16, 17, 63, 64, 65, 1023, 4096, 65537, 1 << 20]
+    B = len(lens)
+    sk = rnd.randrange(1, o.R)
+    pk = u8(o.g1_uncompressed(o.E1.mul(o.G1_GEN, sk)))
+    rs = np.random.RandomState(20261001)
+    msgs = [rs.randint(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
+    flat, off = pack_messages(msgs)
+    r = np.stack([u8(rnd.randrange(1, o.R).to_bytes(32, "little")) for _ in range(B)])
+    u, v, w, st = engine.encrypt(pk, r, flat, off)
+    assert not st.any()
+    g1_gen = o.g1_uncompressed(o.G1_GEN)
+    for j in range(B):
+        vj = bytes(v[int(off[j]):int(off[j + 1])])
+        rc, uj = c.g1_mul(bytes(r[j]), g1_gen)
+        assert rc == 0 and bytes(u[j]) == uj, j
+        rc, g = c.g1_mul(bytes(r[j]), bytes(pk))
+        rc2, want_v = c.xor_with_hash(g, msgs[j])
+        assert rc == 0 and rc2 == 0 and vj == want_v, "v of the %d-byte plaintext" % lens[j]
+        rc, h = c.hash_g1_g2(uj, vj)
+        rc2, wj = c.g2_mul(bytes(r[j]), h)
+        assert rc == 0 and rc2 == 0 and bytes(w[j]) == wj, j
+        assert c.ciphertext_verify(uj, vj, wj), j
+    assert engine.ciphertext_verify(u, v, off, w).all()
+    fr = u8(sk.to_bytes(32, "little"))
+    plain, ok = engine.secret_key_decrypt(fr, u, v, off, w)
+    assert ok.all() and bytes(plain[: int(off[-1])]) == b"".join(msgs)
+    # one flipped byte in the middle of the megabyte: that job alone fails, and returns zeros
+    v2 = v.copy()
+    v2[int(off[B - 1]) + (1 << 19)] ^= 0x80
+    plain2, ok2 = engine.secret_key_decrypt(fr, u, v2, off, w)
+    assert ok2.tolist() == [1] * (B - 1) + [0]
+    assert bytes(plain2[: int(off[B - 1])]) == b"".join(msgs[:-1]) and not plain2[int(off[B - 1]):int(off[B])].any()
