@@ -33,7 +33,11 @@
  * I/O residency: by default every data pointer is HOST memory and the call stages through
  * device buffers owned by the context.  After tc_ctx_set_device_io(ctx, 1) every data
  * pointer (inputs, outputs, offsets, status, ok) must be DEVICE memory on the context's GPU,
- * 8-byte aligned, and nothing crosses PCIe.
+ * 8-byte aligned, and nothing crosses PCIe.  Output buffers should not overlap input buffers: results are written while
+ * other jobs' operands are still being read.  The one supported exception is an output that overlaps a POINT operand of the
+ * same call job for job (an in-place tc_g{1,2}_mul_batch with S = 1, ok[] over the head of a buffer the call reads): the
+ * membership tests of that operand, which otherwise run beside the call's main kernels on the context's second stream, then
+ * run in front of them on the main stream.
  *
  * Threading: a context is bound to one GPU and one HIP stream and is thread-compatible (one
  * thread at a time); distinct contexts may be used concurrently (one per GPU, or several on one GPU

@@ -600,3 +600,49 @@ def test_ragged_and_megabyte_plaintexts_encrypt_verify_decrypt_vs_oracle(engine,
     plain2, ok2 = engine.secret_key_decrypt(fr, u, v2, off, w)
     assert ok2.tolist() == [1] * (B - 1) + [0]
     assert bytes(plain2[: int(off[B - 1])]) == b"".join(msgs[:-1]) and not plain2[int(off[B - 1]):int(off[B])].any()
+
+
+def test_in_place_device_calls_keep_the_tests_in_front(engine, rnd):
+    """A deferred membership test reads its operand on the second stream WHILE the main kernels write their results: when the
+    caller's output buffer IS the operand (device-resident, S = 1 multiplication in place; verify_g2's ok bytes written over the
+    head of the signature buffer) the call must behave like a one-stream context -- tests first (tc_api.hip Call::out /
+    check_points: an operand that overlaps an output is not deferred).  Same bytes and statuses as the out-of-place call,
+    non-members and an off-curve point planted, at a batch with several waves per SIMD and at a small one.  (A regression test
+    of the in-place semantics, not a reproducer: the stale read needs the low-priority tests to start AFTER a main wave wrote its
+    result, i.e. a saturated device, and the library before the change passed this test too.)"""
+    import torch
+    from threshold_crypto_amd.engine import _ptr
+    assert engine.input_checks()
+    for B in (33, 40000):
+        ks = [rnd.randrange(1, o.R) for _ in range(8)]
+        base = np.stack([u8(o.g2_uncompressed(o.E2.mul(o.G2_GEN, k))) for k in ks])
+        pts = np.ascontiguousarray(base[np.arange(B) % 8])
+        bad = sorted(rnd.sample(range(B), 5))
+        for n, j in enumerate(bad):
+            pts[j] = u8(o.g2_uncompressed(non_member_g2(rnd)))
+            if n == 4:
+                pts[j, 100] ^= 1                                   # not even on the curve
+        fr = u8(o.fr_to_bytes(rnd.randrange(1, o.R)))[None]
+        want, want_st = engine.g2_mul(fr, pts)                     # host buffers, out of place
+        assert sorted(np.flatnonzero(want_st[:, 0]).tolist()) == bad
+        d_fr, d_pts = torch.from_numpy(fr).cuda(), torch.from_numpy(pts).cuda()
+        d_st = torch.empty((B, 1), dtype=torch.uint8, device="cuda")
+        engine._mode(d_fr, d_pts, d_st)
+        engine._call("tc_g2_mul_batch", _ptr(d_fr), _ptr(d_pts), 1, B, _ptr(d_pts), _ptr(d_st))      # out == pts
+        engine.sync()
+        assert (d_st.cpu().numpy() == want_st).all()
+        assert (d_pts.cpu().numpy() == want[:, 0]).all()
+    # verify_g2 with its ok bytes written INTO the signature buffer it reads
+    B = 20000
+    from threshold_crypto_amd.workload import ThresholdSigWorkload
+    wl = ThresholdSigWorkload(engine, 3, 10, B)
+    sig, st = engine.combine_g2(3, wl.idx, wl.shares)
+    sig[7] = u8(o.g2_uncompressed(non_member_g2(rnd)))
+    sig[9] = sig[10]
+    want = engine.verify_g2(wl.master_pk, sig, wl.hashes)
+    assert want.tolist()[:12] == [1] * 7 + [0, 1, 0, 1, 1]
+    d_pk, d_sig, d_h = (torch.from_numpy(x).cuda() for x in (wl.master_pk, sig, wl.hashes))
+    engine._mode(d_pk, d_sig, d_h)
+    engine._call("tc_verify_g2_batch", _ptr(d_pk), 0, _ptr(d_sig), _ptr(d_h), B, _ptr(d_sig))          # ok == sig
+    engine.sync()
+    assert (d_sig.reshape(-1)[:B].cpu().numpy() == want).all()

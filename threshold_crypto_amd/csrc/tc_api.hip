@@ -75,8 +75,20 @@ struct Call {
     bool g2 = false;
     const uint8_t* pts = nullptr;
     size_t stride = 0, n_per_job = 0, take = 0, n = 0;
+    size_t bytes = 0;  // extent of the operand the deferred test reads (records * n_per_job * stride)
   };
   std::vector<Pending> checks;  // checked-input mode: validity bytes waiting to be applied to the jobs
+  // device-io mode: the caller's output buffers.  A deferred membership test reads its operand WHILE the main kernels write
+  // their results, so an operand that overlaps an output (an in-place call) keeps the order of a one-stream context: test first.
+  std::vector<std::pair<const uint8_t*, size_t>> out_ranges;
+  static bool ranges_overlap(const uint8_t* a, size_t na, const uint8_t* b, size_t nb) {
+    return a && b && na && nb && (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
+  }
+  bool overlaps_output(const uint8_t* p, size_t n) const {
+    for (auto& r : out_ranges)
+      if (ranges_overlap(p, n, r.first, r.second)) return true;
+    return false;
+  }
 
   explicit Call(tc_ctx* ctx) : c(ctx) {
     c->next_slot = 0;
@@ -143,6 +155,11 @@ struct Call {
       d = (T*)scratch(n);
       if (!d) return nullptr;
       outs.push_back({p, d, n});
+    } else if (n) {
+      out_ranges.emplace_back((const uint8_t*)d, n);
+      // (an operand registered before this output and deferred already: test it now, on the main stream, before anything writes)
+      for (auto& pc : checks)
+        if (pc.pts && ranges_overlap(pc.pts, pc.bytes, (const uint8_t*)d, n)) launch_pending(pc, c->stream);
     }
     if (zero && n) check(hipMemsetAsync(d, 0, n, c->stream), "memset");
     return d;
@@ -171,6 +188,7 @@ struct Call {
       group = (size_t)-1;
     }
     const size_t n = records * take;
+    const size_t bytes = records * n_per_job * stride;
     uint8_t* v = temp<uint8_t>(n);
     if (!v) return;
     // The tests are NOT launched here.  They read operands only and nothing reads their verdict before apply_checks, so they
@@ -178,9 +196,9 @@ struct Call {
     // that ends with idle SIMDs -- the 65 536-job combination's last third, DESIGN.md 5.2 -- gets its tail filled (default-mode
     // combine_signatures 10.2 -> 9.3 ms per call, profiles/r06_checks_beside_ab.txt), and a small batch runs both at once.
     // ev_fork marks where the operands are ready in the main stream (every check_points call precedes the main kernels).
-    const bool beside = c->tuning.checks_beside && side_stream_ready();
+    const bool beside = c->tuning.checks_beside && !overlaps_output(d_pts, bytes) && side_stream_ready();
     if (beside && !check(hipEventRecord(c->ev_fork, c->stream), "event record")) return;
-    checks.push_back({v, take, group, g2, d_pts, stride, n_per_job, take, n});
+    checks.push_back({v, take, group, g2, d_pts, stride, n_per_job, take, n, bytes});
     if (!beside) launch_pending(checks.back(), c->stream);
   }
   // the context's second stream, made on first use: non-blocking and of the LOWEST priority the device offers, so that its
