@@ -195,3 +195,48 @@ def test_comb_signing_many_signers_vs_oracle(engine, wl):
     # a small batch of the same jobs takes the ladders with fewer signers per lane pair: same bytes
     outs, sts = engine.sign_shares_g2(sk, np.ascontiguousarray(idx[:200]), np.ascontiguousarray(pts[:200]))
     assert (outs == out[:200]).all() and (sts == st[:200]).all()
+
+
+def test_failed_device_allocation_is_an_error_and_the_context_survives(engine, wl):
+    """SURVEY 8b "no panics on the hot path" at the C ABI: with the HBM full, the first G2 call of a FRESH context cannot allocate
+    its 256 MB table arena -- the call must come back TC_ERR_HIP with the allocator's message (the Rust shim turns that into
+    Err(GpuError), rust/threshold_crypto_gpu/gpu.rs check()), not abort, not hang, not return stale bytes; and once memory is
+    free again the SAME context must work: no sticky HIP error, no half-built arena.  Same for a staging slot that cannot grow."""
+    import torch
+    from threshold_crypto_amd.engine import Engine, TcError
+    from threshold_crypto_amd import _native
+    B = 256
+    idx, shares = np.ascontiguousarray(wl.idx[:B]), np.ascontiguousarray(wl.shares[:B])
+    want, st = engine.combine_g2(wl.t, idx, shares)
+    assert not st.any()
+    eng = Engine(0)                      # fresh: no arena, no staging slots yet
+    eng.set_input_checks(False)
+    torch.cuda.empty_cache()
+    hogs = []
+    try:
+        free, _total = torch.cuda.mem_get_info()
+        hogs.append(torch.empty(max(free - (1 << 30), 0), dtype=torch.uint8, device="cuda"))      # all but 1 GiB ...
+        while True:                                                                               # ... then down to < 48 MB
+            free, _total = torch.cuda.mem_get_info()
+            if free < (48 << 20):
+                break
+            hogs.append(torch.empty(max(free // 2, 16 << 20), dtype=torch.uint8, device="cuda"))
+    except torch.OutOfMemoryError:
+        pass
+    free, _total = torch.cuda.mem_get_info()
+    assert free < (200 << 20), "could not fill the HBM (free %d MB)" % (free >> 20)
+    try:
+        with pytest.raises(TcError) as e:
+            eng.combine_g2(wl.t, idx, shares)
+        assert e.value.code == _native.TC_ERR_HIP and "hipMalloc" in str(e.value), str(e.value)
+        with pytest.raises(TcError) as e2:                                                         # and again: still an error, still no abort
+            eng.combine_g2(wl.t, idx, shares)
+        assert e2.value.code == _native.TC_ERR_HIP
+    finally:
+        del hogs
+        torch.cuda.empty_cache()
+    got, st = eng.combine_g2(wl.t, idx, shares)                                                    # the same context, memory free again
+    assert not st.any() and (got == want).all()
+    ok = eng.verify_g2(wl.master_pk, got, np.ascontiguousarray(wl.hashes[:B]))
+    assert ok.all()
+    eng.close()

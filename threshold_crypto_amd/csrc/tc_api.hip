@@ -94,6 +94,11 @@ struct Call {
     c->next_slot = 0;
     c->err.clear();
     if (hipSetDevice(c->device) != hipSuccess) fail("hipSetDevice failed");
+    // hipGetLastError() is how finish() learns of a failed kernel LAUNCH, and the runtime keeps the last error of this host thread
+    // until somebody reads it: a hipMalloc that failed in an EARLIER call (HBM full) would otherwise be reported, as "kernel
+    // launch: out of memory", by the first call that runs after the memory came back
+    // (tests/test_gpu_tables.py::test_failed_device_allocation_is_an_error_and_the_context_survives).  A call starts clean.
+    (void)hipGetLastError();
   }
   void fail(const std::string& m) {
     if (!failed) c->err = m;
@@ -108,10 +113,16 @@ struct Call {
   }
   // the table arena of the G2 ladder kernels (tc_table.h)
   tc::TableArena tables() {
-    if (!c->tbl_mem && !failed) {
-      if (check(hipMalloc((void**)&c->tbl_mem, tc::kTableArenaWords * sizeof(int32_t)), "hipMalloc") &&
-          check(hipMalloc((void**)&c->tbl_flags, tc::kTableArenaFlags * sizeof(uint32_t)), "hipMalloc"))
-        check(hipMemsetAsync(c->tbl_flags, 0, tc::kTableArenaFlags * sizeof(uint32_t), c->stream), "memset");
+    // (either half may be missing: an earlier call can have failed between the two allocations -- HBM full -- and a launcher
+    // handed an arena without flags returns without doing anything)
+    if ((!c->tbl_mem || !c->tbl_flags) && !failed) {
+      if (!c->tbl_mem && !check(hipMalloc((void**)&c->tbl_mem, tc::kTableArenaWords * sizeof(int32_t)), "hipMalloc")) c->tbl_mem = nullptr;
+      if (!failed && !c->tbl_flags) {
+        if (check(hipMalloc((void**)&c->tbl_flags, tc::kTableArenaFlags * sizeof(uint32_t)), "hipMalloc"))
+          check(hipMemsetAsync(c->tbl_flags, 0, tc::kTableArenaFlags * sizeof(uint32_t), c->stream), "memset");
+        else
+          c->tbl_flags = nullptr;
+      }
     }
     if (c->tbl_flags && c->tbl_reset && !failed) {
       // stream-ordered after whatever ran before; nothing of this context is in flight beyond the stream
@@ -128,7 +139,10 @@ struct Call {
       s.p = nullptr;
       s.cap = 0;
       size_t cap = n + n / 4 + 256;
-      if (!check(hipMalloc(&s.p, cap), "hipMalloc")) return nullptr;
+      if (!check(hipMalloc(&s.p, cap), "hipMalloc")) {
+        s.p = nullptr;  // (whatever the failed call left in the slot is not a pointer to free later)
+        return nullptr;
+      }
       s.cap = cap;
     }
     return s.p;
@@ -272,6 +286,7 @@ struct Call {
       if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     }
     if (failed && !arg_error) c->tbl_reset = true;
+    if (failed) (void)hipGetLastError();  // this call's own failure has been reported through `err`: do not leave it for the caller's next HIP check
     return failed ? (arg_error ? TC_ERR_INVALID_ARG : TC_ERR_HIP) : TC_OK;
   }
 };
@@ -419,6 +434,7 @@ int tc_ctx_create(tc_ctx** out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount;
   }
+  (void)hipGetLastError();  // (whatever this thread's earlier HIP calls left behind is not this launch's)
   tc::launch_fill_g1_generator(c->stream, c->g1_gen, c->g1_gen_unfix);
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
     // typically: no gfx950 code object for this device
@@ -1503,6 +1519,8 @@ int tc_g1_commitment_batch(tc_ctx* ctx, const uint8_t* coeff_fr, size_t M, uint8
   if (!ctx->fb_table && !k.failed) {
     if (k.check(hipMalloc((void**)&ctx->fb_table, tc::fixed_base_table_bytes()), "hipMalloc"))
       tc::launch_fixed_base_table(ctx->stream, ctx->fb_table);
+    else
+      ctx->fb_table = nullptr;
   }
   const uint8_t* d_fr = k.in(coeff_fr, M * 32, /*secret=*/true);
   uint8_t* d_out = k.out(out, M * 96);
