@@ -450,6 +450,7 @@ void tc_ctx_destroy(tc_ctx* c) {
   (void)hipSetDevice(c->device);
   // device-I/O calls may still be running on the context's (or the caller's) stream: nothing is freed under them
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);  // (joined into the main stream by every call that completed; a call that FAILED between launch and join is the exception)
   for (auto& s : c->slots)
     if (s.p) (void)hipFree(s.p);
   if (c->g1_gen) (void)hipFree(c->g1_gen);
@@ -459,10 +460,7 @@ void tc_ctx_destroy(tc_ctx* c) {
   if (c->tbl_flags) (void)hipFree(c->tbl_flags);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->side_stream) {
-    (void)hipStreamSynchronize(c->side_stream);
-    (void)hipStreamDestroy(c->side_stream);
-  }
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
