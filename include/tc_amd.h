@@ -25,8 +25,8 @@
  * tc_g{1,2}_subgroup_check_batch; typically device-resident data -- opts out with
  * tc_ctx_set_input_checks(ctx, 0) and saves one 64-bit ladder per G2 operand and two per G1 operand.
  *
- * Return value: 0 = TC_OK, < 0 = call-level failure (bad argument / HIP error / no device);
- * never aborts, never throws across the boundary.  Per-job results go to `status[]`
+ * Return value: 0 = TC_OK, < 0 = call-level failure (bad argument / HIP error / no device / host failure);
+ * never aborts, never throws across the boundary (every entry is a function-try-block: an exception becomes TC_ERR_HOST).  Per-job results go to `status[]`
  * (mirrors threshold_crypto::error::Error / FromBytesError, src/error.rs:7-17,37-41) and
  * `ok[]` (the `bool` of the verify methods).
  *
@@ -58,6 +58,7 @@ extern "C" {
 #define TC_ERR_INVALID_ARG (-1)
 #define TC_ERR_HIP (-2)
 #define TC_ERR_NO_DEVICE (-3)
+#define TC_ERR_HOST (-4) /* a host-side failure (std::bad_alloc, any C++ exception) stopped at the boundary */
 
 /* per-job status codes */
 #define TC_JOB_OK 0

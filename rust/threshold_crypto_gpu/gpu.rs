@@ -53,7 +53,7 @@ pub const FR_BYTES: usize = 32;
 pub struct Gpu(*mut TcCtx);
 unsafe impl Send for Gpu {}
 
-/// A call-level failure: the library's return code (TC_ERR_INVALID_ARG / TC_ERR_HIP / TC_ERR_NO_DEVICE, or GPU_ERR_BAD_ANSWER for
+/// A call-level failure: the library's return code (TC_ERR_INVALID_ARG / TC_ERR_HIP / TC_ERR_NO_DEVICE / TC_ERR_HOST, or GPU_ERR_BAD_ANSWER for
 /// bytes the shim could not turn back into a group element) and its message (`tc_last_error`).  The context stays usable.
 #[derive(Debug, Clone, PartialEq)]
 pub struct GpuError(pub c_int, pub String);

@@ -245,3 +245,32 @@ print("BAD", bad)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
     assert "BAD []" in out.stdout, out.stdout[-2000:]
+
+
+def test_every_entry_point_stops_exceptions_at_the_boundary():
+    """include/tc_amd.h promises "never throws across the boundary": every int- or void-returning entry point of the C ABI whose body
+    is more than one expression is a function-try-block that ends in on_exception (TC_ERR_HOST); worker threads of the group API catch
+    too.  An exception that reached Rust or ctypes would be undefined behaviour."""
+    declared = set(_declared())
+    seen = set()
+    for name in ("tc_api.hip", "tc_group.hip"):
+        before = len(seen)
+        lines = open(os.path.join(ROOT, "threshold_crypto_amd", "csrc", name)).read().split("\n")
+        i = 0
+        while i < len(lines):
+            m = re.match(r"^(int|void) (tc_\w+)\(", lines[i])
+            if m and m.group(2) in declared and not lines[i].rstrip().endswith(";"):
+                j = i
+                while not lines[j].rstrip().endswith("{") and not lines[j].rstrip().endswith("}"):
+                    j += 1
+                one_liner = lines[j].rstrip().endswith("}") and "{" in lines[j]
+                assert one_liner or lines[j].rstrip().endswith("try {"), "%s: %s is not a function-try-block" % (name, m.group(2))
+                if not one_liner:
+                    seen.add(m.group(2))
+                i = j
+            i += 1
+        text = "\n".join(lines)
+        assert text.count("} catch (...) {") >= len(seen) - before, name
+    assert len(seen) >= 55, sorted(seen)
+    assert "rc = TC_ERR_HOST" in open(os.path.join(ROOT, "threshold_crypto_amd", "csrc", "tc_group.hip")).read()
+    assert "TC_ERR_HOST" in open(os.path.join(ROOT, "include", "tc_amd.h")).read() and _native.TC_ERR_HOST == -4

@@ -13,6 +13,7 @@ TC_OK = 0
 TC_ERR_INVALID_ARG = -1
 TC_ERR_HIP = -2
 TC_ERR_NO_DEVICE = -3
+TC_ERR_HOST = -4
 
 JOB_OK = 0
 JOB_NOT_ENOUGH_SHARES = 1

@@ -6,6 +6,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -407,11 +408,36 @@ tc::Tuning tuning_from_env() {
 
 }  // namespace
 
+// "never throws across the boundary" (include/tc_amd.h): every entry point below is a function-try-block that ends here.
+// The host code allocates (std::vector, std::string); under memory pressure that throws, and an exception that crossed the C ABI
+// into Rust or ctypes would be undefined behaviour.  The context stays usable: the arena flags are reset before the next use.
+static int on_exception(tc_ctx* ctx) noexcept {
+  const char* what = "C++ exception";
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    what = "host allocation failed (std::bad_alloc)";
+  } catch (const std::exception&) {
+    what = "C++ exception in the host code";
+  } catch (...) {
+  }
+  if (ctx) {
+    ctx->tbl_reset = true;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+    try {
+      ctx->err = what;
+    } catch (...) {
+    }
+  }
+  return TC_ERR_HOST;
+}
+
 extern "C" {
 
 const char* tc_version(void) { return "tc_amd 0.1.0 (gfx950)"; }
 
-int tc_ctx_create(tc_ctx** out, int device) {
+int tc_ctx_create(tc_ctx** out, int device) try {
   if (!out) return TC_ERR_INVALID_ARG;
   *out = nullptr;
   int n = 0;
@@ -443,9 +469,11 @@ int tc_ctx_create(tc_ctx** out, int device) {
   }
   *out = c;
   return TC_OK;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
-void tc_ctx_destroy(tc_ctx* c) {
+void tc_ctx_destroy(tc_ctx* c) try {
   if (!c) return;
   (void)hipSetDevice(c->device);
   // device-I/O calls may still be running on the context's (or the caller's) stream: nothing is freed under them
@@ -465,28 +493,35 @@ void tc_ctx_destroy(tc_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+} catch (...) {
 }
 
-int tc_ctx_set_device_io(tc_ctx* ctx, int enabled) {
+int tc_ctx_set_device_io(tc_ctx* ctx, int enabled) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   ctx->device_io = enabled != 0;
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream) {
+int tc_ctx_set_stream(tc_ctx* ctx, void* hip_stream) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_ctx_set_input_checks(tc_ctx* ctx, int enabled) {
+int tc_ctx_set_input_checks(tc_ctx* ctx, int enabled) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   ctx->input_checks = enabled != 0;
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // gives the context's grow-only staging / table buffers back to the device (they are allocated again on demand)
-int tc_ctx_trim(tc_ctx* ctx) {
+int tc_ctx_trim(tc_ctx* ctx) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return TC_ERR_HIP;
   for (auto& s : ctx->slots) {
@@ -500,11 +535,13 @@ int tc_ctx_trim(tc_ctx* ctx) {
     s.cap = 0;
   }
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_ctx_get_input_checks(const tc_ctx* ctx) { return (ctx && ctx->input_checks) ? 1 : 0; }
 int tc_ctx_get_device_io(const tc_ctx* ctx) { return (ctx && ctx->device_io) ? 1 : 0; }
-int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8) {
+int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8) try {
   if (!ctx || !out8) return TC_ERR_INVALID_ARG;
   out8[0] = ctx->tuning.duo_min_decode;
   out8[1] = ctx->tuning.duo_min_hash;
@@ -513,33 +550,41 @@ int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8) {
   out8[4] = (uint64_t)ctx->tuning.checks_beside;
   out8[5] = out8[6] = out8[7] = 0;  // reserved
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
+int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   if (h2d_bytes) *h2d_bytes = ctx->h2d_bytes;
   if (d2h_bytes) *d2h_bytes = ctx->d2h_bytes;
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_ctx_set_timing(tc_ctx* ctx, int enabled) {
+int tc_ctx_set_timing(tc_ctx* ctx, int enabled) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   ctx->timing = enabled != 0;
   return TC_OK;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 double tc_last_kernel_ms(const tc_ctx* ctx) { return ctx ? ctx->last_ms : 0.0; }
 
-int tc_sync(tc_ctx* ctx) {
+int tc_sync(tc_ctx* ctx) try {
   if (!ctx) return TC_ERR_INVALID_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return TC_ERR_HIP;
   return hipStreamSynchronize(ctx->stream) == hipSuccess ? TC_OK : TC_ERR_HIP;
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 const char* tc_last_error(const tc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 // ---- hashing ------------------------------------------------------------------------------
-int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out_g2) {
+int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t B, uint8_t* out_g2) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && off && out_g2);
@@ -554,10 +599,12 @@ int tc_hash_g2_batch(tc_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size
   if (!k.failed) tc::launch_hash_g2(ctx->tuning, ctx->stream, d_msgs, d_off, B, d_out);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, const uint64_t* off, size_t B,
-                        uint8_t* out_g2, uint8_t* status) {
+                        uint8_t* out_g2, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && g1 && off && out_g2);
@@ -576,6 +623,8 @@ int tc_hash_g1_g2_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* msgs, con
   k.apply_checks(B, d_st, d_out, 192, nullptr);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // ---- scalar multiplication -----------------------------------------------------------------
@@ -602,17 +651,21 @@ static int point_mul(tc_ctx* ctx, bool g2, const uint8_t* fr, const uint8_t* pts
 }
 
 int tc_g2_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
-                    uint8_t* status) {
+                    uint8_t* status) try {
   return point_mul(ctx, true, fr, pts, S, B, out, status);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_g1_mul_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* pts, size_t S, size_t B, uint8_t* out,
-                    uint8_t* status) {
+                    uint8_t* status) try {
   return point_mul(ctx, false, fr, pts, S, B, out, status);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, const uint64_t* idx, const uint8_t* hashes, size_t n,
-                            size_t B, uint8_t* out, uint8_t* status) {
+                            size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (n == 0 || B == 0) return TC_OK;
   TC_REQUIRE(ctx && sk_table && idx && hashes && out && N > 0);
@@ -645,10 +698,12 @@ int tc_sign_shares_g2_batch(tc_ctx* ctx, const uint8_t* sk_table, size_t N, cons
   k.apply_checks(B * n, d_st, d_out, 192, nullptr);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uint64_t* off, size_t S, size_t B,
-                  uint8_t* out_g2, uint8_t* status) {
+                  uint8_t* out_g2, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (S == 0 || B == 0) return TC_OK;
   TC_REQUIRE(ctx && fr && off && out_g2);
@@ -673,6 +728,8 @@ int tc_sign_batch(tc_ctx* ctx, const uint8_t* fr, const uint8_t* msgs, const uin
   }
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // ---- combination -----------------------------------------------------------------------------
@@ -830,46 +887,62 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
 }
 
 int tc_combine_g2_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                        size_t B, uint8_t* out, uint8_t* status) {
+                        size_t B, uint8_t* out, uint8_t* status) try {
   return combine(ctx, true, t, n_per_job, idx, nullptr, shares, B, out, status, nullptr, nullptr, nullptr);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares,
-                        size_t B, uint8_t* out, uint8_t* status) {
+                        size_t B, uint8_t* out, uint8_t* status) try {
   return combine(ctx, false, t, n_per_job, idx, nullptr, shares, B, out, status, nullptr, nullptr, nullptr);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
-                     const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
+                     const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx && out && status && off);
   return combine(ctx, false, t, n_per_job, idx, nullptr, shares_g1, B, out /*non-null marker*/, status, v, off, out);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // `T: IntoFr` beyond u64 (src/into_fr.rs:10-14, 28-56; combine_signatures / decrypt are generic over it, src/lib.rs:608-622)
 int tc_combine_g2_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares, size_t B, uint8_t* out,
-                           uint8_t* status) {
+                           uint8_t* status) try {
   return combine(ctx, true, t, n_per_job, nullptr, idx_fr, shares, B, out, status, nullptr, nullptr, nullptr);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 int tc_combine_g1_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares, size_t B, uint8_t* out,
-                           uint8_t* status) {
+                           uint8_t* status) try {
   return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares, B, out, status, nullptr, nullptr, nullptr);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 int tc_decrypt_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares_g1, const uint8_t* v,
-                        const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
+                        const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx && out && status && off);
   return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares_g1, B, out, status, v, off, out);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // wire-level forms: shares as they travel (Signature::to_bytes / DecryptionShare's compressed G1, checked decode of
 // from_bytes src/lib.rs:140-146, 246-252), the combined signature back as Signature::to_bytes (src/lib.rs:255-259)
 int tc_combine_signatures_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares96, size_t B,
-                                     uint8_t* out96, uint8_t* status) {
+                                     uint8_t* out96, uint8_t* status) try {
   return combine(ctx, true, t, n_per_job, idx, nullptr, shares96, B, out96, status, nullptr, nullptr, nullptr, /*wire=*/true);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 int tc_decrypt_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares48, const uint8_t* v,
-                          const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) {
+                          const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx && out && status && off);
   return combine(ctx, false, t, n_per_job, idx, nullptr, shares48, B, out, status, v, off, out, /*wire=*/true);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
@@ -907,17 +980,21 @@ static int lincomb(tc_ctx* ctx, bool g2, size_t n, const uint8_t* scalars, const
 }
 
 int tc_g1_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                        uint8_t* status) {
+                        uint8_t* status) try {
   return lincomb(ctx, false, n, scalars, points, B, out, status);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_g2_lincomb_batch(tc_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, size_t B, uint8_t* out,
-                        uint8_t* status) {
+                        uint8_t* status) try {
   return lincomb(ctx, true, n, scalars, points, B, out, status);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, const uint64_t* off, size_t B,
-                           uint8_t* out, uint8_t* status) {
+                           uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && g1 && off && out);
@@ -938,11 +1015,13 @@ int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, 
   }
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // ---- pairing checks ---------------------------------------------------------------------------
 int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8_t* b, size_t sb, const uint8_t* c,
-                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok) {
+                           size_t sc, const uint8_t* d, size_t sd, size_t B, uint8_t* ok) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && a && b && c && d && ok);
@@ -963,10 +1042,12 @@ int tc_pairing_check_batch(tc_ctx* ctx, const uint8_t* a, size_t sa, const uint8
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* sig, const uint8_t* hash,
-                       size_t B, uint8_t* ok) {
+                       size_t B, uint8_t* ok) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk && sig && hash && ok);
@@ -985,10 +1066,12 @@ int tc_verify_g2_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const u
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* sig, const uint8_t* msgs,
-                        const uint64_t* off, size_t B, uint8_t* ok) {
+                        const uint64_t* off, size_t B, uint8_t* ok) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk && sig && off && ok);
@@ -1015,6 +1098,8 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // Share validation by ONE random linear combination per message (opt-in fast path of the loop at
@@ -1023,7 +1108,7 @@ int tc_verify_sig_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const 
 // do and fails with probability >= 1 - 2^-63 otherwise; messages whose combined check fails are re-checked
 // share by share, so ok[] equals the per-share path's (up to that 2^-63).
 int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* sig_shares, const uint8_t* msgs,
-                               const uint64_t* off, size_t B, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+                               const uint64_t* off, size_t B, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) try {
   TC_REQUIRE(ctx);
   if (n_fallback) *n_fallback = 0;
   if (B == 0 || N == 0) return TC_OK;
@@ -1117,6 +1202,8 @@ int tc_verify_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, 
   }
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // Signature batches under ONE key (BASELINE config 3's shape: 65 536 verifies under the master key) by random linear
@@ -1249,25 +1336,29 @@ static int verify_rlc(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const 
 }
 
 int tc_verify_g2_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* hash, size_t B, size_t group,
-                           const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+                           const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) try {
   if (ctx && !hash) {
     ctx->err = "invalid argument: hash";
     return TC_ERR_INVALID_ARG;
   }
   return verify_rlc(ctx, pk, sig, hash, nullptr, nullptr, B, group, seed32, ok, n_fallback);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_verify_sig_rlc_batch(tc_ctx* ctx, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* off, size_t B,
-                            size_t group, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) {
+                            size_t group, const uint8_t* seed32, uint8_t* ok, uint64_t* n_fallback) try {
   if (ctx && !off) {
     ctx->err = "invalid argument: off";
     return TC_ERR_INVALID_ARG;
   }
   return verify_rlc(ctx, pk, sig, nullptr, msgs, off, B, group, seed32, ok, n_fallback);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, const uint64_t* off,
-                               const uint8_t* w, size_t B, uint8_t* ok) {
+                               const uint8_t* w, size_t B, uint8_t* ok) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && u && off && w && ok);
@@ -1293,6 +1384,8 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // Ciphertext::verify, then [sk] u for the ciphertexts that pass: SecretKeyShare::decrypt_share (src/lib.rs:452-457) when
@@ -1340,20 +1433,24 @@ static int verified_decrypt(tc_ctx* ctx, const uint8_t* sk, const uint8_t* u, co
 }
 
 int tc_decrypt_share_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
-                           size_t B, uint8_t* out_g1, uint8_t* ok) {
+                           size_t B, uint8_t* out_g1, uint8_t* ok) try {
   TC_REQUIRE(ctx && (B == 0 || out_g1));
   return verified_decrypt(ctx, sk_fr, u, v, off, w, B, out_g1, nullptr, ok);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_secret_key_decrypt_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
-                                size_t B, uint8_t* out, uint8_t* ok) {
+                                size_t B, uint8_t* out, uint8_t* ok) try {
   TC_REQUIRE(ctx && (B == 0 || out));
   return verified_decrypt(ctx, sk_fr, u, v, off, w, B, nullptr, out, ok);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_t pk_stride, const uint8_t* share,
                                      const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
-                                     size_t B, uint8_t* ok) {
+                                     size_t B, uint8_t* ok) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk_share && share && u && off && w && ok);
@@ -1386,6 +1483,8 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
   k.apply_checks(B, nullptr, nullptr, 0, d_ok);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // Decryption-share validation by ONE random linear combination per ciphertext (opt-in fast path of the loop of
@@ -1396,7 +1495,7 @@ int tc_verify_decryption_share_batch(tc_ctx* ctx, const uint8_t* pk_share, size_
 // re-checked share by share, so ok[] equals the per-share path's up to 2^-63.
 int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares, size_t N, const uint8_t* shares, const uint8_t* u,
                                           const uint8_t* v, const uint64_t* off, const uint8_t* w, size_t B, const uint8_t* seed32,
-                                          uint8_t* ok, uint64_t* n_fallback) {
+                                          uint8_t* ok, uint64_t* n_fallback) try {
   TC_REQUIRE(ctx);
   if (n_fallback) *n_fallback = 0;
   if (B == 0 || N == 0) return TC_OK;
@@ -1506,10 +1605,12 @@ int tc_verify_decryption_shares_rlc_batch(tc_ctx* ctx, const uint8_t* pk_shares,
   }
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // ---- DKG algebra -----------------------------------------------------------------------------------
-int tc_g1_commitment_batch(tc_ctx* ctx, const uint8_t* coeff_fr, size_t M, uint8_t* out, uint8_t* status) {
+int tc_g1_commitment_batch(tc_ctx* ctx, const uint8_t* coeff_fr, size_t M, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (M == 0) return TC_OK;
   TC_REQUIRE(ctx && coeff_fr && out);
@@ -1527,10 +1628,12 @@ int tc_g1_commitment_batch(tc_ctx* ctx, const uint8_t* coeff_fr, size_t M, uint8
   if (!k.failed) tc::launch_g1_fixed_base(ctx->stream, ctx->fb_table, d_fr, M, d_out, d_st, ctx->cus);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_bivar_commitment_row_batch(tc_ctx* ctx, const uint8_t* commit, size_t degree, const uint64_t* xs, size_t M, uint8_t* out,
-                                  uint8_t* status) {
+                                  uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (M == 0) return TC_OK;
   TC_REQUIRE(ctx && commit && xs && out);
@@ -1547,9 +1650,11 @@ int tc_bivar_commitment_row_batch(tc_ctx* ctx, const uint8_t* commit, size_t deg
   k.apply_checks(M * (degree + 1), d_st, d_out, 96, nullptr);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_fr_interpolate_batch(tc_ctx* ctx, size_t n, const uint8_t* xs, const uint8_t* ys, size_t B, uint8_t* out_coeff, uint8_t* status) {
+int tc_fr_interpolate_batch(tc_ctx* ctx, size_t n, const uint8_t* xs, const uint8_t* ys, size_t B, uint8_t* out_coeff, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0 || n == 0) return TC_OK;
   TC_REQUIRE(ctx && xs && ys && out_coeff);
@@ -1569,6 +1674,8 @@ int tc_fr_interpolate_batch(tc_ctx* ctx, size_t n, const uint8_t* xs, const uint
     tc::launch_fr_interpolate(ctx->stream, n, (const uint32_t*)d_x, (const uint32_t*)d_y, B, (uint32_t*)d_out, d_ws, d_st);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // ---- membership tests ---------------------------------------------------------------------------
@@ -1588,15 +1695,19 @@ static int subgroup_check(tc_ctx* ctx, bool g2, const uint8_t* pts, size_t B, ui
   k.end_timing();
   return k.finish();
 }
-int tc_g1_subgroup_check_batch(tc_ctx* ctx, const uint8_t* pts96, size_t B, uint8_t* ok) {
+int tc_g1_subgroup_check_batch(tc_ctx* ctx, const uint8_t* pts96, size_t B, uint8_t* ok) try {
   return subgroup_check(ctx, false, pts96, B, ok);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
-int tc_g2_subgroup_check_batch(tc_ctx* ctx, const uint8_t* pts192, size_t B, uint8_t* ok) {
+int tc_g2_subgroup_check_batch(tc_ctx* ctx, const uint8_t* pts192, size_t B, uint8_t* ok) try {
   return subgroup_check(ctx, true, pts192, B, ok);
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 // ---- wire formats ------------------------------------------------------------------------------
-int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status) {
+int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out48, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && in96 && out48);
@@ -1608,9 +1719,11 @@ int tc_g1_compress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* ou
   if (!k.failed) tc::launch_g1_compress(ctx->stream, d_in, B, d_out, d_st);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* out96, uint8_t* status) {
+int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* out96, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && in192 && out96);
@@ -1622,10 +1735,12 @@ int tc_g2_compress_batch(tc_ctx* ctx, const uint8_t* in192, size_t B, uint8_t* o
   if (!k.failed) tc::launch_g2_compress(ctx->stream, d_in, B, d_out, d_st);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uint8_t* r, const uint8_t* msgs,
-                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) {
+                     const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && pk && r && off && out_u && out_v && out_w);
@@ -1655,10 +1770,12 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uin
   }
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, const uint64_t* idx, size_t M, uint8_t* out,
-                              uint8_t* status) {
+                              uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (M == 0) return TC_OK;
   TC_REQUIRE(ctx && commit && idx && out);
@@ -1674,9 +1791,11 @@ int tc_public_key_share_batch(tc_ctx* ctx, const uint8_t* commit, size_t t, cons
   k.apply_checks(M, d_st, d_out, 96, nullptr);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status) {
+int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* out96, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && in48 && out96);
@@ -1688,9 +1807,11 @@ int tc_g1_decompress_batch(tc_ctx* ctx, const uint8_t* in48, size_t B, uint8_t* 
   if (!k.failed) tc::launch_g1_decompress(ctx->stream, d_in, B, d_out, d_st);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
-int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out192, uint8_t* status) {
+int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* out192, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && in96 && out192);
@@ -1702,6 +1823,8 @@ int tc_g2_decompress_batch(tc_ctx* ctx, const uint8_t* in96, size_t B, uint8_t* 
   if (!k.failed) tc::launch_g2_decompress(ctx->tuning, ctx->stream, d_in, B, d_out, d_st);
   k.end_timing();
   return k.finish();
+} catch (...) {
+  return on_exception((tc_ctx*)ctx);
 }
 
 }  // extern "C"

@@ -104,7 +104,12 @@ void worker_main(tc_group* g, int r) {
     std::function<int()> task = std::move(w->task);
     w->has_task = false;
     lk.unlock();
-    const int rc = task();
+    int rc;
+    try {
+      rc = task();
+    } catch (...) {
+      rc = TC_ERR_HOST;  // (an exception must not leave a worker thread: std::terminate)
+    }
     lk.lock();
     w->rc = rc;
     w->done = true;
@@ -190,9 +195,20 @@ int all_reduce_counts(tc_group* g, const std::vector<uint64_t>& local, uint64_t*
 
 }  // namespace
 
+static int on_exception_group(tc_group* g) noexcept {
+  if (g) {
+    try {
+      g->err = "C++ exception in the host code (std::bad_alloc?)";
+    } catch (...) {
+    }
+  }
+  return TC_ERR_HOST;
+}
+static int on_exception(void*) noexcept { return TC_ERR_HOST; }
+
 extern "C" {
 
-int tc_group_create(tc_group** out, const int* devices, int ndev) {
+int tc_group_create(tc_group** out, const int* devices, int ndev) try {
   if (!out || !devices || ndev <= 0) return TC_ERR_INVALID_ARG;
   *out = nullptr;
   tc_group* g = new tc_group();
@@ -241,9 +257,11 @@ int tc_group_create(tc_group** out, const int* devices, int ndev) {
   for (int r = 0; r < ndev; r++) g->workers[r]->th = std::thread(worker_main, g, r);
   *out = g;
   return TC_OK;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
-void tc_group_destroy(tc_group* g) {
+void tc_group_destroy(tc_group* g) try {
   if (!g) return;
   for (auto w : g->workers) {
     {
@@ -270,6 +288,7 @@ void tc_group_destroy(tc_group* g) {
     if (g->streams[r]) (void)hipStreamDestroy(g->streams[r]);
   }
   delete g;
+} catch (...) {
 }
 
 int tc_group_size(const tc_group* g) { return g ? (int)g->ctx.size() : 0; }
@@ -277,14 +296,16 @@ tc_ctx* tc_group_ctx(tc_group* g, int rank) { return (g && rank >= 0 && rank < (
 const char* tc_group_last_error(const tc_group* g) { return g ? g->err.c_str() : "null group"; }
 int tc_group_uses_rccl(const tc_group* g) { return g && !g->comms.empty(); }
 
-int tc_group_shard(const tc_group* g, size_t B, int rank, size_t* start, size_t* count) {
+int tc_group_shard(const tc_group* g, size_t B, int rank, size_t* start, size_t* count) try {
   if (!g || !start || !count || rank < 0 || rank >= (int)g->ctx.size()) return TC_ERR_INVALID_ARG;
   shard(B, (int)g->ctx.size(), rank, start, count);
   return TC_OK;
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 // bytes that crossed PCIe since the group was created: the group's own copies plus its contexts' staging copies
-int tc_group_transfer_bytes(const tc_group* g, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
+int tc_group_transfer_bytes(const tc_group* g, uint64_t* h2d_bytes, uint64_t* d2h_bytes) try {
   if (!g) return TC_ERR_INVALID_ARG;
   uint64_t up = g->h2d.load(), down = g->d2h.load();
   for (auto c : g->ctx) {
@@ -296,10 +317,12 @@ int tc_group_transfer_bytes(const tc_group* g, uint64_t* h2d_bytes, uint64_t* d2
   if (h2d_bytes) *h2d_bytes = up;
   if (d2h_bytes) *d2h_bytes = down;
   return TC_OK;
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 // PublicKeySet { commit } (src/lib.rs:539-543) -> every GPU: rank 0's HBM copy is broadcast over RCCL
-int tc_group_set_keyset(tc_group* g, size_t t, const uint8_t* commit) {
+int tc_group_set_keyset(tc_group* g, size_t t, const uint8_t* commit) try {
   if (!g || !commit || t >= (1u << 20)) return TC_ERR_INVALID_ARG;
   const size_t bytes = (t + 1) * 96;
   const int n = (int)g->ctx.size();
@@ -328,19 +351,23 @@ int tc_group_set_keyset(tc_group* g, size_t t, const uint8_t* commit) {
   g->t = t;
   g->have_keyset = true;
   return TC_OK;
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 // a rank's copy of the key set (host buffer of (t+1) x 96 B): what tests read back to see the broadcast
-int tc_group_get_keyset(tc_group* g, int rank, uint8_t* out_commit) {
+int tc_group_get_keyset(tc_group* g, int rank, uint8_t* out_commit) try {
   if (!g || !out_commit || !g->have_keyset || rank < 0 || rank >= (int)g->ctx.size()) return TC_ERR_INVALID_ARG;
   if (hipSetDevice(g->devices[rank]) != hipSuccess) return TC_ERR_HIP;
   return hipMemcpy(out_commit, g->d_keyset[rank], (g->t + 1) * 96, hipMemcpyDeviceToHost) == hipSuccess ? TC_OK : TC_ERR_HIP;
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 // PublicKeySet::combine_signatures (src/lib.rs:608-615) for B jobs in host memory, sharded over the GPUs.  The share
 // signatures are the INPUT here (they arrive from the signers): each rank stages its own slice, nothing else moves.
 int tc_group_combine_signatures(tc_group* g, size_t n_per_job, const uint64_t* idx, const uint8_t* shares, size_t B, uint8_t* out,
-                                uint8_t* status) {
+                                uint8_t* status) try {
   if (!g || !g->have_keyset || !idx || !shares || !out || !status) return TC_ERR_INVALID_ARG;
   return run_ranks(g, [&](int r) {
     size_t s, c;
@@ -352,11 +379,13 @@ int tc_group_combine_signatures(tc_group* g, size_t n_per_job, const uint64_t* i
     (void)tc_ctx_set_device_io(g->ctx[r], dio);
     return e;
   });
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 // PublicKey::verify_g2 (src/lib.rs:108-110) under the key set's master key (commit[0], already resident on every
 // GPU); n_valid (optional) = sum over ranks of the valid counts, all-reduced over RCCL
-int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, size_t B, uint8_t* ok, uint64_t* n_valid) {
+int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, size_t B, uint8_t* ok, uint64_t* n_valid) try {
   if (!g || !g->have_keyset || !sig || !hash || !ok) return TC_ERR_INVALID_ARG;
   const int n = (int)g->ctx.size();
   std::vector<uint64_t> local(n, 0);
@@ -381,6 +410,8 @@ int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, siz
   });
   if (rc != TC_OK || !n_valid) return rc;
   return all_reduce_counts(g, local, n_valid);
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 // BASELINE config 5 through the C ABI: for each of B messages sign the n shares of its signer subset on the device
@@ -389,7 +420,7 @@ int tc_group_verify_g2(tc_group* g, const uint8_t* sig, const uint8_t* hash, siz
 // msgs / off / idx goes up and its slice of sig / ok comes back; hash points and share signatures -- B x n x 192 B, the
 // bulk of the data -- are made and consumed in the rank's HBM.
 int tc_group_sign_combine_verify(tc_group* g, const uint8_t* sk_table, size_t N, const uint64_t* idx, size_t n, const uint8_t* msgs,
-                                 const uint64_t* off, size_t B, uint8_t* sig, uint8_t* ok, uint64_t* n_valid) {
+                                 const uint64_t* off, size_t B, uint8_t* sig, uint8_t* ok, uint64_t* n_valid) try {
   if (!g || !g->have_keyset || !sk_table || !idx || !off || !sig || !ok || n == 0 || n <= g->t || N == 0) return TC_ERR_INVALID_ARG;
   // offsets are read before anything is sharded: they must start at 0 and never decrease
   if (off[0] != 0) return TC_ERR_INVALID_ARG;
@@ -447,6 +478,8 @@ int tc_group_sign_combine_verify(tc_group* g, const uint8_t* sk_table, size_t N,
   });
   if (rc != TC_OK || !n_valid) return rc;
   return all_reduce_counts(g, local, n_valid);
+} catch (...) {
+  return on_exception_group(const_cast<tc_group*>(g));
 }
 
 }  // extern "C"
