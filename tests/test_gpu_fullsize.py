@@ -666,6 +666,16 @@ def test_operand_buffers_beyond_four_gib(engine, sig_workload, combined):
         expect = torch.ones(reps * B, dtype=torch.bool, device="cuda")
         expect[swapped] = False
         assert bool((ok == expect).all()), "verify_g2 verdicts differ at rows %s" % torch.nonzero(ok != expect).flatten()[:8].tolist()
+        del hs, sig, out, want, ok, expect
+        torch.cuda.empty_cache()
+        # the same batch size with HOST buffers: one 5.6 GB host-to-device staging copy (a staging slot and a copy length past 2^32)
+        h_idx = np.concatenate([np.roll(wl.idx, k, 0) for k in range(reps)])
+        h_sh = np.concatenate([np.roll(wl.shares, k, 0) for k in range(reps)])
+        h_out, h_st = engine.combine_g2(3, h_idx, h_sh)
+        assert not h_st.any()
+        for k in (0, 1, 57, reps - 1):
+            assert (h_out[k * B:(k + 1) * B] == np.roll(combined, k, 0)).all(), "host-mode tile %d" % k
+        assert (h_out.reshape(reps, B, 192)[:, 0] == np.stack([np.roll(combined, k, 0)[0] for k in range(reps)])).all()
     finally:
         engine.set_input_checks(was)
         engine.trim()
