@@ -240,3 +240,46 @@ def test_failed_device_allocation_is_an_error_and_the_context_survives(engine, w
     ok = eng.verify_g2(wl.master_pk, got, np.ascontiguousarray(wl.hashes[:B]))
     assert ok.all()
     eng.close()
+
+
+def test_pairing_check_with_the_hbm_nearly_full_takes_the_form_without_a_line_buffer(engine, wl):
+    """ADVICE r05 on the REAL path (the existing test forces it through TC_PAIRING_BUDGET): with under 1 GB of HBM free the prepared
+    pairing form's smallest line buffer (1.013 GB) does not fit; pairing_line_budget then answers a tile of 0 and the check runs
+    in the one-loop form instead of failing an allocation -- same verdicts as with the memory free."""
+    import torch
+    from threshold_crypto_amd.engine import Engine
+    B = 20000                                           # above the four-lanes-per-check form's 16 384
+    reps = (B + wl.B - 1) // wl.B
+    idx = np.ascontiguousarray(np.tile(wl.idx, (reps, 1))[:B])
+    shares = np.ascontiguousarray(np.tile(wl.shares, (reps, 1, 1))[:B])
+    hashes = np.ascontiguousarray(np.tile(wl.hashes, (reps, 1))[:B])
+    sig, st = engine.combine_g2(wl.t, idx, shares)
+    assert not st.any()
+    sig[5] = sig[6]
+    sig[B - 1] = sig[0]
+    want = engine.verify_g2(wl.master_pk, sig, hashes)
+    assert want.sum() == B - 2
+    eng = Engine(0)
+    eng.set_input_checks(False)
+    assert eng.verify_g2(wl.master_pk, sig[:64], hashes[:64]).sum() == 63       # (the context's small buffers exist now)
+    torch.cuda.empty_cache()
+    hogs = []
+    try:
+        free, _total = torch.cuda.mem_get_info()
+        hogs.append(torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda"))
+        while True:
+            free, _total = torch.cuda.mem_get_info()
+            if free < (700 << 20):
+                break
+            hogs.append(torch.empty(min(free - (600 << 20), 256 << 20), dtype=torch.uint8, device="cuda"))
+    except torch.OutOfMemoryError:
+        pass
+    try:
+        free, _total = torch.cuda.mem_get_info()
+        assert (300 << 20) < free < (1 << 30), "free HBM %d MB" % (free >> 20)
+        got = eng.verify_g2(wl.master_pk, sig, hashes)
+    finally:
+        del hogs
+        torch.cuda.empty_cache()
+    assert (got == want).all()
+    eng.close()
