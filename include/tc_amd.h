@@ -26,7 +26,10 @@
  * tc_ctx_set_input_checks(ctx, 0) and saves one 64-bit ladder per G2 operand and two per G1 operand.
  *
  * Return value: 0 = TC_OK, < 0 = call-level failure (bad argument / HIP error / no device / host failure);
- * never aborts, never throws across the boundary (every entry is a function-try-block: an exception becomes TC_ERR_HOST).  Per-job results go to `status[]`
+ * never aborts, never throws across the boundary (every entry is a function-try-block: an exception becomes TC_ERR_HOST).
+ * One abort is the ROCm runtime's own -- it kills the process when it cannot allocate a dispatch's private segments -- so a
+ * call first compares the free device memory with what its size could ask for (at most ~6.5 GB for a large batch) and
+ * returns TC_ERR_HIP instead of launching; TC_PRIVATE_RESERVE=<bytes> in the environment of tc_ctx_create overrides, 0 disables.  Per-job results go to `status[]`
  * (mirrors threshold_crypto::error::Error / FromBytesError, src/error.rs:7-17,37-41) and
  * `ok[]` (the `bool` of the verify methods).
  *

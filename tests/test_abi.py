@@ -274,3 +274,14 @@ def test_every_entry_point_stops_exceptions_at_the_boundary():
     assert len(seen) >= 55, sorted(seen)
     assert "rc = TC_ERR_HOST" in open(os.path.join(ROOT, "threshold_crypto_amd", "csrc", "tc_group.hip")).read()
     assert "TC_ERR_HOST" in open(os.path.join(ROOT, "include", "tc_amd.h")).read() and _native.TC_ERR_HOST == -4
+
+
+def test_private_segment_bound_covers_every_kernel():
+    """Call::guard_private (tc_api.hip) prices a lane at tc_launch.h kMaxPrivateBytesPerLane: no kernel of the shipped library may
+    have a larger private segment (profiles/kernel_resources.json is checked against the built .so by the test above)."""
+    import json
+    text = open(os.path.join(ROOT, "threshold_crypto_amd", "csrc", "tc_launch.h")).read()
+    bound = int(re.search(r"kMaxPrivateBytesPerLane = (\d+);", text).group(1))
+    res = json.load(open(os.path.join(ROOT, "profiles", "kernel_resources.json")))
+    worst = max(v["scratch_bytes_per_lane"] for v in res.values())
+    assert worst <= bound < 2 * worst, (worst, bound)

@@ -6,6 +6,7 @@
   * jobs whose ladder meets the point at infinity (identity operand, zero scalar) keep their table entries'
     infinity flags through the arena.
 """
+import os
 import random
 import threading
 
@@ -228,7 +229,8 @@ def test_failed_device_allocation_is_an_error_and_the_context_survives(engine, w
     try:
         with pytest.raises(TcError) as e:
             eng.combine_g2(wl.t, idx, shares)
-        assert e.value.code == _native.TC_ERR_HIP and "hipMalloc" in str(e.value), str(e.value)
+        # (whichever notices first: a staging / arena hipMalloc that fails, or the guard in front of the first launch)
+        assert e.value.code == _native.TC_ERR_HIP and ("hipMalloc" in str(e.value) or "out of memory" in str(e.value)), str(e.value)
         with pytest.raises(TcError) as e2:                                                         # and again: still an error, still no abort
             eng.combine_g2(wl.t, idx, shares)
         assert e2.value.code == _native.TC_ERR_HIP
@@ -259,7 +261,13 @@ def test_pairing_check_with_the_hbm_nearly_full_takes_the_form_without_a_line_bu
     sig[B - 1] = sig[0]
     want = engine.verify_g2(wl.master_pk, sig, hashes)
     assert want.sum() == B - 2
-    eng = Engine(0)
+    # (TC_PRIVATE_RESERVE=0: this context does not insist on free HBM for the kernels' private segments -- the guard that would
+    # turn this very call away, see the test below; 20 000 checks are 625 waves of 117 KB, which the runtime does find)
+    os.environ["TC_PRIVATE_RESERVE"] = "0"
+    try:
+        eng = Engine(0)
+    finally:
+        os.environ.pop("TC_PRIVATE_RESERVE")
     eng.set_input_checks(False)
     assert eng.verify_g2(wl.master_pk, sig[:64], hashes[:64]).sum() == 63       # (the context's small buffers exist now)
     torch.cuda.empty_cache()
@@ -282,4 +290,88 @@ def test_pairing_check_with_the_hbm_nearly_full_takes_the_form_without_a_line_bu
         del hogs
         torch.cuda.empty_cache()
     assert (got == want).all()
+    eng.close()
+
+
+def test_two_stage_kernels_run_tile_by_tile_when_the_table_budget_is_short(engine):
+    """tc_api.hip msm_g2 / msm_g1: the per-share tables of the large-threshold path live in HBM (2 KB per share in G2); a batch whose
+    tables exceed what the call may spend (a third of the free HBM, 1-24 GiB) runs as consecutive tiles through ONE table buffer.
+    At 24 GiB no test ever needed a second tile: TC_MSM_BUDGET (read when the context is created) makes 3 000 jobs at t = 21 take
+    nine tiles, 20 000 jobs seven -- and 90 000 G1 jobs under the library's own 1 GiB floor.  Every job combines 22 shares of ONE
+    point, so every result must be [f(0)] h; a sample is recomputed by Oracle B."""
+    import tc_oracle as o
+    from conftest import engine_with_env
+    c.load()
+    rnd = random.Random(2121)
+    t, N = 21, 40
+    poly = [rnd.randrange(o.R) for _ in range(t + 1)]
+    fr = np.stack([u8(o.secret_key_share(poly, i).to_bytes(32, "little")) for i in range(N)])
+    h2 = o.E2.mul(o.G2_GEN, rnd.randrange(1, o.R))
+    h1 = o.E1.mul(o.G1_GEN, rnd.randrange(1, o.R))
+    s2, st = engine.g2_mul(fr, u8(o.g2_uncompressed(h2))[None])
+    s1, st1 = engine.g1_mul(fr, u8(o.g1_uncompressed(h1))[None])
+    assert not st.any() and not st1.any()
+    want2 = u8(o.g2_uncompressed(o.E2.mul(h2, poly[0])))
+    want1 = u8(o.g1_uncompressed(o.E1.mul(h1, poly[0])))
+    sets = np.stack([np.array(sorted(rnd.sample(range(N), t + 1)), dtype=np.uint64) for _ in range(512)])
+    for B, budget in ((3000, 16 << 20), (20000, 128 << 20), (90000, 1 << 30)):
+        idx = np.ascontiguousarray(sets[(np.arange(B) * 7) % 512])
+        sh2 = np.ascontiguousarray(s2[0][idx.astype(np.int64)])
+        sh1 = np.ascontiguousarray(s1[0][idx.astype(np.int64)])
+        with engine_with_env(TC_MSM_BUDGET=budget) as eng:
+            eng.set_input_checks(False)
+            out2, st2 = eng.combine_g2(t, idx, sh2) if B <= 20000 else (None, None)
+            out1, st1 = eng.combine_g1(t, idx, sh1)
+        assert not st1.any() and (out1 == want1).all(), (B, budget)
+        if out2 is not None:
+            assert not st2.any() and (out2 == want2).all(), (B, budget)
+            for j in (0, B // 2, B - 1):
+                rc, w = c.combine_g2(t, [int(i) for i in idx[j]], [bytes(x) for x in sh2[j]])
+                assert rc == 0 and bytes(out2[j]) == w, j
+
+
+def test_a_call_the_runtime_could_not_survive_is_turned_away(engine, wl):
+    """The ROCm runtime allocates the kernels' private segments when a dispatch needs them and ABORTS THE PROCESS when it cannot
+    (amd::roc::callbackQueue <- AqlQueue::DynamicQueueEventsHandler, reproduced with ~0.4 GB of HBM free after the call's own
+    allocations: DESIGN.md 7): no error code reaches anybody.  Call::guard_private therefore compares the free HBM with what a
+    call of this size could ask for before the first launch: with ~1.5 GB free a 16 384-job combination comes back TC_ERR_HIP
+    with the reason, a 64-job one still runs, and with the memory free again the same context runs the large one."""
+    import torch
+    from threshold_crypto_amd.engine import Engine, TcError
+    from threshold_crypto_amd import _native
+    B = 16384
+    reps = (B + wl.B - 1) // wl.B
+    idx = np.ascontiguousarray(np.tile(wl.idx, (reps, 1))[:B])
+    shares = np.ascontiguousarray(np.tile(wl.shares, (reps, 1, 1))[:B])
+    want, st = engine.combine_g2(wl.t, idx, shares)
+    assert not st.any()
+    eng = Engine(0)
+    eng.set_input_checks(False)
+    out, st = eng.combine_g2(wl.t, idx[:64], shares[:64])
+    assert not st.any()
+    torch.cuda.empty_cache()
+    hogs = []
+    try:
+        free, _total = torch.cuda.mem_get_info()
+        hogs.append(torch.empty(max(free - (4 << 30), 0), dtype=torch.uint8, device="cuda"))
+        while True:
+            free, _total = torch.cuda.mem_get_info()
+            if free < (1700 << 20):
+                break
+            hogs.append(torch.empty(min(free - (1500 << 20), 256 << 20), dtype=torch.uint8, device="cuda"))
+    except torch.OutOfMemoryError:
+        pass
+    try:
+        free, _total = torch.cuda.mem_get_info()
+        assert (1 << 30) < free < (2 << 30), "free HBM %d MB" % (free >> 20)
+        with pytest.raises(TcError) as e:
+            eng.combine_g2(wl.t, idx, shares)
+        assert e.value.code == _native.TC_ERR_HIP and "private segments" in str(e.value), str(e.value)
+        small, st = eng.combine_g2(wl.t, idx[:64], shares[:64])           # 64 jobs ask for 3 waves' worth: allowed, and it runs
+        assert not st.any() and (small == want[:64]).all()
+    finally:
+        del hogs
+        torch.cuda.empty_cache()
+    got, st = eng.combine_g2(wl.t, idx, shares)
+    assert not st.any() and (got == want).all()
     eng.close()

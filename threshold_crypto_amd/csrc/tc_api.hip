@@ -151,6 +151,7 @@ struct Call {
   // input operand: device pointer usable by kernels
   template <class T>
   const T* in(const T* p, size_t count, bool secret = false) {
+    if (p) operand_bytes += count * sizeof(T);
     if (c->device_io || p == nullptr) return p;
     size_t n = count * sizeof(T);
     void* d = scratch(n);
@@ -165,6 +166,7 @@ struct Call {
   T* out(T* p, size_t count, bool zero = false) {
     if (p == nullptr) return nullptr;
     size_t n = count * sizeof(T);
+    operand_bytes += n;
     T* d = p;
     if (!c->device_io) {
       d = (T*)scratch(n);
@@ -262,7 +264,31 @@ struct Call {
       for (auto& p : checks) tc::launch_invalidate_jobs(c->stream, p.valid, p.per_job, p.group, B, status, out, out_bytes, ok);
     checks.clear();
   }
+  // Every entry calls begin_timing() after its allocations and before its first launch: the place to refuse a call the RUNTIME
+  // could not survive.  The kernels' private segments (spilled registers, ladder tables: up to 11 KB per lane) are allocated by
+  // the ROCm runtime when a dispatch needs them, per queue, for as many waves as the dispatch has (at most 32 per CU); when that
+  // allocation fails the runtime's queue-error callback calls abort() -- the process dies on a runtime thread, no error code
+  // reaches anybody (reproduced with ~0.4 GB of HBM free: DESIGN.md 7).  So a call whose size could ask for more than is free is
+  // turned away HERE, as TC_ERR_HIP.  The bound is generous (operand bytes / 48 lanes, every lane at the largest private
+  // segment of the library): it only ever bites with the HBM nearly full.
+  size_t operand_bytes = 0;
+  void guard_private() {
+    if (failed || c->tuning.private_reserve == 0) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    size_t need = c->tuning.private_reserve;
+    if (need == (size_t)-1) {
+      const size_t device_waves = (size_t)(c->cus > 0 ? c->cus : 256) * 32;
+      size_t waves = operand_bytes / 48 / 64 + 1;  // (no entry moves fewer than 97 operand bytes per job, no kernel runs more than two lanes per 97 bytes)
+      if (waves > device_waves) waves = device_waves;
+      need = waves * 64 * tc::kMaxPrivateBytesPerLane + ((size_t)64 << 20);
+    }
+    if (free_b < need)
+      fail("out of memory: " + std::to_string(free_b >> 20) + " MB of HBM free, the kernels' private segments may need " + std::to_string(need >> 20) +
+           " MB (the ROCm runtime aborts the process when it cannot allocate them; TC_PRIVATE_RESERVE overrides)");
+  }
   void begin_timing() {
+    guard_private();
     if (c->timing && !failed) check(hipEventRecord(c->ev0, c->stream), "event record");
   }
   void end_timing() {
@@ -321,6 +347,7 @@ constexpr size_t kMsmTableBudget = (size_t)24 << 30;
 // slots already hold), at most 24 GiB, at least 1 GiB -- several contexts on one GPU, or a smaller card, tile their batches
 // finer instead of failing an allocation.  tc_ctx_trim() gives the slots back.
 size_t msm_table_budget(Call& k) {
+  if (k.c->tuning.msm_budget) return k.c->tuning.msm_budget;  // (TC_MSM_BUDGET at context creation: the tile loops under test)
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)1 << 30;
   size_t held = 0;
@@ -394,6 +421,8 @@ tc::Tuning tuning_from_env() {
   if (const char* e = getenv("TC_DUO_MIN")) tn.duo_min_decode = tn.duo_min_hash = (size_t)strtoull(e, nullptr, 10);
   if (const char* f = getenv("TC_PAIRING_FORM")) tn.pairing_form = f[0] == 'q' ? 1 : f[0] == 'l' ? 2 : f[0] == 'p' ? 3 : f[0] == 'f' ? 4 : 0;
   if (const char* b = getenv("TC_PAIRING_BUDGET")) tn.pairing_budget = (size_t)strtoull(b, nullptr, 10);
+  if (const char* m = getenv("TC_MSM_BUDGET")) tn.msm_budget = (size_t)strtoull(m, nullptr, 10);
+  if (const char* r = getenv("TC_PRIVATE_RESERVE")) tn.private_reserve = (size_t)strtoull(r, nullptr, 10);
   if (const char* o = getenv("TC_CHECKS_BESIDE")) tn.checks_beside = (o[0] >= '0' && o[0] <= '2') ? o[0] - '0' : 1;  // 0 one stream, 1 low priority, 2 normal
   return tn;
 }

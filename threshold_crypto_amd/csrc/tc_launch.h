@@ -44,10 +44,16 @@ inline bool duo_form(size_t jobs, size_t min_jobs) { return jobs >= min_jobs; }
 // (TC_DUO_MIN=<jobs>, TC_PAIRING_FORM=quad|lines|pair|fused, TC_PAIRING_BUDGET=<bytes>, TC_CHECKS_BESIDE=0|1: tests and experiments) is read ONCE,
 // when the context is created (tc_api.hip tuning_from_env) -- no getenv on the launch path, nothing a concurrent setenv can race
 // with -- and tc_ctx_get_tuning reports what a context uses.
+constexpr size_t kMaxPrivateBytesPerLane = 12288;  // >= the largest private segment of any kernel (11 136 B: k_msm_tables_g1; tests/test_abi.py)
 struct Tuning {
   size_t duo_min_decode = kDuoMinDecode, duo_min_hash = kDuoMinHash;
   int pairing_form = 0;       // 0 = by batch size; 1 quad, 2 lines (prepared), 3 pair (one loop), 4 fused
   size_t pairing_budget = 0;  // bytes the prepared form's line buffer may take; 0 = a third of the HBM that is free
+  // free HBM a call insists on before it launches (after its own allocations): the ROCm runtime allocates the kernels' private
+  // segments (scratch) at dispatch and ABORTS THE PROCESS when it cannot (amd::roc::callbackQueue <- AqlQueue::DynamicQueueEventsHandler,
+  // seen with ~0.4 GB free).  (size_t)-1 = by the size of the call (Call::guard_private); TC_PRIVATE_RESERVE=<bytes> fixes it, 0 disables.
+  size_t private_reserve = (size_t)-1;
+  size_t msm_budget = 0;      // bytes the per-share tables of the two-stage kernels may take per call; 0 = a third of the free HBM, 1-24 GiB (TC_MSM_BUDGET: tests)
   int checks_beside = 1;  // checked-input mode: the membership tests on a second stream beside the call's main kernels (TC_CHECKS_BESIDE=0: before them, one stream)
 };
 
