@@ -114,9 +114,11 @@ int tc_ctx_transfer_bytes(const tc_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_
  * (0 = by batch size: four lanes per check up to 16 384 checks, the prepared three-kernel form above; 1 quad, 2 lines,
  * 3 pair, 4 fused), out8[3] = bytes the prepared form's line buffer may take (0 = a third of the free HBM), out8[4] = 1 when
  * the membership tests of checked-input mode run on the context's second stream beside the main kernels of a call (default)
- * and 0 when they run before them; out8[5..7] = 0 (reserved).  The defaults are the measured choices (csrc/tc_launch.h); the
- * environment variables TC_DUO_MIN, TC_PAIRING_FORM, TC_PAIRING_BUDGET, TC_CHECKS_BESIDE (tests, experiments) are read ONCE,
- * by tc_ctx_create -- never on the launch path. */
+ * and 0 when they run before them; out8[5] = bytes the per-share tables of the two-stage kernels may take per call (0 = a third of the
+ * free HBM, 1-24 GiB), out8[6] = free device memory a call insists on before its first launch (all ones = by the size of the call,
+ * 0 = no check: see "Return value" above); out8[7] = 0 (reserved).  The defaults are the measured choices (csrc/tc_launch.h); the
+ * environment variables TC_DUO_MIN, TC_PAIRING_FORM, TC_PAIRING_BUDGET, TC_CHECKS_BESIDE, TC_MSM_BUDGET, TC_PRIVATE_RESERVE (tests,
+ * experiments) are read ONCE, by tc_ctx_create -- never on the launch path. */
 int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8);
 const char* tc_version(void);
 

@@ -577,7 +577,9 @@ int tc_ctx_get_tuning(const tc_ctx* ctx, uint64_t* out8) try {
   out8[2] = (uint64_t)ctx->tuning.pairing_form;
   out8[3] = ctx->tuning.pairing_budget;
   out8[4] = (uint64_t)ctx->tuning.checks_beside;
-  out8[5] = out8[6] = out8[7] = 0;  // reserved
+  out8[5] = ctx->tuning.msm_budget;
+  out8[6] = ctx->tuning.private_reserve;  // ~0 = by the size of the call
+  out8[7] = 0;  // reserved
   return TC_OK;
 } catch (...) {
   return on_exception((tc_ctx*)ctx);

@@ -100,13 +100,14 @@ class Engine:
         """the form choices of this context (tc_ctx_get_tuning): jobs from which a checked G2 decode / a hash takes two jobs per
         lane pair, the pairing form (0 = by batch size), the line-buffer budget (0 = a third of the free HBM), whether the membership
         tests of checked-input mode run beside the main kernels on a second stream.  Fixed when the context was created (defaults, or
-        TC_DUO_MIN / TC_PAIRING_FORM / TC_PAIRING_BUDGET / TC_CHECKS_BESIDE in the environment at that moment)."""
+        TC_DUO_MIN / TC_PAIRING_FORM / TC_PAIRING_BUDGET / TC_CHECKS_BESIDE / TC_MSM_BUDGET / TC_PRIVATE_RESERVE in the environment at that
+        moment)."""
         out = (ctypes.c_uint64 * 8)()
         rc = self._lib.tc_ctx_get_tuning(self._ctx, out)
         if rc != 0:
             raise TcError(rc, "tc_ctx_get_tuning")
         return {"duo_min_decode": int(out[0]), "duo_min_hash": int(out[1]), "pairing_form": int(out[2]), "pairing_budget": int(out[3]),
-                "checks_beside": int(out[4])}
+                "checks_beside": int(out[4]), "msm_budget": int(out[5]), "private_reserve": int(out[6])}
 
     def last_kernel_ms(self):
         return float(self._lib.tc_last_kernel_ms(self._ctx))
