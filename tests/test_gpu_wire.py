@@ -429,7 +429,8 @@ def test_two_jobs_per_lane_pair_forms_equal_the_one_job_forms(engine, rnd):
             h = eng.hash_g2(blob, off)
             hg, hst = eng.hash_g1_g2(g1_a, blob, off)
             res[form] = (pts, st, h, hg, hst)
-    assert engine.tuning() == {"duo_min_decode": 32769, "duo_min_hash": 131072, "pairing_form": 0, "pairing_budget": 0, "checks_beside": 1}   # the defaults
+    assert engine.tuning() == {"duo_min_decode": 32769, "duo_min_hash": 131072, "pairing_form": 0, "pairing_budget": 0, "checks_beside": 1,
+                               "msm_budget": 0, "private_reserve": (1 << 64) - 1}   # the defaults
     for x, y in zip(res["two"], res["one"]):
         assert (x == y).all(), np.flatnonzero((x != y).reshape(n, -1).any(axis=1))[:16]
     pts, st, h, hg, hst = res["two"]
