@@ -649,6 +649,8 @@ def test_operand_buffers_beyond_four_gib(engine, sig_workload, combined):
     was = engine.input_checks()
     engine.set_input_checks(False)   # (the operands are this library's own outputs; the default-mode path has its own full-size test)
     try:
+        # (the context runs on its OWN stream: torch's cat / roll kernels above must have finished before the library reads their output)
+        torch.cuda.synchronize()
         out, st = engine.combine_g2(3, idx, sh)
         engine.sync()
         assert not bool(st.any())
@@ -660,6 +662,7 @@ def test_operand_buffers_beyond_four_gib(engine, sig_workload, combined):
         swapped = torch.arange(0, reps * B, 1000003, device="cuda")
         sig = out.clone()
         sig[swapped] = out[swapped + 1]
+        torch.cuda.synchronize()
         ok = engine.verify_g2(torch.from_numpy(wl.master_pk).cuda(), sig, hs)
         engine.sync()
         ok = ok.bool()
@@ -699,6 +702,7 @@ def test_message_blob_beyond_four_gib(engine):
     blob = base.repeat(reps, 1).reshape(-1)
     off = torch.arange(0, reps * B + 1, dtype=torch.int64, device="cuda") * L
     assert blob.numel() > (1 << 32) and int(off[-1]) == blob.numel()
+    torch.cuda.synchronize()                 # (torch's generator / repeat kernels before the library's own stream reads the blob)
     out = engine.hash_g2(blob, off)
     engine.sync()
     first = out[:B]

@@ -629,6 +629,7 @@ def test_in_place_device_calls_keep_the_tests_in_front(engine, rnd):
         d_fr, d_pts = torch.from_numpy(fr).cuda(), torch.from_numpy(pts).cuda()
         d_st = torch.empty((B, 1), dtype=torch.uint8, device="cuda")
         engine._mode(d_fr, d_pts, d_st)
+        torch.cuda.synchronize()
         engine._call("tc_g2_mul_batch", _ptr(d_fr), _ptr(d_pts), 1, B, _ptr(d_pts), _ptr(d_st))      # out == pts
         engine.sync()
         assert (d_st.cpu().numpy() == want_st).all()
@@ -644,6 +645,7 @@ def test_in_place_device_calls_keep_the_tests_in_front(engine, rnd):
     assert want.tolist()[:12] == [1] * 7 + [0, 1, 0, 1, 1]
     d_pk, d_sig, d_h = (torch.from_numpy(x).cuda() for x in (wl.master_pk, sig, wl.hashes))
     engine._mode(d_pk, d_sig, d_h)
+    torch.cuda.synchronize()
     engine._call("tc_verify_g2_batch", _ptr(d_pk), 0, _ptr(d_sig), _ptr(d_h), B, _ptr(d_sig))          # ok == sig
     engine.sync()
     assert (d_sig.reshape(-1)[:B].cpu().numpy() == want).all()
