@@ -36,7 +36,9 @@
  * I/O residency: by default every data pointer is HOST memory and the call stages through
  * device buffers owned by the context.  After tc_ctx_set_device_io(ctx, 1) every data
  * pointer (inputs, outputs, offsets, status, ok) must be DEVICE memory on the context's GPU,
- * 8-byte aligned, and nothing crosses PCIe.  Output buffers should not overlap input buffers: results are written while
+ * 8-byte aligned, and nothing crosses PCIe.  The kernels read and write them on the CONTEXT's stream and a call returns
+ * once they are queued: whatever produced the operands must have finished (or run on the same stream: tc_ctx_set_stream),
+ * and results are read after tc_sync or in stream order.  Output buffers should not overlap input buffers: results are written while
  * other jobs' operands are still being read.  The one supported exception is an output that overlaps a POINT operand of the
  * same call job for job (an in-place tc_g{1,2}_mul_batch with S = 1, ok[] over the head of a buffer the call reads): the
  * membership tests of that operand, which otherwise run beside the call's main kernels on the context's second stream, then
