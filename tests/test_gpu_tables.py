@@ -28,6 +28,30 @@ def oracle_mul(fr, pt):
     return out
 
 
+def _fill_hbm(leave):
+    """torch tensors that take the device's free memory down to about `leave` bytes: one large block, then 256 MB blocks, then
+    whatever is left -- an allocation that fails (the largest free extent shrinks with fragmentation) is retried at half the size."""
+    import torch
+    torch.cuda.empty_cache()
+    hogs = []
+    chunk = None
+    while True:
+        free, _total = torch.cuda.mem_get_info()
+        room = free - leave
+        if room < (4 << 20):
+            break
+        if chunk is None:
+            chunk = max(room - (2 << 30), 256 << 20)
+        try:
+            hogs.append(torch.empty(min(chunk, room), dtype=torch.uint8, device="cuda"))
+            chunk = min(chunk, 256 << 20)
+        except torch.OutOfMemoryError:
+            if chunk <= (4 << 20):
+                break
+            chunk //= 2
+    return hogs
+
+
 @pytest.fixture(scope="module")
 def wl(engine):
     from threshold_crypto_amd.workload import ThresholdSigWorkload
@@ -212,18 +236,7 @@ def test_failed_device_allocation_is_an_error_and_the_context_survives(engine, w
     assert not st.any()
     eng = Engine(0)                      # fresh: no arena, no staging slots yet
     eng.set_input_checks(False)
-    torch.cuda.empty_cache()
-    hogs = []
-    try:
-        free, _total = torch.cuda.mem_get_info()
-        hogs.append(torch.empty(max(free - (1 << 30), 0), dtype=torch.uint8, device="cuda"))      # all but 1 GiB ...
-        while True:                                                                               # ... then down to < 48 MB
-            free, _total = torch.cuda.mem_get_info()
-            if free < (48 << 20):
-                break
-            hogs.append(torch.empty(max(free // 2, 16 << 20), dtype=torch.uint8, device="cuda"))
-    except torch.OutOfMemoryError:
-        pass
+    hogs = _fill_hbm(32 << 20)
     free, _total = torch.cuda.mem_get_info()
     assert free < (200 << 20), "could not fill the HBM (free %d MB)" % (free >> 20)
     try:
@@ -270,18 +283,7 @@ def test_pairing_check_with_the_hbm_nearly_full_takes_the_form_without_a_line_bu
         os.environ.pop("TC_PRIVATE_RESERVE")
     eng.set_input_checks(False)
     assert eng.verify_g2(wl.master_pk, sig[:64], hashes[:64]).sum() == 63       # (the context's small buffers exist now)
-    torch.cuda.empty_cache()
-    hogs = []
-    try:
-        free, _total = torch.cuda.mem_get_info()
-        hogs.append(torch.empty(max(free - (2 << 30), 0), dtype=torch.uint8, device="cuda"))
-        while True:
-            free, _total = torch.cuda.mem_get_info()
-            if free < (700 << 20):
-                break
-            hogs.append(torch.empty(min(free - (600 << 20), 256 << 20), dtype=torch.uint8, device="cuda"))
-    except torch.OutOfMemoryError:
-        pass
+    hogs = _fill_hbm(600 << 20)
     try:
         free, _total = torch.cuda.mem_get_info()
         assert (300 << 20) < free < (1 << 30), "free HBM %d MB" % (free >> 20)
@@ -349,18 +351,7 @@ def test_a_call_the_runtime_could_not_survive_is_turned_away(engine, wl):
     eng.set_input_checks(False)
     out, st = eng.combine_g2(wl.t, idx[:64], shares[:64])
     assert not st.any()
-    torch.cuda.empty_cache()
-    hogs = []
-    try:
-        free, _total = torch.cuda.mem_get_info()
-        hogs.append(torch.empty(max(free - (4 << 30), 0), dtype=torch.uint8, device="cuda"))
-        while True:
-            free, _total = torch.cuda.mem_get_info()
-            if free < (1700 << 20):
-                break
-            hogs.append(torch.empty(min(free - (1500 << 20), 256 << 20), dtype=torch.uint8, device="cuda"))
-    except torch.OutOfMemoryError:
-        pass
+    hogs = _fill_hbm(1500 << 20)
     try:
         free, _total = torch.cuda.mem_get_info()
         assert (1 << 30) < free < (2 << 30), "free HBM %d MB" % (free >> 20)
