@@ -236,7 +236,10 @@ def test_failed_device_allocation_is_an_error_and_the_context_survives(engine, w
     eng.set_input_checks(False)
     hogs = _fill_hbm(32 << 20)
     free, _total = torch.cuda.mem_get_info()
-    assert free < (2 << 30), "could not fill the HBM (free %d MB)" % (free >> 20)
+    if free >= (2 << 30):                 # (a precondition of the test, not a property of the library)
+        del hogs
+        torch.cuda.empty_cache()
+        pytest.skip("could not fill the HBM (free %d MB)" % (free >> 20))
     # a batch whose share buffer ALONE is larger than what is left (the allocator does not always get under a few hundred MB
     # when other contexts of the process hold memory): the staging slot, if not the arena, cannot be allocated
     B = max(256, ((free + (96 << 20)) // (4 * 192) + 255) // 256 * 256)
@@ -291,7 +294,8 @@ def test_pairing_check_with_the_hbm_nearly_full_takes_the_form_without_a_line_bu
     hogs = _fill_hbm(600 << 20)
     try:
         free, _total = torch.cuda.mem_get_info()
-        assert (300 << 20) < free < (1 << 30), "free HBM %d MB" % (free >> 20)
+        if not (300 << 20) < free < (1 << 30):
+            pytest.skip("could not bring the free HBM into 0.3-1 GB (free %d MB)" % (free >> 20))
         got = eng.verify_g2(wl.master_pk, sig, hashes)
     finally:
         del hogs
@@ -359,7 +363,8 @@ def test_a_call_the_runtime_could_not_survive_is_turned_away(engine, wl):
     hogs = _fill_hbm(1500 << 20)
     try:
         free, _total = torch.cuda.mem_get_info()
-        assert (1 << 30) < free < (2 << 30), "free HBM %d MB" % (free >> 20)
+        if not (1 << 30) < free < (2 << 30):
+            pytest.skip("could not bring the free HBM into 1-2 GB (free %d MB)" % (free >> 20))
         with pytest.raises(TcError) as e:
             eng.combine_g2(wl.t, idx, shares)
         assert e.value.code == _native.TC_ERR_HIP and "private segments" in str(e.value), str(e.value)
