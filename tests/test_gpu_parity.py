@@ -376,6 +376,22 @@ def test_empty_batches_and_long_messages(engine, rnd):
     assert engine.pairing_check(np.zeros((0, 96), np.uint8), z8, np.zeros((0, 96), np.uint8), z8, B=0).shape == (0,)
     flat, off = pack_messages([])
     assert engine.hash_g2(flat, off).shape == (0, 192)
+    # the same with device-resident operands: an empty torch tensor has NO address (data_ptr() == 0) -- still a no-op, not an argument error
+    import torch
+
+    def dev(shape, dt=torch.uint8):
+        return torch.empty(shape, dtype=dt, device="cuda")
+    zoff = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert engine.combine_g2(3, dev((0, 4), torch.int64), dev((0, 4, 192)))[0].shape == (0, 192)
+    assert engine.combine_g1(3, dev((0, 4), torch.int64), dev((0, 4, 96)))[0].shape == (0, 96)
+    assert engine.g2_mul(dev((1, 32)), dev((0, 192)))[0].shape == (0, 1, 192)
+    assert engine.verify_g2(dev((96,)), dev((0, 192)), dev((0, 192))).shape == (0,)
+    assert engine.hash_g2(dev((0,)), zoff).shape == (0, 192)
+    assert engine.g2_compress(dev((0, 192)))[0].shape == (0, 96) and engine.g1_decompress(dev((0, 48)))[0].shape == (0, 96)
+    assert engine.decrypt(3, dev((0, 4), torch.int64), dev((0, 4, 96)), dev((0,)), zoff)[0].shape == (0,)
+    assert engine.ciphertext_verify(dev((0, 96)), dev((0,)), zoff, dev((0, 192))).shape == (0,)
+    assert engine.xor_with_hash(dev((0, 96)), dev((0,)), zoff)[0].shape == (0,)
+    engine.sync()
     msgs = [bytes(rnd.randrange(256) for _ in range(n)) for n in (4096, 10000, 136 * 7, 136 * 7 + 1)]
     flat, off = pack_messages(msgs)
     out = engine.hash_g2(flat, off)

@@ -933,6 +933,8 @@ int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t*
 
 int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
                      const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;  // (an empty batch is a no-op for every entry: a device-resident empty buffer has no address)
   TC_REQUIRE(ctx && out && status && off);
   return combine(ctx, false, t, n_per_job, idx, nullptr, shares_g1, B, out /*non-null marker*/, status, v, off, out);
 } catch (...) {
@@ -954,6 +956,8 @@ int tc_combine_g1_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_
 }
 int tc_decrypt_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* idx_fr, const uint8_t* shares_g1, const uint8_t* v,
                         const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;  // (an empty batch is a no-op for every entry: a device-resident empty buffer has no address)
   TC_REQUIRE(ctx && out && status && off);
   return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares_g1, B, out, status, v, off, out);
 } catch (...) {
@@ -970,6 +974,8 @@ int tc_combine_signatures_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, co
 }
 int tc_decrypt_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares48, const uint8_t* v,
                           const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
+  TC_REQUIRE(ctx);
+  if (B == 0) return TC_OK;  // (an empty batch is a no-op for every entry: a device-resident empty buffer has no address)
   TC_REQUIRE(ctx && out && status && off);
   return combine(ctx, false, t, n_per_job, idx, nullptr, shares48, B, out, status, v, off, out, /*wire=*/true);
 } catch (...) {
