@@ -392,6 +392,26 @@ def test_empty_batches_and_long_messages(engine, rnd):
     assert engine.ciphertext_verify(dev((0, 96)), dev((0,)), zoff, dev((0, 192))).shape == (0,)
     assert engine.xor_with_hash(dev((0, 96)), dev((0,)), zoff)[0].shape == (0,)
     engine.sync()
+    # B > 0 jobs whose messages are ALL empty: no message / plaintext / keystream bytes at all, so the device-resident blob, `v`
+    # and plaintext buffers have no address -- encrypt(b""), Ciphertext::verify, SecretKey::decrypt and the threshold decryption
+    # still work and agree with the host-buffer run and the oracle
+    sk = rnd.randrange(1, o.R)
+    pk = g1s([o.E1.mul(o.G1_GEN, sk)])[0]
+    r = np.stack([u8(o.fr_to_bytes(rnd.randrange(1, o.R))) for _ in range(3)])
+    flat0, off0 = pack_messages([b"", b"", b""])
+    u_h, v_h, w_h, st_h = engine.encrypt(pk, r, flat0, off0)
+    assert not st_h.any() and v_h.shape[0] in (0, 1) and engine.ciphertext_verify(u_h, v_h, off0, w_h).all()
+    want_ct = o.encrypt_with_r(o.E1.mul(o.G1_GEN, sk), int.from_bytes(bytes(r[0]), "little"), b"")
+    assert bytes(u_h[0]) == o.g1_uncompressed(want_ct[0]) and bytes(w_h[0]) == o.g2_uncompressed(want_ct[2])
+    d_off0 = torch.from_numpy(off0.astype(np.int64)).cuda()
+    u_d, v_d, w_d, st_d = engine.encrypt(torch.from_numpy(pk).cuda(), torch.from_numpy(r).cuda(), dev((0,)), d_off0)
+    engine.sync()
+    assert (u_d.cpu().numpy() == u_h).all() and (w_d.cpu().numpy() == w_h).all() and not st_d.cpu().numpy().any()
+    fr_sk = torch.from_numpy(u8(o.fr_to_bytes(sk))).cuda()
+    plain_d, ok_d = engine.secret_key_decrypt(fr_sk, u_d, dev((0,)), d_off0, w_d)
+    x_d, stx = engine.xor_with_hash(u_d, dev((0,)), d_off0)
+    engine.sync()
+    assert ok_d.cpu().numpy().all() and plain_d.shape == (0,) and not stx.cpu().numpy().any()
     msgs = [bytes(rnd.randrange(256) for _ in range(n)) for n in (4096, 10000, 136 * 7, 136 * 7 + 1)]
     flat, off = pack_messages(msgs)
     out = engine.hash_g2(flat, off)

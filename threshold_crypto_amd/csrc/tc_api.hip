@@ -831,7 +831,8 @@ static int not_enough_shares(Call& k, size_t B, uint8_t* out, size_t out_bytes, 
 // idx_fr != nullptr: the abscissae as 32-byte Fr values (idx unused); wire: the shares arrive compressed (48 / 96 B, checked
 // decode) and a G2 result leaves compressed
 static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx, const uint8_t* idx_fr, const uint8_t* shares, size_t B,
-                   uint8_t* out, uint8_t* status, const uint8_t* v, const uint64_t* off, uint8_t* plain, bool wire = false) {
+                   uint8_t* out, uint8_t* status, const uint8_t* v, const uint64_t* off, uint8_t* plain, bool wire = false,
+                   bool plain_unbacked = false) {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && out && status);
@@ -846,6 +847,7 @@ static int combine(tc_ctx* ctx, bool g2, size_t t, size_t n, const uint64_t* idx
     TC_REQUIRE(off);
     if (!total_bytes(k, off, B, &total)) return k.finish();
     TC_REQUIRE(total == 0 || v);
+    TC_REQUIRE(total == 0 || !plain_unbacked);  // (a null plaintext buffer is only acceptable when there is nothing to write)
   }
   const uint64_t* d_idx = idx_fr ? nullptr : k.in(idx, B * n);
   const uint32_t* d_idx_fr = idx_fr ? reinterpret_cast<const uint32_t*>(k.in(idx_fr, B * n * 32)) : nullptr;
@@ -931,12 +933,18 @@ int tc_combine_g1_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t*
   return on_exception((tc_ctx*)ctx);
 }
 
+// The plaintext buffer of a batch whose plaintexts are ALL empty has no address when it is device-resident (an empty tensor's
+// data pointer is null): the decrypt entries then stand a private byte in for it -- never written, combine() insists that the
+// total length is 0 -- so that `SecretKey::decrypt(encrypt(b""))` works with either residency.
+static uint8_t g_no_plaintext_bytes;
 int tc_decrypt_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_t* idx, const uint8_t* shares_g1,
                      const uint8_t* v, const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;  // (an empty batch is a no-op for every entry: a device-resident empty buffer has no address)
-  TC_REQUIRE(ctx && out && status && off);
-  return combine(ctx, false, t, n_per_job, idx, nullptr, shares_g1, B, out /*non-null marker*/, status, v, off, out);
+  TC_REQUIRE(ctx && status && off);
+  const bool unbacked = out == nullptr;
+  if (unbacked) out = &g_no_plaintext_bytes;
+  return combine(ctx, false, t, n_per_job, idx, nullptr, shares_g1, B, out /*non-null marker*/, status, v, off, out, /*wire=*/false, unbacked);
 } catch (...) {
   return on_exception((tc_ctx*)ctx);
 }
@@ -958,8 +966,10 @@ int tc_decrypt_fr_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint8_t* 
                         const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;  // (an empty batch is a no-op for every entry: a device-resident empty buffer has no address)
-  TC_REQUIRE(ctx && out && status && off);
-  return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares_g1, B, out, status, v, off, out);
+  TC_REQUIRE(ctx && status && off);
+  const bool unbacked = out == nullptr;
+  if (unbacked) out = &g_no_plaintext_bytes;
+  return combine(ctx, false, t, n_per_job, nullptr, idx_fr, shares_g1, B, out, status, v, off, out, /*wire=*/false, unbacked);
 } catch (...) {
   return on_exception((tc_ctx*)ctx);
 }
@@ -976,8 +986,10 @@ int tc_decrypt_wire_batch(tc_ctx* ctx, size_t t, size_t n_per_job, const uint64_
                           const uint64_t* off, size_t B, uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;  // (an empty batch is a no-op for every entry: a device-resident empty buffer has no address)
-  TC_REQUIRE(ctx && out && status && off);
-  return combine(ctx, false, t, n_per_job, idx, nullptr, shares48, B, out, status, v, off, out, /*wire=*/true);
+  TC_REQUIRE(ctx && status && off);
+  const bool unbacked = out == nullptr;
+  if (unbacked) out = &g_no_plaintext_bytes;
+  return combine(ctx, false, t, n_per_job, idx, nullptr, shares48, B, out, status, v, off, out, /*wire=*/true, unbacked);
 } catch (...) {
   return on_exception((tc_ctx*)ctx);
 }
@@ -1034,11 +1046,11 @@ int tc_xor_with_hash_batch(tc_ctx* ctx, const uint8_t* g1, const uint8_t* data, 
                            uint8_t* out, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
-  TC_REQUIRE(ctx && g1 && off && out);
+  TC_REQUIRE(ctx && g1 && off);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
-  TC_REQUIRE(total == 0 || data);
+  TC_REQUIRE(total == 0 || (data && out));  // (all-empty inputs: a device-resident empty buffer has no address)
   const uint8_t* d_g1 = k.in(g1, B * 96);
   const uint8_t* d_data = k.in(data, (size_t)total);
   const uint64_t* d_off = k.in(off, B + 1);
@@ -1428,14 +1440,14 @@ int tc_ciphertext_verify_batch(tc_ctx* ctx, const uint8_t* u, const uint8_t* v, 
 // Ciphertext::verify, then [sk] u for the ciphertexts that pass: SecretKeyShare::decrypt_share (src/lib.rs:452-457) when
 // plain == nullptr, SecretKey::decrypt (src/lib.rs:384-391: the same, then xor_with_hash) otherwise
 static int verified_decrypt(tc_ctx* ctx, const uint8_t* sk, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
-                            size_t B, uint8_t* out_g1, uint8_t* plain, uint8_t* ok) {
+                            size_t B, uint8_t* out_g1, uint8_t* plain, uint8_t* ok, bool plain_unbacked = false) {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
   TC_REQUIRE(ctx && sk && u && off && w && ok && (out_g1 || plain));
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
-  TC_REQUIRE(total == 0 || v);
+  TC_REQUIRE(total == 0 || (v && !plain_unbacked));
   const uint8_t* d_sk = k.in(sk, 32, /*secret=*/true);
   const uint8_t* d_u = k.in(u, B * 96);
   const uint8_t* d_v = k.in(v, (size_t)total);
@@ -1479,8 +1491,10 @@ int tc_decrypt_share_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u, 
 
 int tc_secret_key_decrypt_batch(tc_ctx* ctx, const uint8_t* sk_fr, const uint8_t* u, const uint8_t* v, const uint64_t* off, const uint8_t* w,
                                 size_t B, uint8_t* out, uint8_t* ok) try {
-  TC_REQUIRE(ctx && (B == 0 || out));
-  return verified_decrypt(ctx, sk_fr, u, v, off, w, B, nullptr, out, ok);
+  TC_REQUIRE(ctx);
+  const bool unbacked = out == nullptr;  // (all-empty plaintexts, device-resident: see g_no_plaintext_bytes)
+  if (unbacked) out = &g_no_plaintext_bytes;
+  return verified_decrypt(ctx, sk_fr, u, v, off, w, B, nullptr, out, ok, unbacked);
 } catch (...) {
   return on_exception((tc_ctx*)ctx);
 }
@@ -1780,12 +1794,12 @@ int tc_encrypt_batch(tc_ctx* ctx, const uint8_t* pk, size_t pk_stride, const uin
                      const uint64_t* off, size_t B, uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* status) try {
   TC_REQUIRE(ctx);
   if (B == 0) return TC_OK;
-  TC_REQUIRE(ctx && pk && r && off && out_u && out_v && out_w);
+  TC_REQUIRE(ctx && pk && r && off && out_u && out_w);
   TC_REQUIRE(pk_stride == 0 || pk_stride >= 96);
   Call k(ctx);
   uint64_t total = 0;
   if (!total_bytes(k, off, B, &total)) return k.finish();
-  TC_REQUIRE(total == 0 || msgs);
+  TC_REQUIRE(total == 0 || (msgs && out_v));  // (all-empty messages: no v bytes, and a device-resident empty buffer has no address)
   const uint8_t* d_pk = k.in(pk, pk_stride ? (B - 1) * pk_stride + 96 : 96);
   const uint8_t* d_r = k.in(r, B * 32, /*secret=*/true);
   const uint8_t* d_msgs = k.in(msgs, (size_t)total);
