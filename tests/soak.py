@@ -29,6 +29,48 @@ assert e_duo.tuning()["duo_min_hash"] == 1 and e_default.tuning()["duo_min_hash"
 e = e_default
 
 
+class DeviceResident:
+    """The same engine with DEVICE-resident operands (r06): every numpy argument of a call goes up as a torch tensor first, the
+    call runs in device-I/O mode (nothing crosses PCIe inside it, results are written where torch allocated them), and the results
+    come back as numpy arrays -- so that every entry the soak drives is also compared with the oracle in the residency the bench
+    and a GPU-resident caller use.  Scalars, None and Python ints pass through."""
+
+    def __init__(self, eng):
+        self._eng = eng
+
+    def __getattr__(self, name):
+        import torch
+        fn = getattr(self._eng, name)
+        if not callable(fn) or name in ("tuning", "sync", "trim", "close", "version", "set_input_checks", "input_checks"):
+            return fn
+
+        def up(a):
+            if isinstance(a, np.ndarray):
+                return torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else np.ascontiguousarray(a)).cuda()
+            return a
+
+        def down(r):
+            if type(r).__module__.startswith("torch"):
+                return r.cpu().numpy().view(np.uint64) if r.dtype == torch.int64 else r.cpu().numpy()
+            if isinstance(r, tuple):
+                return tuple(down(x) for x in r)
+            return r
+
+        def call(*args, **kw):
+            if not any(isinstance(a, np.ndarray) for a in list(args) + list(kw.values())):
+                return fn(*args, **kw)
+            d_args = [up(a) for a in args]
+            d_kw = {k: up(v) for k, v in kw.items()}
+            torch.cuda.synchronize()        # (the copies above ran on torch's stream, the library runs on the context's)
+            r = fn(*d_args, **d_kw)
+            self._eng.sync()
+            return down(r)
+        return call
+
+
+dev_rounds = 0
+
+
 def u8(b):
     return np.frombuffer(bytes(b), dtype=np.uint8).copy()
 
@@ -74,6 +116,10 @@ while time.time() < t_end:
         duo_rounds += 1
     else:
         e = e_default
+    # r06: every third round with device-resident operands
+    if rnd.randrange(3) == 0:
+        e = DeviceResident(e)
+        dev_rounds += 1
     # ---- scalar multiplication (S signers x B points) -------------------------------------------
     S = rnd.choice([1, 2, 3])
     ks = [rnd.choice([0, 1, o.R - 1, rnd.randrange(o.R), rnd.randrange(1 << 64)]) for _ in range(S)]
@@ -372,4 +418,4 @@ while time.time() < t_end:
             if (std[j] != 0) != (rc2 != 0) or (rc2 == 0 and bytes(d2[j]) != want2):
                 fail("g2_decompress", rounds, j)
     checked += 2 * B
-print("SOAK-OK seed=%d rounds=%d (two-jobs-per-lane-pair forms in %d of them) jobs_checked=%d seconds=%.0f" % (SEED, rounds, duo_rounds, checked, SECONDS), flush=True)
+print("SOAK-OK seed=%d rounds=%d (two-jobs-per-lane-pair forms in %d of them, device-resident operands in %d) jobs_checked=%d seconds=%.0f" % (SEED, rounds, duo_rounds, dev_rounds, checked, SECONDS), flush=True)
